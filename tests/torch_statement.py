@@ -1,0 +1,108 @@
+"""Independent PyTorch-CPU statement of the call_mods forward pass (TEST INFRASTRUCTURE).
+
+Written separately from oracle/ds_oracle.c, with library ops instead of loops (F.conv1d on NCW
+tensors with explicit asymmetric SAME pads, F.max_pool1d over -inf padding, avg_pool1d with
+count_include_pad=False, an LSTM from raw matmuls in TF gate order i,j,f,o). Two independent
+statements of SURVEY.md Appendix A/B agreeing is the strongest pin available, because TensorFlow 1.x
+itself cannot run here (parity unpinned by the reference).
+
+Reference call sites: deepsignal/model.py:61-108, deepsignal/layers.py:20-264.
+"""
+from __future__ import annotations
+
+from typing import Dict
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from deepsignal_amd import spec
+
+
+def _same(x: torch.Tensor, k: int, s: int, value: float = 0.0) -> torch.Tensor:
+    _, l, r = spec.same_pad(x.shape[-1], k, s)
+    return F.pad(x, (l, r), value=value)
+
+
+def _conv_bn(x, w: Dict[str, torch.Tensor], c: spec.ConvBN):
+    # HWIO [1,K,Cin,Cout] -> torch [Cout,Cin,K]
+    ker = w[c.kernel_name][0].permute(2, 1, 0).contiguous()
+    y = F.conv1d(_same(x, c.k, c.stride), ker, stride=c.stride)
+    g, b = w[c.bn_tensor("gamma")], w[c.bn_tensor("beta")]
+    m, v = w[c.bn_tensor("moving_mean")], w[c.bn_tensor("moving_variance")]
+    y = (y - m[None, :, None]) * (g / torch.sqrt(v + spec.BN_EPS))[None, :, None] + b[None, :, None]
+    return torch.relu(y) if c.relu else y
+
+
+def _maxpool3(x, s):
+    return F.max_pool1d(_same(x, 3, s, value=float("-inf")), 3, stride=s)
+
+
+def _inception(x, w, n, cin):
+    c = spec.inception_convs(n, cin)
+    b1 = _conv_bn(_maxpool3(x, 1), w, c["b1"])
+    b2 = _conv_bn(x, w, c["b2"])
+    b3 = _conv_bn(_conv_bn(x, w, c["b3a"]), w, c["b3b"])
+    b4 = _conv_bn(_conv_bn(x, w, c["b4a"]), w, c["b4b"])
+    stem = _conv_bn(x, w, c["b5s"])
+    r = _conv_bn(_conv_bn(_conv_bn(x, w, c["b5a"]), w, c["b5b"]), w, c["b5c"])
+    b5 = torch.relu(stem + r)
+    return torch.cat([b1, b2, b3, b4, b5], dim=1)
+
+
+def forward(weights: Dict[str, np.ndarray], feats: Dict[str, np.ndarray], dtype=torch.float64,
+            return_taps: bool = False):
+    w = {k: torch.from_numpy(np.asarray(v)).to(dtype) for k, v in weights.items()}
+    kmer = torch.from_numpy(feats["kmer"]).long()
+    n, T = kmer.shape
+    d = spec.net_dims(T, feats["signals"].shape[1], w["dense_1/kernel"].shape[1])
+    taps = {}
+    # --- signal model (NCW) ---
+    x = torch.from_numpy(feats["signals"]).to(dtype)[:, None, :]
+    stem = spec.stem_convs()
+    x = _maxpool3(_conv_bn(x, w, stem[0]), 2)
+    taps["stem_pool"] = x
+    x = _conv_bn(x, w, stem[1]); taps["stem_conv2"] = x
+    x = _conv_bn(x, w, stem[2]); taps["stem_conv3"] = x
+    for m in range(1, spec.N_INCEPTION + 1):
+        x = _inception(x, w, m, d.module_cin(m))
+        taps["module%d" % m] = x
+        if m in (3, 8):
+            x = _maxpool3(x, 2)
+    x = F.avg_pool1d(x, 7, stride=1, padding=3, count_include_pad=False)
+    signal_feat = x.permute(0, 2, 1).reshape(n, -1)          # flatten order (w, c)
+    # --- event model ---
+    emb = w[spec.MODEL_PREFIX + "embedding"][kmer]            # [n,T,128]
+    extra = [torch.from_numpy(feats[k]).to(dtype)[:, :, None] for k in ("means", "stds", "sanums")]
+    x0 = torch.cat([emb] + extra, dim=2)                      # [n,T,131]
+    outs = []
+    for direction in ("fw", "bw"):
+        seq = x0 if direction == "fw" else torch.flip(x0, dims=[1])
+        for layer in range(spec.LSTM_LAYERS):
+            K = w[spec.lstm_tensor(direction, layer, "kernel")]
+            b = w[spec.lstm_tensor(direction, layer, "bias")]
+            h = torch.zeros(n, spec.HIDDEN, dtype=dtype)
+            c = torch.zeros(n, spec.HIDDEN, dtype=dtype)
+            hs = []
+            for t in range(T):
+                z = torch.cat([seq[:, t, :], h], dim=1) @ K + b
+                i, j, f, o = torch.split(z, spec.HIDDEN, dim=1)
+                c = torch.sigmoid(f + spec.FORGET_BIAS) * c + torch.sigmoid(i) * torch.tanh(j)
+                h = torch.sigmoid(o) * torch.tanh(c)
+                hs.append(h)
+            seq = torch.stack(hs, dim=1)
+            taps["lstm_%s_l%d" % (direction, layer)] = seq if direction == "fw" else torch.flip(seq, dims=[1])
+        outs.append(seq[:, -1, :])      # fw: t=T-1 ; bw: last processed step == original t=0
+    joint = torch.cat(outs + [signal_feat], dim=1)
+    fc1 = joint @ w["dense/kernel"]
+    logits = fc1 @ w["dense_1/kernel"]
+    act = torch.sigmoid(logits)
+    pred = torch.argmax(act, dim=1)
+    taps.update(signal_feat=signal_feat, joint=joint, fc1=fc1, logits=logits)
+    if return_taps:
+        out = {}
+        for k, v in taps.items():
+            v = v.permute(0, 2, 1) if (k.startswith("stem") or k.startswith("module")) else v
+            out[k] = v.contiguous().to(torch.float32).numpy()
+        return act.to(torch.float32).numpy(), pred.to(torch.int32).numpy(), out
+    return act.to(torch.float32).numpy(), pred.to(torch.int32).numpy()
