@@ -1,0 +1,995 @@
+// ds_engine.cpp — host side of libdeepsignal_hip.so: handle, weight folding / MFMA operand
+// packing, launch planning (two HIP streams + optional hipGraph) and the extern "C" ABI declared
+// in include/deepsignal_hip.h. The math it schedules restates /root/reference/deepsignal/model.py
+// and layers.py (cited per stage below); nothing here falls back to a CPU path.
+#include "../../include/deepsignal_hip.h"
+#include "ds_internal.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <functional>
+#include <map>
+#include <string>
+#include <vector>
+
+using namespace ds;
+
+namespace {
+
+constexpr int VOCAB = 1024, EMB = 128, HID = 256, NLAYER = 3, NMOD = 11, INC_OUT = 240;
+constexpr double BN_EPS = 1e-3;
+
+thread_local std::string g_create_error;
+
+void same_pad(int in, int k, int s, int* out, int* pl)
+{
+    int o = (in + s - 1) / s;
+    int tot = std::max((o - 1) * s + k - in, 0);
+    *out = o;
+    *pl = tot / 2;
+}
+
+struct HostTensor {
+    std::vector<int64_t> shape;
+    std::vector<float> data;
+};
+
+struct PackedGemm {      // device-resident packed weights of one GEMM
+    float* Bp = nullptr;
+    float* bias = nullptr;
+    int K = 0, N = 0;
+};
+
+enum OpKind { OP_GEMM, OP_STEM1, OP_MAXPOOL, OP_AVGPOOL, OP_HEAD };
+
+struct Op {
+    OpKind kind;
+    int stream;          // 0 = signal/joint stream, 1 = event (BiLSTM) stream
+    int stage;
+    GemmCfg cfg;
+    int launch_index;    // index into the plan's GemmLaunch array
+    int total_tiles;
+    // elementwise params
+    const float* in = nullptr;
+    float* out = nullptr;
+    int a = 0, b = 0, c = 0, d = 0;
+};
+
+struct Stage {
+    std::string name;
+    int stream = 0;
+    int launches = 0;
+    double flops_per_site = 0;
+    double total_ms = 0;
+    int64_t calls = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool pending = false;
+};
+
+struct Plan {
+    int n = 0;
+    std::vector<GemmLaunch> launches;     // host copy
+    GemmLaunch* d_launches = nullptr;
+    std::vector<Op> ops;                  // merged issue order
+    hipGraphExec_t graph = nullptr;
+};
+
+}  // namespace
+
+struct ds_handle {
+    ds_config cfg{};
+    std::string err;
+    int T = 17, S = 360, C = 2;
+    int w1 = 0, wa = 0, wb = 0, wc = 0, J = 0, SF = 0;
+    int pl_conv1 = 0, pl_pool1 = 0, pl_pool2 = 0, pl_pool3 = 0;
+    int B = 512;
+    bool finalized = false;
+    bool debug = false;
+    bool profiling = false;
+    bool use_graph = true;
+    hipStream_t s0 = nullptr, s1 = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    std::map<std::string, HostTensor> host;
+    std::vector<void*> allocs;
+
+    // packed weights
+    float *stem1_w = nullptr, *stem1_b = nullptr;
+    PackedGemm conv2, conv3;
+    PackedGemm m_s1[NMOD], m_b1[NMOD], m_b3b[NMOD], m_b4b[NMOD], m_b5b[NMOD], m_b5c[NMOD];
+    PackedGemm lstm[2][NLAYER];
+    float* lstm_table[2] = {nullptr, nullptr};
+    float* lstm_wfeat[2] = {nullptr, nullptr};
+    PackedGemm fc1;
+    float* fc2 = nullptr;
+
+    // workspace
+    int* d_kmer = nullptr;
+    float *d_means = nullptr, *d_stds = nullptr, *d_sanums = nullptr, *d_signals = nullptr;
+    float *stem_pool = nullptr, *conv2o = nullptr, *conv3o = nullptr;
+    float* modout[NMOD] = {nullptr};
+    float *pool2 = nullptr, *pool3 = nullptr;
+    float *tmpA = nullptr, *tmpS = nullptr, *tmpB = nullptr;
+    float* sigfeat = nullptr;
+    float* H[2][NLAYER] = {{nullptr}};   // [T][B][256]
+    float* Cst[2][NLAYER] = {{nullptr}}; // [B][256]
+    float *fc1o = nullptr, *logits = nullptr, *act = nullptr;
+    int* pred = nullptr;
+
+    std::vector<Stage> stages;
+    std::map<int, Plan> plans;
+    int last_n = 0;
+};
+
+namespace {
+
+int fail(ds_handle* h, int code, const std::string& msg)
+{
+    if (h) h->err = msg; else g_create_error = msg;
+    return code;
+}
+
+#define HIPCHK(h, expr)                                                                                  \
+    do {                                                                                                 \
+        hipError_t e_ = (expr);                                                                          \
+        if (e_ != hipSuccess)                                                                            \
+            return fail(h, DS_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));              \
+    } while (0)
+
+template <class T>
+int dalloc(ds_handle* h, T** p, size_t count)
+{
+    void* q = nullptr;
+    size_t bytes = std::max<size_t>(count * sizeof(T), 256);
+    hipError_t e = hipMalloc(&q, bytes);
+    if (e != hipSuccess) return fail(h, DS_ERR_NOMEM, std::string("hipMalloc: ") + hipGetErrorString(e));
+    h->allocs.push_back(q);
+    *p = static_cast<T*>(q);
+    return DS_OK;
+}
+
+int upload(ds_handle* h, float** dst, const std::vector<float>& v)
+{
+    int rc = dalloc(h, dst, v.size());
+    if (rc) return rc;
+    HIPCHK(h, hipMemcpy(*dst, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice));
+    return DS_OK;
+}
+
+// Pack a logical [K][N] matrix into MFMA-fragment order: [ntile][kgroup][lane][4] where
+// lane (j = lane&31, half = lane>>5) element s holds W[kgroup*8 + 4*half + s][ntile*32 + j].
+std::vector<float> pack_b(int K, int N, const std::function<float(int, int)>& w)
+{
+    const int ntiles = (N + 31) / 32, kg = K / 8;
+    std::vector<float> out((size_t)ntiles * kg * 256, 0.0f);
+    for (int nt = 0; nt < ntiles; ++nt)
+        for (int g = 0; g < kg; ++g)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int col = nt * 32 + (lane & 31);
+                if (col >= N) continue;
+                const int k0 = g * 8 + 4 * (lane >> 5);
+                float* o = &out[(((size_t)nt * kg + g) * 64 + lane) * 4];
+                for (int s = 0; s < 4; ++s) o[s] = w(k0 + s, col);
+            }
+    return out;
+}
+
+struct FoldedConv {     // BN folded into the kernel: y = conv(x, w') + b'   (layers.py:80-84)
+    int k, cin, cout;
+    std::vector<float> w;   // [k*cin][cout]
+    std::vector<float> b;   // [cout]
+};
+
+const HostTensor* find(ds_handle* h, const std::string& name)
+{
+    auto it = h->host.find(name);
+    return it == h->host.end() ? nullptr : &it->second;
+}
+
+int fold_conv(ds_handle* h, const std::string& scope, const std::string& conv, const std::string& bn, int k, int cin,
+              int cout, FoldedConv* out)
+{
+    const HostTensor* ker = find(h, scope + "/" + conv + "/kernel");
+    const HostTensor* beta = find(h, scope + "/" + bn + "/beta");
+    const HostTensor* gamma = find(h, scope + "/" + bn + "/gamma");
+    const HostTensor* mean = find(h, scope + "/" + bn + "/moving_mean");
+    const HostTensor* var = find(h, scope + "/" + bn + "/moving_variance");
+    if (!ker || !beta || !gamma || !mean || !var)
+        return fail(h, DS_ERR_INVALID, "missing tensor(s) under " + scope + "/" + conv);
+    if ((int64_t)ker->data.size() != (int64_t)k * cin * cout || (int)beta->data.size() != cout)
+        return fail(h, DS_ERR_INVALID, "bad shape for " + scope + "/" + conv);
+    out->k = k; out->cin = cin; out->cout = cout;
+    out->w.resize((size_t)k * cin * cout);
+    out->b.resize(cout);
+    std::vector<double> sc(cout);
+    for (int c = 0; c < cout; ++c) {
+        sc[c] = (double)gamma->data[c] / std::sqrt((double)var->data[c] + BN_EPS);
+        out->b[c] = (float)((double)beta->data[c] - (double)mean->data[c] * sc[c]);
+    }
+    for (size_t r = 0; r < (size_t)k * cin; ++r)
+        for (int c = 0; c < cout; ++c) out->w[r * cout + c] = (float)((double)ker->data[r * cout + c] * sc[c]);
+    return DS_OK;
+}
+
+// upload a GEMM whose columns are the concatenation of several folded convs with identical K
+int upload_concat(ds_handle* h, const std::vector<const FoldedConv*>& parts, PackedGemm* pg)
+{
+    const int K = parts[0]->k * parts[0]->cin;
+    int N = 0;
+    for (auto* p : parts) N += p->cout;
+    std::vector<int> owner(N), local(N);
+    int c0 = 0;
+    for (size_t i = 0; i < parts.size(); ++i) {
+        for (int c = 0; c < parts[i]->cout; ++c) { owner[c0 + c] = (int)i; local[c0 + c] = c; }
+        c0 += parts[i]->cout;
+    }
+    std::vector<float> packed = pack_b(K, N, [&](int k, int col) {
+        const FoldedConv* p = parts[owner[col]];
+        return p->w[(size_t)k * p->cout + local[col]];
+    });
+    std::vector<float> bias(N);
+    for (int col = 0; col < N; ++col) bias[col] = parts[owner[col]]->b[local[col]];
+    pg->K = K; pg->N = N;
+    int rc = upload(h, &pg->Bp, packed);
+    if (rc) return rc;
+    return upload(h, &pg->bias, bias);
+}
+
+std::string mod_root(int n)
+{
+    char buf[128];
+    snprintf(buf, sizeof buf, "modelsignalmincp_layer%d/modelsignalm%d", n, n);
+    return buf;
+}
+
+int finalize_weights(ds_handle* h)
+{
+    // ---- stem (layers.py:183-203) ----
+    FoldedConv c1, c2, c3;
+    int rc;
+    if ((rc = fold_conv(h, "modelsignalmconv_layer1", "conv", "bn", 7, 1, 64, &c1))) return rc;
+    if ((rc = fold_conv(h, "modelsignalmconv_layer2", "conv", "bn", 1, 64, 128, &c2))) return rc;
+    if ((rc = fold_conv(h, "modelsignalmconv_layer3", "conv", "bn", 3, 128, 256, &c3))) return rc;
+    if ((rc = upload(h, &h->stem1_w, c1.w))) return rc;
+    if ((rc = upload(h, &h->stem1_b, c1.b))) return rc;
+    if ((rc = upload_concat(h, {&c2}, &h->conv2))) return rc;
+    if ((rc = upload_concat(h, {&c3}, &h->conv3))) return rc;
+    // ---- inception modules (layers.py:87-139) ----
+    for (int m = 0; m < NMOD; ++m) {
+        const int cin = m == 0 ? 256 : INC_OUT;
+        const std::string r = mod_root(m + 1);
+        FoldedConv b1, b2, b3a, b3b, b4a, b4b, b5s, b5a, b5b, b5c;
+        if ((rc = fold_conv(h, r + "branch1_maxpooling", "conv1a_1x1", "bn", 1, cin, 48, &b1))) return rc;
+        if ((rc = fold_conv(h, r + "branch2_1x1", "conv0b_1x1", "bn", 1, cin, 48, &b2))) return rc;
+        if ((rc = fold_conv(h, r + "branch3_1x3", "conv0c_1x1", "bn1", 1, cin, 32, &b3a))) return rc;
+        if ((rc = fold_conv(h, r + "branch3_1x3", "conv1c_1x3", "bn2", 3, 32, 48, &b3b))) return rc;
+        if ((rc = fold_conv(h, r + "branch4_1x5", "conv0d_1x1", "bn1", 1, cin, 32, &b4a))) return rc;
+        if ((rc = fold_conv(h, r + "branch4_1x5", "conv1d_1x5", "bn2", 5, 32, 48, &b4b))) return rc;
+        if ((rc = fold_conv(h, r + "branch5_residual_1x3", "convstem_1x1", "bn0", 1, cin, 48, &b5s))) return rc;
+        if ((rc = fold_conv(h, r + "branch5_residual_1x3", "conv0e_1x1", "bn1", 1, cin, 32, &b5a))) return rc;
+        if ((rc = fold_conv(h, r + "branch5_residual_1x3", "conv1e_1x3", "bn2", 3, 32, 64, &b5b))) return rc;
+        if ((rc = fold_conv(h, r + "branch5_residual_1x3", "conv2e_1x1", "bn3", 1, 64, 48, &b5c))) return rc;
+        // the five 1x1 convs that read the module input share one GEMM: [b2 | b5s | b3a | b4a | b5a]
+        if ((rc = upload_concat(h, {&b2, &b5s, &b3a, &b4a, &b5a}, &h->m_s1[m]))) return rc;
+        if ((rc = upload_concat(h, {&b1}, &h->m_b1[m]))) return rc;
+        if ((rc = upload_concat(h, {&b3b}, &h->m_b3b[m]))) return rc;
+        if ((rc = upload_concat(h, {&b4b}, &h->m_b4b[m]))) return rc;
+        if ((rc = upload_concat(h, {&b5b}, &h->m_b5b[m]))) return rc;
+        if ((rc = upload_concat(h, {&b5c}, &h->m_b5c[m]))) return rc;
+    }
+    // ---- BiLSTM (layers.py:45-72; TF LSTMCell kernel rows = [input ; h], columns = [i j f o]) ----
+    const HostTensor* emb = find(h, "modelembedding");
+    if (!emb || (int64_t)emb->data.size() != (int64_t)VOCAB * EMB) return fail(h, DS_ERR_INVALID, "missing modelembedding");
+    float* d_emb = nullptr;
+    if ((rc = upload(h, &d_emb, emb->data))) return rc;
+    const char* dirs[2] = {"fw", "bw"};
+    for (int d = 0; d < 2; ++d)
+        for (int l = 0; l < NLAYER; ++l) {
+            char nm[160];
+            snprintf(nm, sizeof nm, "modelem/%s/multi_rnn_cell/cell_%d/lstm_cell/kernel", dirs[d], l);
+            const HostTensor* ker = find(h, nm);
+            snprintf(nm, sizeof nm, "modelem/%s/multi_rnn_cell/cell_%d/lstm_cell/bias", dirs[d], l);
+            const HostTensor* bias = find(h, nm);
+            const int in = l == 0 ? EMB + 3 : HID;
+            if (!ker || !bias || (int64_t)ker->data.size() != (int64_t)(in + HID) * 4 * HID || bias->data.size() != 4 * HID)
+                return fail(h, DS_ERR_INVALID, std::string("missing/bad LSTM tensor ") + nm);
+            const float* kd = ker->data.data();
+            // rows fed through the MFMA GEMM: layer 0 -> only the h rows (x part is table + 3 rank-1 terms)
+            const int row0 = l == 0 ? EMB + 3 : 0;
+            const int K = l == 0 ? HID : 2 * HID;
+            // packed n-tile p = ug*4 + g  <->  TF columns g*256 + ug*32 + [0,32)
+            std::vector<float> packed = pack_b(K, 4 * HID, [&](int k, int pc) {
+                const int p = pc / 32, j = pc % 32, ug = p / 4, g = p % 4;
+                return kd[(size_t)(row0 + k) * 4 * HID + g * HID + ug * 32 + j];
+            });
+            h->lstm[d][l].K = K; h->lstm[d][l].N = 4 * HID;
+            if ((rc = upload(h, &h->lstm[d][l].Bp, packed))) return rc;
+            if ((rc = upload(h, &h->lstm[d][l].bias, bias->data))) return rc;
+            if (l == 0) {
+                // embedding folded into W_x: table[v] = emb[v] @ kernel[0:128]   (model.py:61-69)
+                float* d_k0 = nullptr;
+                std::vector<float> k0(kd, kd + (size_t)EMB * 4 * HID);
+                if ((rc = upload(h, &d_k0, k0))) return rc;
+                if ((rc = dalloc(h, &h->lstm_table[d], (size_t)VOCAB * 4 * HID))) return rc;
+                HIPCHK(h, launch_embed_table(d_emb, d_k0, h->lstm_table[d], VOCAB, EMB, 4 * HID, h->s0));
+                std::vector<float> wf(kd + (size_t)EMB * 4 * HID, kd + (size_t)(EMB + 3) * 4 * HID);
+                if ((rc = upload(h, &h->lstm_wfeat[d], wf))) return rc;
+            }
+        }
+    // ---- joint FC (layers.py:247-264) ----
+    const HostTensor* w1 = find(h, "dense/kernel");
+    const HostTensor* w2 = find(h, "dense_1/kernel");
+    const int J = h->J;
+    if (!w1 || !w2 || (int64_t)w1->data.size() != (int64_t)J * J || (int64_t)w2->data.size() != (int64_t)J * h->C)
+        return fail(h, DS_ERR_INVALID, "missing/bad dense kernels");
+    {
+        const float* wd = w1->data.data();
+        std::vector<float> packed = pack_b(J, J, [&](int k, int col) { return wd[(size_t)k * J + col]; });
+        h->fc1.K = J; h->fc1.N = J;
+        if ((rc = upload(h, &h->fc1.Bp, packed))) return rc;
+        h->fc1.bias = nullptr;
+        if ((rc = upload(h, &h->fc2, w2->data))) return rc;
+    }
+    HIPCHK(h, hipStreamSynchronize(h->s0));
+    h->host.clear();
+    h->finalized = true;
+    return DS_OK;
+}
+
+int alloc_workspace(ds_handle* h)
+{
+    const size_t B = h->B;
+    int rc = 0;
+    auto A = [&](auto** p, size_t count) { if (!rc) rc = dalloc(h, p, count); };
+    A(&h->d_kmer, B * h->T); A(&h->d_means, B * h->T); A(&h->d_stds, B * h->T); A(&h->d_sanums, B * h->T);
+    A(&h->d_signals, B * h->S);
+    A(&h->stem_pool, B * h->wa * 64); A(&h->conv2o, B * h->wa * 128); A(&h->conv3o, B * h->wa * 256);
+    A(&h->pool2, B * h->wb * INC_OUT); A(&h->pool3, B * h->wc * INC_OUT);
+    A(&h->tmpA, B * h->wa * 96); A(&h->tmpS, B * h->wa * 48); A(&h->tmpB, B * h->wa * 64);
+    A(&h->sigfeat, B * h->SF);
+    for (int d = 0; d < 2; ++d)
+        for (int l = 0; l < NLAYER; ++l) { A(&h->H[d][l], (size_t)h->T * B * HID); A(&h->Cst[d][l], B * HID); }
+    A(&h->fc1o, B * h->J); A(&h->logits, B * h->C); A(&h->act, B * h->C); A(&h->pred, B);
+    // module outputs: ping-pong pair normally; one buffer per module in debug mode (for taps)
+    const int nbuf = h->debug ? NMOD : 2;
+    float* bufs[NMOD] = {nullptr};
+    for (int i = 0; i < nbuf; ++i) A(&bufs[i], B * h->wa * INC_OUT);
+    for (int m = 0; m < NMOD; ++m) h->modout[m] = bufs[h->debug ? m : (m & 1)];
+    return rc;
+}
+
+int module_width(const ds_handle* h, int m) { return m < 3 ? h->wa : (m < 8 ? h->wb : h->wc); }
+
+void add_tiles(GemmLaunch& L, GemmProblem& P, GemmCfg cfg)
+{
+    const TileGeom g = gemm_geom(cfg);
+    P.tiles_m = (P.M + g.bm - 1) / g.bm;
+    P.tiles_n = (P.N + g.bn - 1) / g.bn;
+    P.ntiles32 = (P.N + 31) / 32;
+    P.tile_start = L.total_tiles;
+    L.total_tiles += P.tiles_m * P.tiles_n;
+    L.prob[L.nprob++] = P;
+}
+
+GemmProblem base_problem(int M, int N, int W, const PackedGemm& pg)
+{
+    GemmProblem P;
+    memset(&P, 0, sizeof P);
+    P.M = M; P.N = N; P.W = W;
+    P.Bp = pg.Bp; P.bias = pg.bias;
+    P.kgroups_stride = pg.K / 8;
+    return P;
+}
+
+void add_seg(GemmProblem& P, const float* base, int ld, int shift, int klen)
+{
+    ASeg& s = P.seg[P.nseg++];
+    s.base = base; s.ld = ld; s.row_shift = shift; s.klen = klen;
+    P.K += klen;
+}
+
+void add_out(GemmProblem& P, float* base, int ld, int col0, int ncols, int relu, const float* add = nullptr, int add_ld = 0)
+{
+    OSeg& o = P.out[P.nout++];
+    o.base = base; o.ld = ld; o.col0 = col0; o.ncols = ncols; o.relu = relu; o.add = add; o.add_ld = add_ld;
+}
+
+int stage_id(ds_handle* h, const std::string& name, int stream)
+{
+    for (size_t i = 0; i < h->stages.size(); ++i)
+        if (h->stages[i].name == name) return (int)i;
+    Stage s;
+    s.name = name; s.stream = stream;
+    h->stages.push_back(s);
+    return (int)h->stages.size() - 1;
+}
+
+int build_plan(ds_handle* h, int n, Plan* plan)
+{
+    plan->n = n;
+    std::vector<Op> cnn, rnn;
+    auto& LS = plan->launches;
+    const bool first_plan = h->plans.empty();
+    auto add_gemm_op = [&](std::vector<Op>& list, int stream, int stage, GemmCfg cfg, const GemmLaunch& L) {
+        Op op{};
+        op.kind = OP_GEMM; op.stream = stream; op.stage = stage; op.cfg = cfg;
+        op.launch_index = (int)LS.size(); op.total_tiles = L.total_tiles;
+        LS.push_back(L);
+        list.push_back(op);
+        if (first_plan) {
+            h->stages[stage].launches += 1;
+            for (int i = 0; i < L.nprob; ++i)
+                h->stages[stage].flops_per_site += 2.0 * L.prob[i].M * (double)L.prob[i].N * L.prob[i].K / n;
+        }
+    };
+    auto add_ew_op = [&](std::vector<Op>& list, Op op) {
+        list.push_back(op);
+        if (first_plan) h->stages[op.stage].launches += 1;
+    };
+
+    // ================= signal model (stream 0) — layers.py:181-239 =================
+    int st = stage_id(h, "stem", 0);
+    {
+        Op op{};
+        op.kind = OP_STEM1; op.stream = 0; op.stage = st; op.in = h->d_signals; op.out = h->stem_pool;
+        add_ew_op(cnn, op);
+        if (first_plan) h->stages[st].flops_per_site += 2.0 * h->w1 * 7 * 64;
+        const int M = n * h->wa;
+        GemmLaunch L{};
+        GemmProblem P = base_problem(M, 128, h->wa, h->conv2);                 // conv_layer2 1x1 (layers.py:192-197)
+        add_seg(P, h->stem_pool, 64, 0, 64);
+        add_out(P, h->conv2o, 128, 0, 128, 1);
+        add_tiles(L, P, CFG_CONV);
+        add_gemm_op(cnn, 0, st, CFG_CONV, L);
+        GemmLaunch L3{};
+        GemmProblem P3 = base_problem(M, 256, h->wa, h->conv3);                // conv_layer3 1x3 (layers.py:198-203)
+        for (int t = 0; t < 3; ++t) add_seg(P3, h->conv2o, 128, t - 1, 128);
+        add_out(P3, h->conv3o, 256, 0, 256, 1);
+        add_tiles(L3, P3, CFG_CONV);
+        add_gemm_op(cnn, 0, st, CFG_CONV, L3);
+    }
+    const float* x = h->conv3o;
+    int cin = 256;
+    for (int m = 0; m < NMOD; ++m) {
+        char nm[32];
+        snprintf(nm, sizeof nm, "module%d", m + 1);
+        st = stage_id(h, nm, 0);
+        const int W = module_width(h, m), M = n * W;
+        float* y = h->modout[m];
+        {   // five 1x1 convs on the module input + branch1 (maxpool on load)   layers.py:90-101,103,112,121-126
+            GemmLaunch L{};
+            GemmProblem P = base_problem(M, 192, W, h->m_s1[m]);
+            add_seg(P, x, cin, 0, cin);
+            add_out(P, y + 48, INC_OUT, 0, 48, 1);          // branch2
+            add_out(P, h->tmpS, 48, 48, 48, 0);             // branch5 stem (BN, no ReLU)
+            add_out(P, h->tmpA, 96, 96, 96, 1);             // b3a | b4a | b5a
+            add_tiles(L, P, CFG_CONV);
+            GemmProblem Q = base_problem(M, 48, W, h->m_b1[m]);
+            Q.a_mode = 1;
+            add_seg(Q, x, cin, 0, cin);
+            add_out(Q, y, INC_OUT, 0, 48, 1);               // branch1
+            add_tiles(L, Q, CFG_CONV);
+            add_gemm_op(cnn, 0, st, CFG_CONV, L);
+        }
+        {   // second-stage convs from the 32-channel intermediates             layers.py:106-110,115-119,127-131
+            GemmLaunch L{};
+            GemmProblem P = base_problem(M, 48, W, h->m_b3b[m]);
+            for (int t = 0; t < 3; ++t) add_seg(P, h->tmpA + 0, 96, t - 1, 32);
+            add_out(P, y + 96, INC_OUT, 0, 48, 1);
+            add_tiles(L, P, CFG_CONV);
+            GemmProblem Q = base_problem(M, 48, W, h->m_b4b[m]);
+            for (int t = 0; t < 5; ++t) add_seg(Q, h->tmpA + 32, 96, t - 2, 32);
+            add_out(Q, y + 144, INC_OUT, 0, 48, 1);
+            add_tiles(L, Q, CFG_CONV);
+            GemmProblem R = base_problem(M, 64, W, h->m_b5b[m]);
+            for (int t = 0; t < 3; ++t) add_seg(R, h->tmpA + 64, 96, t - 1, 32);
+            add_out(R, h->tmpB, 64, 0, 64, 1);
+            add_tiles(L, R, CFG_CONV);
+            add_gemm_op(cnn, 0, st, CFG_CONV, L);
+        }
+        {   // residual tail: relu(stem + BN(1x1 48 of tmpB))                    layers.py:132-138
+            GemmLaunch L{};
+            GemmProblem P = base_problem(M, 48, W, h->m_b5c[m]);
+            add_seg(P, h->tmpB, 64, 0, 64);
+            add_out(P, y + 192, INC_OUT, 0, 48, 1, h->tmpS, 48);
+            add_tiles(L, P, CFG_CONV);
+            add_gemm_op(cnn, 0, st, CFG_CONV, L);
+        }
+        x = y; cin = INC_OUT;
+        if (m == 2 || m == 7) {   // maxpool_layer2/3                            layers.py:211-213,224-226
+            Op op{};
+            op.kind = OP_MAXPOOL; op.stream = 0; op.stage = stage_id(h, "pools", 0);
+            op.in = y; op.out = m == 2 ? h->pool2 : h->pool3;
+            op.a = W; op.b = m == 2 ? h->wb : h->wc; op.c = m == 2 ? h->pl_pool2 : h->pl_pool3; op.d = INC_OUT;
+            add_ew_op(cnn, op);
+            x = op.out;
+        }
+    }
+    {   // avgpool_layer1 + flatten                                              layers.py:233-238
+        Op op{};
+        op.kind = OP_AVGPOOL; op.stream = 0; op.stage = stage_id(h, "pools", 0);
+        op.in = x; op.out = h->sigfeat; op.a = h->wc; op.d = INC_OUT;
+        add_ew_op(cnn, op);
+    }
+
+    // ================= event model (stream 1) — layers.py:20-72,161-173 =================
+    // Anti-diagonal wavefront: diagonal d runs cells (layer l, step d-l) of both directions in ONE
+    // grouped launch; cell (l,s) depends only on (l-1,s) and (l,s-1), both on diagonal d-1.
+    st = stage_id(h, "bilstm", 1);
+    const int T = h->T;
+    for (int d = 0; d < T + NLAYER - 1; ++d) {
+        GemmLaunch L{};
+        for (int dir = 0; dir < 2; ++dir)
+            for (int l = 0; l < NLAYER; ++l) {
+                const int s = d - l;
+                if (s < 0 || s >= T) continue;
+                const int t = dir == 0 ? s : T - 1 - s;
+                const int tprev = dir == 0 ? t - 1 : t + 1;
+                GemmProblem P = base_problem(n, 4 * HID, n, h->lstm[dir][l]);
+                if (l > 0) add_seg(P, h->H[dir][l - 1] + (size_t)t * h->B * HID, HID, 0, HID);
+                if (s > 0) add_seg(P, h->H[dir][l] + (size_t)tprev * h->B * HID, HID, 0, HID);
+                P.lstm.table = l == 0 ? h->lstm_table[dir] : nullptr;
+                P.lstm.wfeat = h->lstm_wfeat[dir];
+                P.lstm.codes = h->d_kmer; P.lstm.means = h->d_means; P.lstm.stds = h->d_stds; P.lstm.lens = h->d_sanums;
+                P.lstm.c = h->Cst[dir][l];
+                P.lstm.h_out = h->H[dir][l] + (size_t)t * h->B * HID;
+                P.lstm.t = t; P.lstm.T = T; P.lstm.c_zero = s == 0;
+                add_tiles(L, P, CFG_LSTM);
+            }
+        add_gemm_op(rnn, 1, st, CFG_LSTM, L);
+    }
+
+    // ================= joint model (stream 0 after join) — layers.py:247-264 =================
+    std::vector<Op> tail;
+    st = stage_id(h, "fc1", 0);
+    {
+        GemmLaunch L{};
+        GemmProblem P = base_problem(n, h->J, n, h->fc1);
+        // joint = [fw h(T-1) | bw h(0) | signal features]: three A segments, no concat buffer (layers.py:171-172,250-252)
+        add_seg(P, h->H[0][NLAYER - 1] + (size_t)(T - 1) * h->B * HID, HID, 0, HID);
+        add_seg(P, h->H[1][NLAYER - 1] + 0, HID, 0, HID);
+        add_seg(P, h->sigfeat, h->SF, 0, h->SF);
+        add_out(P, h->fc1o, h->J, 0, h->J, 0);
+        add_tiles(L, P, CFG_FC);
+        add_gemm_op(tail, 0, st, CFG_FC, L);
+    }
+    st = stage_id(h, "head", 0);
+    {
+        Op op{};
+        op.kind = OP_HEAD; op.stream = 0; op.stage = st;
+        add_ew_op(tail, op);
+        if (first_plan) h->stages[st].flops_per_site += 2.0 * h->J * h->C;
+    }
+
+    // merged issue order: alternate the two independent branches, then the tail
+    size_t i = 0, j = 0;
+    while (i < cnn.size() || j < rnn.size()) {
+        if (i < cnn.size()) plan->ops.push_back(cnn[i++]);
+        if (j < rnn.size()) plan->ops.push_back(rnn[j++]);
+    }
+    for (auto& op : tail) plan->ops.push_back(op);
+
+    void* p = nullptr;
+    HIPCHK(h, hipMalloc(&p, LS.size() * sizeof(GemmLaunch)));
+    h->allocs.push_back(p);
+    plan->d_launches = static_cast<GemmLaunch*>(p);
+    HIPCHK(h, hipMemcpy(p, LS.data(), LS.size() * sizeof(GemmLaunch), hipMemcpyHostToDevice));
+    return DS_OK;
+}
+
+int issue_op(ds_handle* h, Plan& plan, const Op& op, hipStream_t s)
+{
+    const int n = plan.n;
+    switch (op.kind) {
+    case OP_GEMM:
+        HIPCHK(h, launch_gemm(op.cfg, plan.d_launches + op.launch_index, op.total_tiles, s));
+        break;
+    case OP_STEM1:
+        HIPCHK(h, launch_stem1(op.in, h->stem1_w, h->stem1_b, op.out, n, h->S, h->w1, h->pl_conv1, h->wa, h->pl_pool1, s));
+        break;
+    case OP_MAXPOOL:
+        HIPCHK(h, launch_maxpool_s2(op.in, op.out, n, op.a, op.b, op.c, op.d, s));
+        break;
+    case OP_AVGPOOL:
+        HIPCHK(h, launch_avgpool7(op.in, op.out, n, op.a, op.d, s));
+        break;
+    case OP_HEAD:
+        HIPCHK(h, launch_head(h->fc1o, h->fc2, h->logits, h->act, h->pred, n, h->J, h->C, s));
+        break;
+    }
+    return DS_OK;
+}
+
+// Enqueue the whole forward on (s0, s1): fork after the inputs are in place, join before fc1.
+int enqueue_forward(ds_handle* h, Plan& plan, bool timed)
+{
+    HIPCHK(h, hipEventRecord(h->ev_fork, h->s0));
+    HIPCHK(h, hipStreamWaitEvent(h->s1, h->ev_fork, 0));
+    int cur_stage[2] = {-1, -1};
+    bool joined = false;
+    auto close_stage = [&](int stream) -> int {
+        if (timed && cur_stage[stream] >= 0) {
+            Stage& S = h->stages[cur_stage[stream]];
+            HIPCHK(h, hipEventRecord(S.ev1, stream == 0 ? h->s0 : h->s1));
+            S.pending = true;
+        }
+        cur_stage[stream] = -1;
+        return DS_OK;
+    };
+    for (const Op& op : plan.ops) {
+        hipStream_t s = op.stream == 0 ? h->s0 : h->s1;
+        const bool is_tail = h->stages[op.stage].name == "fc1" || h->stages[op.stage].name == "head";
+        if (is_tail && !joined) {
+            int rc = close_stage(0); if (rc) return rc;
+            rc = close_stage(1); if (rc) return rc;
+            HIPCHK(h, hipEventRecord(h->ev_join, h->s1));
+            HIPCHK(h, hipStreamWaitEvent(h->s0, h->ev_join, 0));
+            joined = true;
+        }
+        if (timed && cur_stage[op.stream] != op.stage) {
+            // a stage whose events are still pending (e.g. "pools" runs three separate times) is
+            // flushed first so each interval is accumulated
+            int rc = close_stage(op.stream); if (rc) return rc;
+            Stage& S = h->stages[op.stage];
+            if (S.pending) {
+                HIPCHK(h, hipEventSynchronize(S.ev1));
+                float ms = 0;
+                HIPCHK(h, hipEventElapsedTime(&ms, S.ev0, S.ev1));
+                S.total_ms += ms; S.pending = false;
+            }
+            HIPCHK(h, hipEventRecord(S.ev0, s));
+            cur_stage[op.stream] = op.stage;
+        }
+        int rc = issue_op(h, plan, op, s);
+        if (rc) return rc;
+    }
+    int rc = close_stage(0); if (rc) return rc;
+    rc = close_stage(1); if (rc) return rc;
+    if (!joined) {
+        HIPCHK(h, hipEventRecord(h->ev_join, h->s1));
+        HIPCHK(h, hipStreamWaitEvent(h->s0, h->ev_join, 0));
+    }
+    return DS_OK;
+}
+
+int collect_stage_times(ds_handle* h)
+{
+    for (Stage& S : h->stages) {
+        if (!S.pending) continue;
+        HIPCHK(h, hipEventSynchronize(S.ev1));
+        float ms = 0;
+        HIPCHK(h, hipEventElapsedTime(&ms, S.ev0, S.ev1));
+        S.total_ms += ms;
+        S.pending = false;
+    }
+    return DS_OK;
+}
+
+int get_plan(ds_handle* h, int n, Plan** out)
+{
+    auto it = h->plans.find(n);
+    if (it == h->plans.end()) {
+        Plan p;
+        int rc = build_plan(h, n, &p);
+        if (rc) return rc;
+        it = h->plans.emplace(n, std::move(p)).first;
+        for (Stage& S : h->stages)
+            if (!S.ev0) {
+                HIPCHK(h, hipEventCreate(&S.ev0));
+                HIPCHK(h, hipEventCreate(&S.ev1));
+            }
+    }
+    *out = &it->second;
+    return DS_OK;
+}
+
+// inputs must already be in the handle's device input buffers
+int run_resident(ds_handle* h, int n)
+{
+    Plan* plan = nullptr;
+    int rc = get_plan(h, n, &plan);
+    if (rc) return rc;
+    h->last_n = n;
+    if (h->profiling) {
+        rc = enqueue_forward(h, *plan, true);
+        if (rc) return rc;
+        for (Stage& S : h->stages) S.calls += 1;
+        return DS_OK;
+    }
+    if (h->use_graph) {
+        if (!plan->graph) {
+            hipGraph_t g = nullptr;
+            HIPCHK(h, hipStreamBeginCapture(h->s0, hipStreamCaptureModeThreadLocal));
+            rc = enqueue_forward(h, *plan, false);
+            hipError_t e = hipStreamEndCapture(h->s0, &g);
+            if (rc) { if (g) hipGraphDestroy(g); return rc; }
+            if (e != hipSuccess) return fail(h, DS_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
+            e = hipGraphInstantiate(&plan->graph, g, nullptr, nullptr, 0);
+            hipGraphDestroy(g);
+            if (e != hipSuccess) return fail(h, DS_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e));
+        }
+        HIPCHK(h, hipGraphLaunch(plan->graph, h->s0));
+        return DS_OK;
+    }
+    return enqueue_forward(h, *plan, false);
+}
+
+}  // namespace
+
+// ======================================= C ABI =======================================
+extern "C" {
+
+const char* ds_version(void) { return "deepsignal_amd 0.1 (gfx950, fp32 MFMA)"; }
+
+const char* ds_last_error(const ds_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int ds_create(const ds_config* cfg, ds_handle** out)
+{
+    if (!cfg || !out) return fail(nullptr, DS_ERR_INVALID, "ds_create: null argument");
+    *out = nullptr;
+    if (!(cfg->is_cnn && cfg->is_rnn && cfg->is_base))
+        return fail(nullptr, DS_ERR_UNSUPPORTED, "only the full model (is_cnn=is_rnn=is_base=yes) is implemented");
+    if (cfg->precision != DS_PRECISION_FP32) return fail(nullptr, DS_ERR_UNSUPPORTED, "only fp32 is implemented");
+    if (cfg->kmer_len < 1 || cfg->kmer_len > 255 || (cfg->kmer_len & 1) == 0)
+        return fail(nullptr, DS_ERR_INVALID, "kmer_len must be odd and in [1,255]");
+    if (cfg->signal_len < 16 || cfg->class_num < 1 || cfg->class_num > 16)
+        return fail(nullptr, DS_ERR_INVALID, "bad signal_len/class_num");
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        return fail(nullptr, DS_ERR_HIP, std::string("no HIP device available: ") + hipGetErrorString(e));
+    if (cfg->device < 0 || cfg->device >= ndev) return fail(nullptr, DS_ERR_INVALID, "device ordinal out of range");
+    ds_handle* h = new ds_handle();
+    h->cfg = *cfg;
+    h->T = cfg->kmer_len; h->S = cfg->signal_len; h->C = cfg->class_num;
+    h->B = cfg->max_batch > 0 ? cfg->max_batch : 512;
+    same_pad(h->S, 7, 2, &h->w1, &h->pl_conv1);
+    same_pad(h->w1, 3, 2, &h->wa, &h->pl_pool1);
+    same_pad(h->wa, 3, 2, &h->wb, &h->pl_pool2);
+    same_pad(h->wb, 3, 2, &h->wc, &h->pl_pool3);
+    h->SF = h->wc * INC_OUT;
+    h->J = 2 * HID + h->SF;
+    h->debug = cfg->reserved[0] != 0;
+#define CK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { fail(nullptr, DS_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); ds_destroy(h); return DS_ERR_HIP; } } while (0)
+    CK(hipSetDevice(cfg->device));
+    CK(hipStreamCreateWithFlags(&h->s0, hipStreamNonBlocking));
+    CK(hipStreamCreateWithFlags(&h->s1, hipStreamNonBlocking));
+    CK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+    CK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
+#undef CK
+    int rc = alloc_workspace(h);
+    if (rc) { g_create_error = h->err; ds_destroy(h); return rc; }
+    *out = h;
+    return DS_OK;
+}
+
+void ds_destroy(ds_handle* h)
+{
+    if (!h) return;
+    hipSetDevice(h->cfg.device);
+    if (h->s0) hipStreamSynchronize(h->s0);
+    if (h->s1) hipStreamSynchronize(h->s1);
+    for (auto& kv : h->plans)
+        if (kv.second.graph) hipGraphExecDestroy(kv.second.graph);
+    for (Stage& S : h->stages) { if (S.ev0) hipEventDestroy(S.ev0); if (S.ev1) hipEventDestroy(S.ev1); }
+    for (void* p : h->allocs) hipFree(p);
+    if (h->ev_fork) hipEventDestroy(h->ev_fork);
+    if (h->ev_join) hipEventDestroy(h->ev_join);
+    if (h->s0) hipStreamDestroy(h->s0);
+    if (h->s1) hipStreamDestroy(h->s1);
+    delete h;
+}
+
+int ds_set_tensor(ds_handle* h, const char* name, const float* data, const int64_t* shape, int32_t ndim)
+{
+    if (!h || !name || !data || !shape || ndim < 1 || ndim > 8) return fail(h, DS_ERR_INVALID, "ds_set_tensor: bad argument");
+    if (h->finalized) return fail(h, DS_ERR_INVALID, "weights already finalized");
+    HostTensor t;
+    int64_t cnt = 1;
+    for (int i = 0; i < ndim; ++i) { t.shape.push_back(shape[i]); cnt *= shape[i]; }
+    if (cnt <= 0) return fail(h, DS_ERR_INVALID, "ds_set_tensor: empty tensor");
+    t.data.assign(data, data + cnt);
+    h->host[name] = std::move(t);
+    return DS_OK;
+}
+
+int ds_finalize_weights(ds_handle* h)
+{
+    if (!h) return DS_ERR_INVALID;
+    if (h->finalized) return fail(h, DS_ERR_INVALID, "weights already finalized");
+    hipSetDevice(h->cfg.device);
+    return finalize_weights(h);
+}
+
+int ds_load_weights(ds_handle* h, const char* path)
+{
+    if (!h || !path) return fail(h, DS_ERR_INVALID, "ds_load_weights: bad argument");
+    FILE* f = fopen(path, "rb");
+    if (!f) return fail(h, DS_ERR_IO, std::string("cannot open ") + path);
+    auto bad = [&](const char* why) { fclose(f); return fail(h, DS_ERR_IO, std::string(path) + ": " + why); };
+    char magic[8];
+    uint32_t nt = 0;
+    if (fread(magic, 1, 8, f) != 8 || memcmp(magic, "DSAMDW01", 8) != 0) return bad("not a DSAMDW01 file");
+    if (fread(&nt, 4, 1, f) != 1 || nt > 100000) return bad("bad tensor count");
+    struct Meta { std::string name; std::vector<int64_t> shape; uint64_t off, nbytes; };
+    std::vector<Meta> metas(nt);
+    for (auto& m : metas) {
+        uint16_t ln = 0; uint8_t nd = 0;
+        if (fread(&ln, 2, 1, f) != 1) return bad("truncated header");
+        m.name.resize(ln);
+        if (ln && fread(&m.name[0], 1, ln, f) != ln) return bad("truncated header");
+        if (fread(&nd, 1, 1, f) != 1 || nd > 8) return bad("truncated header");
+        for (int i = 0; i < nd; ++i) { uint32_t d = 0; if (fread(&d, 4, 1, f) != 1) return bad("truncated header"); m.shape.push_back(d); }
+        if (fread(&m.off, 8, 1, f) != 1 || fread(&m.nbytes, 8, 1, f) != 1) return bad("truncated header");
+    }
+    for (auto& m : metas) {
+        HostTensor t;
+        t.shape = m.shape;
+        t.data.resize(m.nbytes / 4);
+        if (fseek(f, (long)m.off, SEEK_SET) != 0 || fread(t.data.data(), 1, m.nbytes, f) != m.nbytes) return bad("truncated payload");
+        h->host[m.name] = std::move(t);
+    }
+    fclose(f);
+    return ds_finalize_weights(h);
+}
+
+int ds_forward_device(ds_handle* h, int32_t n, const int32_t* d_kmer, const float* d_means, const float* d_stds,
+                      const float* d_sanums, const float* d_signals, float* d_act, int32_t* d_pred)
+{
+    if (!h) return DS_ERR_INVALID;
+    if (!h->finalized) return fail(h, DS_ERR_INVALID, "weights not loaded");
+    if (n < 0 || n > h->B) return fail(h, DS_ERR_INVALID, "n exceeds max_batch");
+    if (n == 0) return DS_OK;
+    if (!d_kmer || !d_means || !d_stds || !d_sanums || !d_signals || !d_act || !d_pred)
+        return fail(h, DS_ERR_INVALID, "null buffer");
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    const size_t nt = (size_t)n * h->T;
+    HIPCHK(h, hipMemcpyAsync(h->d_kmer, d_kmer, nt * 4, hipMemcpyDeviceToDevice, h->s0));
+    HIPCHK(h, hipMemcpyAsync(h->d_means, d_means, nt * 4, hipMemcpyDeviceToDevice, h->s0));
+    HIPCHK(h, hipMemcpyAsync(h->d_stds, d_stds, nt * 4, hipMemcpyDeviceToDevice, h->s0));
+    HIPCHK(h, hipMemcpyAsync(h->d_sanums, d_sanums, nt * 4, hipMemcpyDeviceToDevice, h->s0));
+    HIPCHK(h, hipMemcpyAsync(h->d_signals, d_signals, (size_t)n * h->S * 4, hipMemcpyDeviceToDevice, h->s0));
+    int rc = run_resident(h, n);
+    if (rc) return rc;
+    HIPCHK(h, hipMemcpyAsync(d_act, h->act, (size_t)n * h->C * 4, hipMemcpyDeviceToDevice, h->s0));
+    HIPCHK(h, hipMemcpyAsync(d_pred, h->pred, (size_t)n * 4, hipMemcpyDeviceToDevice, h->s0));
+    return DS_OK;
+}
+
+int ds_sync(ds_handle* h)
+{
+    if (!h) return DS_ERR_INVALID;
+    HIPCHK(h, hipStreamSynchronize(h->s0));
+    HIPCHK(h, hipStreamSynchronize(h->s1));
+    if (h->profiling) return collect_stage_times(h);
+    return DS_OK;
+}
+
+int ds_forward(ds_handle* h, int32_t n, const int32_t* kmer, const float* means, const float* stds, const float* sanums,
+               const float* signals, float* act, int32_t* pred)
+{
+    if (!h) return DS_ERR_INVALID;
+    if (!h->finalized) return fail(h, DS_ERR_INVALID, "weights not loaded");
+    if (n < 0) return fail(h, DS_ERR_INVALID, "negative n");
+    if (n == 0) return DS_OK;
+    if (!kmer || !means || !stds || !sanums || !signals || !act || !pred) return fail(h, DS_ERR_INVALID, "null buffer");
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    for (int off = 0; off < n; off += h->B) {
+        const int m = std::min(h->B, n - off);
+        const size_t mt = (size_t)m * h->T, ot = (size_t)off * h->T;
+        HIPCHK(h, hipMemcpyAsync(h->d_kmer, kmer + ot, mt * 4, hipMemcpyHostToDevice, h->s0));
+        HIPCHK(h, hipMemcpyAsync(h->d_means, means + ot, mt * 4, hipMemcpyHostToDevice, h->s0));
+        HIPCHK(h, hipMemcpyAsync(h->d_stds, stds + ot, mt * 4, hipMemcpyHostToDevice, h->s0));
+        HIPCHK(h, hipMemcpyAsync(h->d_sanums, sanums + ot, mt * 4, hipMemcpyHostToDevice, h->s0));
+        HIPCHK(h, hipMemcpyAsync(h->d_signals, signals + (size_t)off * h->S, (size_t)m * h->S * 4, hipMemcpyHostToDevice, h->s0));
+        int rc = run_resident(h, m);
+        if (rc) return rc;
+        HIPCHK(h, hipMemcpyAsync(act + (size_t)off * h->C, h->act, (size_t)m * h->C * 4, hipMemcpyDeviceToHost, h->s0));
+        HIPCHK(h, hipMemcpyAsync(pred + off, h->pred, (size_t)m * 4, hipMemcpyDeviceToHost, h->s0));
+        rc = ds_sync(h);
+        if (rc) return rc;
+    }
+    return DS_OK;
+}
+
+int ds_alloc_host(size_t bytes, void** out)
+{
+    if (!out) return DS_ERR_INVALID;
+    return hipHostMalloc(out, bytes, hipHostMallocDefault) == hipSuccess ? DS_OK : DS_ERR_NOMEM;
+}
+
+int ds_free_host(void* p) { return hipHostFree(p) == hipSuccess ? DS_OK : DS_ERR_HIP; }
+
+int64_t ds_get_intermediate(ds_handle* h, const char* name, float* out, int64_t capacity)
+{
+    if (!h || !name || !out) return DS_ERR_INVALID;
+    const int n = h->last_n;
+    if (n <= 0) return fail(h, DS_ERR_INVALID, "no forward has run");
+    int rc = ds_sync(h);
+    if (rc) return rc;
+    const std::string s(name);
+    auto copy = [&](const float* src, int64_t count) -> int64_t {
+        if (count > capacity) return fail(h, DS_ERR_INVALID, "capacity too small for " + s);
+        if (hipMemcpy(out, src, (size_t)count * 4, hipMemcpyDeviceToHost) != hipSuccess) return fail(h, DS_ERR_HIP, "hipMemcpy D2H");
+        return count;
+    };
+    if (s == "stem_pool") return copy(h->stem_pool, (int64_t)n * h->wa * 64);
+    if (s == "stem_conv2") return copy(h->conv2o, (int64_t)n * h->wa * 128);
+    if (s == "stem_conv3") return copy(h->conv3o, (int64_t)n * h->wa * 256);
+    if (s == "signal_feat") return copy(h->sigfeat, (int64_t)n * h->SF);
+    if (s == "fc1") return copy(h->fc1o, (int64_t)n * h->J);
+    if (s == "logits") return copy(h->logits, (int64_t)n * h->C);
+    if (s.rfind("module", 0) == 0) {
+        const int m = atoi(s.c_str() + 6) - 1;
+        if (m < 0 || m >= NMOD) return fail(h, DS_ERR_INVALID, "bad module index");
+        if (!h->debug && m < NMOD - 2) return fail(h, DS_ERR_INVALID, "module taps need debug mode (cfg.reserved[0]=1)");
+        return copy(h->modout[m], (int64_t)n * module_width(h, m) * INC_OUT);
+    }
+    if (s.rfind("lstm_", 0) == 0 && s.size() == 10) {   // lstm_fw_l0: device layout [T][B][256] -> [n][T][256]
+        const int d = s[5] == 'f' ? 0 : 1, l = s[9] - '0';
+        if (l < 0 || l >= NLAYER) return fail(h, DS_ERR_INVALID, "bad lstm layer");
+        const int64_t count = (int64_t)n * h->T * HID;
+        if (count > capacity) return fail(h, DS_ERR_INVALID, "capacity too small");
+        std::vector<float> tmp((size_t)h->T * h->B * HID);
+        if (hipMemcpy(tmp.data(), h->H[d][l], tmp.size() * 4, hipMemcpyDeviceToHost) != hipSuccess) return fail(h, DS_ERR_HIP, "hipMemcpy D2H");
+        for (int i = 0; i < n; ++i)
+            for (int t = 0; t < h->T; ++t)
+                memcpy(out + ((size_t)i * h->T + t) * HID, tmp.data() + ((size_t)t * h->B + i) * HID, HID * 4);
+        return count;
+    }
+    if (s == "joint") {
+        const int64_t count = (int64_t)n * h->J;
+        if (count > capacity) return fail(h, DS_ERR_INVALID, "capacity too small");
+        std::vector<float> fw((size_t)n * HID), bw((size_t)n * HID), sf((size_t)n * h->SF);
+        hipMemcpy(fw.data(), h->H[0][NLAYER - 1] + (size_t)(h->T - 1) * h->B * HID, fw.size() * 4, hipMemcpyDeviceToHost);
+        hipMemcpy(bw.data(), h->H[1][NLAYER - 1], bw.size() * 4, hipMemcpyDeviceToHost);
+        if (hipMemcpy(sf.data(), h->sigfeat, sf.size() * 4, hipMemcpyDeviceToHost) != hipSuccess) return fail(h, DS_ERR_HIP, "hipMemcpy D2H");
+        for (int i = 0; i < n; ++i) {
+            memcpy(out + (size_t)i * h->J, fw.data() + (size_t)i * HID, HID * 4);
+            memcpy(out + (size_t)i * h->J + HID, bw.data() + (size_t)i * HID, HID * 4);
+            memcpy(out + (size_t)i * h->J + 2 * HID, sf.data() + (size_t)i * h->SF, (size_t)h->SF * 4);
+        }
+        return count;
+    }
+    return fail(h, DS_ERR_INVALID, "unknown intermediate " + s);
+}
+
+int ds_set_profiling(ds_handle* h, int32_t enable)
+{
+    if (!h) return DS_ERR_INVALID;
+    int rc = ds_sync(h);
+    h->profiling = enable != 0;
+    return rc;
+}
+
+int ds_num_stages(ds_handle* h) { return h ? (int)h->stages.size() : DS_ERR_INVALID; }
+
+int ds_get_stage(ds_handle* h, int32_t index, char* name, int32_t name_cap, int32_t* launches, double* total_ms,
+                 int64_t* calls, double* flops_per_site)
+{
+    if (!h || index < 0 || index >= (int)h->stages.size()) return DS_ERR_INVALID;
+    const Stage& S = h->stages[index];
+    if (name && name_cap > 0) { strncpy(name, S.name.c_str(), name_cap - 1); name[name_cap - 1] = 0; }
+    if (launches) *launches = S.launches;
+    if (total_ms) *total_ms = S.total_ms;
+    if (calls) *calls = S.calls;
+    if (flops_per_site) *flops_per_site = S.flops_per_site;
+    return DS_OK;
+}
+
+int ds_reset_stage_times(ds_handle* h)
+{
+    if (!h) return DS_ERR_INVALID;
+    for (Stage& S : h->stages) { S.total_ms = 0; S.calls = 0; }
+    return DS_OK;
+}
+
+int ds_set_graph(ds_handle* h, int32_t enable)
+{
+    if (!h) return DS_ERR_INVALID;
+    h->use_graph = enable != 0;
+    return DS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,95 @@
+// ds_internal.h — structures shared by the host planner (ds_engine.cpp) and the gfx950 kernels
+// (ds_kernels.hip). Not part of the public ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ds {
+
+constexpr int KC = 16;          // K elements staged per LDS chunk (two 8-wide MFMA read steps)
+constexpr int MAX_SEG = 5;      // A-operand segments (conv taps / concatenated inputs)
+constexpr int MAX_OUT = 6;      // output column segments of one GEMM
+constexpr int MAX_PROB = 8;     // problems per grouped launch
+
+// One K-segment of the implicit-GEMM A operand: rows come from `base` (row stride ld, floats),
+// shifted by row_shift rows; a shifted row is read as zeros when it leaves its site
+// [0, W) (TF SAME zero padding) or the matrix.
+struct ASeg {
+    const float* base;
+    int ld;
+    int row_shift;
+    int klen;      // multiple of KC
+    int pad_;
+};
+
+// Output column segment: GEMM columns [col0, col0+ncols) go to base[row*ld + (col-col0)].
+struct OSeg {
+    float* base;
+    const float* add;   // optional residual addend, same indexing with add_ld
+    int ld;
+    int add_ld;
+    int col0;
+    int ncols;
+    int relu;
+    int pad_;
+};
+
+// Fused LSTM-cell epilogue (TF-1.x LSTMCell, gate order i,j,f,o, forget_bias 1.0).
+struct LstmEp {
+    const float* table;   // [vocab][1024] embedding x W_x(layer 0), or nullptr
+    const float* wfeat;   // [3][1024] rows of W_x for (mean, std, len)
+    const int* codes;     // [n][T]
+    const float* means;   // [n][T]
+    const float* stds;
+    const float* lens;
+    float* c;             // [n][256] cell state (read-modify-write)
+    float* h_out;         // [n][256]
+    int t;                // original time index this step consumes
+    int T;
+    int c_zero;           // 1: previous c is zero (first step)
+    int pad_;
+};
+
+struct GemmProblem {
+    int M, N, K, W;             // K = sum of the used segments' klen
+    int a_mode;                 // 0: plain / taps, 1: maxpool(3, stride 1, SAME) of segment 0 on load
+    int nseg;
+    int kgroups_stride;         // K-groups (of 8) per packed n-tile panel in Bp
+    int nout;
+    ASeg seg[MAX_SEG];
+    OSeg out[MAX_OUT];
+    const float* Bp;            // pre-packed weights [ntile][kgroup][64 lanes][4]
+    const float* bias;          // [N] (folded BN shift / LSTM bias in TF column order)
+    LstmEp lstm;
+    int tiles_m, tiles_n, tile_start, ntiles32;   // ntiles32 = ceil(N/32)
+};
+
+struct GemmLaunch {
+    GemmProblem prob[MAX_PROB];
+    int nprob;
+    int total_tiles;
+    int pad_[2];
+};
+
+enum GemmCfg { CFG_CONV = 0, CFG_FC = 1, CFG_LSTM = 2, CFG_CONV_WIDE = 3 };
+
+// tile geometry per config (host needs it for grid sizing)
+struct TileGeom { int bm, bn, threads; };
+TileGeom gemm_geom(GemmCfg cfg);
+
+hipError_t launch_gemm(GemmCfg cfg, const GemmLaunch* d_launch, int total_tiles, hipStream_t s);
+
+// stem conv1 (K=7, stride 2, Cin=1) + folded BN + ReLU + maxpool(3, stride 2)   layers.py:183-191
+hipError_t launch_stem1(const float* signals, const float* w7x64, const float* bias64, float* out,
+                        int n, int signal_len, int w1, int pad_l_conv, int wa, int pad_l_pool, hipStream_t s);
+// maxpool(3, stride 2, SAME) over [n, win, ch] -> [n, wout, ch]                 layers.py:211-213,224-226
+hipError_t launch_maxpool_s2(const float* in, float* out, int n, int win, int wout, int pad_l, int ch, hipStream_t s);
+// avgpool(7, stride 1, SAME, divisor = valid taps) + flatten                    layers.py:233-238
+hipError_t launch_avgpool7(const float* in, float* out, int n, int w, int ch, hipStream_t s);
+// fc2 (J x class_num, no bias) + sigmoid + argmax                               layers.py:261-263, model.py:100,108
+hipError_t launch_head(const float* fc1, const float* w2, float* logits, float* act, int* pred,
+                       int n, int J, int class_num, hipStream_t s);
+// table[v][c] = sum_e emb[v][e] * kernel[e][c]  (embedding folded into layer-0 W_x; model.py:61-69)
+hipError_t launch_embed_table(const float* emb, const float* kernel, float* table, int vocab, int esize, int ncol, hipStream_t s);
+
+}  // namespace ds

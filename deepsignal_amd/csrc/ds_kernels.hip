@@ -1,0 +1,416 @@
+// ds_kernels.hip — gfx950 (CDNA4 / MI355X) kernels of the call_mods forward pass.
+//
+// One fp32 MFMA implicit-GEMM template carries every matmul-shaped op of the path
+// (1-D convolutions as tap-segmented GEMMs over NWC activations, the LSTM cell matmuls with the
+// gate non-linearities fused into the epilogue, and the 6032x6032 joint FC); small elementwise
+// kernels do the pools, the Cin=1 stem conv and the 2-class head.
+//
+// Design notes (MI355X_MICROARCH.md / cdna_hip_programming.md):
+//  * v_mfma_f32_32x32x2_f32 is exact fp32 (an fmaf chain) at 64 FLOP/clk/SIMD and needs only ONE
+//    VGPR per operand per lane, so the weight (B) operand is pre-packed on the host in fragment
+//    order and streamed global->VGPR with 1 KiB coalesced wave loads (no LDS round trip), while the
+//    activation (A) tile is staged through LDS once per K-chunk and shared by all waves.
+//  * K is consumed in groups of 8 with a lane-local permutation (lane half h owns k = 4h..4h+3 of
+//    the group) so one ds_read_b128 / one global_load_dwordx4 feeds four consecutive MFMAs.
+//  * LDS rows are padded to KC+4 floats: the 16-lane ds_read_b128 groups hit 16 distinct 16-B slots.
+//  * wave64 everywhere; no CUDA-isms, no compatibility shims.
+#include "ds_internal.h"
+
+namespace ds {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ float4 f4max(float4 a, float4 b)
+{
+    return make_float4(fmaxf(a.x, b.x), fmaxf(a.y, b.y), fmaxf(a.z, b.z), fmaxf(a.w, b.w));
+}
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+template <int MT, int NT, int WM, int WN, int EPI>
+__global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmLaunch* __restrict__ L)
+{
+    constexpr int BM = WM * MT * 32;
+    constexpr int LDA = KC + 4;
+    constexpr int NTHR = 64 * WM * WN;
+    constexpr int SLOTS = (BM * 4 + NTHR - 1) / NTHR;
+    __shared__ __attribute__((aligned(16))) float As[2][BM * LDA];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave % WM, wn = wave / WM;
+    const int bid = blockIdx.x;
+    int pi = 0;
+    for (int i = 1; i < L->nprob; ++i)
+        if (bid >= L->prob[i].tile_start) pi = i;
+    const GemmProblem& P = L->prob[pi];
+    const int local = bid - P.tile_start;
+    const int tm = local % P.tiles_m, tn = local / P.tiles_m;
+    const int m0 = tm * BM;
+    const int M = P.M, W = P.W;
+    const int a_mode = P.a_mode;
+    const int nchunks = P.K / KC;
+
+    int sm[SLOTS], sw[SLOTS], sq[SLOTS];
+    bool sin_[SLOTS];
+#pragma unroll
+    for (int i = 0; i < SLOTS; ++i) {
+        const int idx = tid + i * NTHR;
+        const int r = idx >> 2;
+        sq[i] = idx & 3;
+        sm[i] = m0 + r;
+        sin_[i] = (idx < BM * 4) && (sm[i] < M);
+        sw[i] = sm[i] % W;
+    }
+
+    int ntile[NT];
+    bool nvalid[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        ntile[nt] = (tn * WN + wn) * NT + nt;
+        nvalid[nt] = ntile[nt] < P.ntiles32;
+    }
+
+    floatx16 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.0f;
+
+    int seg_i = 0, seg_k = 0;   // uniform cursor of the chunk being LOADED
+
+    auto load_a = [&](float4(&reg)[SLOTS]) {
+        const float* base = P.seg[seg_i].base;
+        const int ld = P.seg[seg_i].ld;
+        const int shift = P.seg[seg_i].row_shift;
+#pragma unroll
+        for (int i = 0; i < SLOTS; ++i) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (a_mode == 0) {
+                const int ws = sw[i] + shift;
+                if (sin_[i] && (unsigned)ws < (unsigned)W)
+                    v = *reinterpret_cast<const float4*>(base + (size_t)(sm[i] + shift) * ld + seg_k + sq[i] * 4);
+            } else if (sin_[i]) {   // maxpool(3, stride 1, SAME): padded taps ignored
+                const float* p = base + (size_t)sm[i] * ld + seg_k + sq[i] * 4;
+                v = *reinterpret_cast<const float4*>(p);
+                if (sw[i] > 0) v = f4max(v, *reinterpret_cast<const float4*>(p - ld));
+                if (sw[i] < W - 1) v = f4max(v, *reinterpret_cast<const float4*>(p + ld));
+            }
+            reg[i] = v;
+        }
+        seg_k += KC;
+        if (seg_k >= P.seg[seg_i].klen) { seg_k = 0; ++seg_i; }
+    };
+    auto store_a = [&](float* dst, const float4(&reg)[SLOTS]) {
+#pragma unroll
+        for (int i = 0; i < SLOTS; ++i) {
+            const int idx = tid + i * NTHR;
+            if (idx < BM * 4) *reinterpret_cast<float4*>(dst + (idx >> 2) * LDA + (idx & 3) * 4) = reg[i];
+        }
+    };
+    auto load_b = [&](float4(&b)[NT][2], int chunk) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int rs = 0; rs < 2; ++rs) {
+                if (nvalid[nt])
+                    b[nt][rs] = *reinterpret_cast<const float4*>(
+                        P.Bp + ((size_t)ntile[nt] * P.kgroups_stride + chunk * 2 + rs) * 256 + lane * 4);
+                else
+                    b[nt][rs] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+    };
+    auto compute = [&](const float* src, const float4(&b)[NT][2]) {
+#pragma unroll
+        for (int rs = 0; rs < 2; ++rs) {
+            float4 a[MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+                a[mt] = *reinterpret_cast<const float4*>(
+                    src + ((wm * MT + mt) * 32 + (lane & 31)) * LDA + rs * 8 + (lane >> 5) * 4);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt].x, b[nt][rs].x, acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt].y, b[nt][rs].y, acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt].z, b[nt][rs].z, acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt].w, b[nt][rs].w, acc[mt][nt], 0, 0, 0);
+                }
+        }
+    };
+
+    float4 areg[SLOTS];
+    float4 b0[NT][2], b1[NT][2];
+    if (nchunks > 0) {
+        load_a(areg);
+        load_b(b0, 0);
+        store_a(As[0], areg);
+    }
+    __syncthreads();
+    for (int c = 0; c < nchunks; c += 2) {
+        const bool more1 = c + 1 < nchunks;
+        if (more1) { load_a(areg); load_b(b1, c + 1); }
+        compute(As[0], b0);
+        if (more1) store_a(As[1], areg);
+        __syncthreads();
+        if (!more1) break;
+        const bool more2 = c + 2 < nchunks;
+        if (more2) { load_a(areg); load_b(b0, c + 2); }
+        compute(As[1], b1);
+        if (more2) store_a(As[0], areg);
+        __syncthreads();
+    }
+
+    // ---------------- epilogue ----------------
+    const int rbase = m0 + wm * MT * 32 + 4 * (lane >> 5);
+    if (EPI == 0) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int col = ntile[nt] * 32 + (lane & 31);
+            if (!nvalid[nt] || col >= P.N) continue;
+            int sel = 0;
+            for (int o = 1; o < P.nout; ++o)
+                if (col >= P.out[o].col0) sel = o;
+            const OSeg os = P.out[sel];
+            const int cc = col - os.col0;
+            const float bias = P.bias ? P.bias[col] : 0.0f;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = rbase + mt * 32 + (r & 3) + 8 * (r >> 2);
+                    if (row < M) {
+                        float v = acc[mt][nt][r] + bias;
+                        if (os.add) v += os.add[(size_t)row * os.add_ld + cc];
+                        if (os.relu) v = fmaxf(v, 0.0f);
+                        os.base[(size_t)row * os.ld + cc] = v;
+                    }
+                }
+        }
+    } else {
+        // NT == 4: the wave's four n-tiles are gates i,j,f,o of unit group ug (weights packed so).
+        const LstmEp E = P.lstm;
+        const int ug = tn * WN + wn;
+        const int u = ug * 32 + (lane & 31);
+        if (nvalid[0]) {
+            float bi = P.bias[u], bj = P.bias[256 + u], bf = P.bias[512 + u], bo = P.bias[768 + u];
+            float wi[3], wj[3], wf[3], wo[3];
+            if (E.table) {
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    wi[q] = E.wfeat[q * 1024 + u];
+                    wj[q] = E.wfeat[q * 1024 + 256 + u];
+                    wf[q] = E.wfeat[q * 1024 + 512 + u];
+                    wo[q] = E.wfeat[q * 1024 + 768 + u];
+                }
+            }
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = rbase + mt * 32 + (r & 3) + 8 * (r >> 2);
+                    if (row < M) {
+                        float zi = acc[mt][0 % NT][r] + bi, zj = acc[mt][1 % NT][r] + bj;
+                        float zf = acc[mt][2 % NT][r] + bf, zo = acc[mt][3 % NT][r] + bo;
+                        if (E.table) {
+                            const size_t it = (size_t)row * E.T + E.t;
+                            const float* trow = E.table + (size_t)E.codes[it] * 1024;
+                            const float f0 = E.means[it], f1 = E.stds[it], f2 = E.lens[it];
+                            zi += trow[u] + f0 * wi[0] + f1 * wi[1] + f2 * wi[2];
+                            zj += trow[256 + u] + f0 * wj[0] + f1 * wj[1] + f2 * wj[2];
+                            zf += trow[512 + u] + f0 * wf[0] + f1 * wf[1] + f2 * wf[2];
+                            zo += trow[768 + u] + f0 * wo[0] + f1 * wo[1] + f2 * wo[2];
+                        }
+                        const size_t ix = (size_t)row * 256 + u;
+                        const float cp = E.c_zero ? 0.0f : E.c[ix];
+                        const float cn = sigmoidf_(zf + 1.0f) * cp + sigmoidf_(zi) * tanhf(zj);
+                        E.c[ix] = cn;
+                        E.h_out[ix] = sigmoidf_(zo) * tanhf(cn);
+                    }
+                }
+        }
+    }
+}
+
+TileGeom gemm_geom(GemmCfg cfg)
+{
+    switch (cfg) {
+    case CFG_CONV: return {128, 64, 256};        // MT1 NT2 WM4 WN1
+    case CFG_FC: return {128, 96, 256};          // MT1 NT3 WM4 WN1
+    case CFG_LSTM: return {128, 128, 256};       // MT1 NT4 WM4 WN1 (one 32-unit gate group per block)
+    case CFG_CONV_WIDE: return {128, 128, 256};  // MT2 NT2 WM2 WN2
+    }
+    return {0, 0, 0};
+}
+
+hipError_t launch_gemm(GemmCfg cfg, const GemmLaunch* d_launch, int total_tiles, hipStream_t s)
+{
+    if (total_tiles <= 0) return hipSuccess;
+    switch (cfg) {
+    case CFG_CONV: hipLaunchKernelGGL((gemm_kernel<1, 2, 4, 1, 0>), dim3(total_tiles), dim3(256), 0, s, d_launch); break;
+    case CFG_FC: hipLaunchKernelGGL((gemm_kernel<1, 3, 4, 1, 0>), dim3(total_tiles), dim3(256), 0, s, d_launch); break;
+    case CFG_LSTM: hipLaunchKernelGGL((gemm_kernel<1, 4, 4, 1, 1>), dim3(total_tiles), dim3(256), 0, s, d_launch); break;
+    case CFG_CONV_WIDE: hipLaunchKernelGGL((gemm_kernel<2, 2, 2, 2, 0>), dim3(total_tiles), dim3(256), 0, s, d_launch); break;
+    }
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// stem conv1: conv(K=7, stride 2, Cin=1 -> 64, SAME) + folded BN + ReLU + maxpool(3, stride 2, SAME)
+// One block per site; the 360-sample window sits in LDS, lane = output channel.
+__global__ __launch_bounds__(256) void stem1_kernel(const float* __restrict__ signals, const float* __restrict__ w,
+                                                     const float* __restrict__ bias, float* __restrict__ out,
+                                                     int signal_len, int w1, int pad_l_conv, int wa, int pad_l_pool)
+{
+    extern __shared__ __attribute__((aligned(16))) float sig[];
+    const int site = blockIdx.x;
+    for (int i = threadIdx.x; i < signal_len; i += blockDim.x) sig[i] = signals[(size_t)site * signal_len + i];
+    __syncthreads();
+    const int c = threadIdx.x & 63;
+    float wk[7];
+#pragma unroll
+    for (int t = 0; t < 7; ++t) wk[t] = w[t * 64 + c];
+    const float b = bias[c];
+    for (int p = threadIdx.x >> 6; p < wa; p += blockDim.x >> 6) {
+        float best = -INFINITY;
+#pragma unroll
+        for (int pt = 0; pt < 3; ++pt) {
+            const int wc = 2 * p + pt - pad_l_pool;
+            if (wc < 0 || wc >= w1) continue;
+            float a = 0.0f;
+#pragma unroll
+            for (int t = 0; t < 7; ++t) {
+                const int si = 2 * wc + t - pad_l_conv;
+                if (si >= 0 && si < signal_len) a = fmaf(sig[si], wk[t], a);
+            }
+            best = fmaxf(best, a);
+        }
+        out[((size_t)site * wa + p) * 64 + c] = fmaxf(best + b, 0.0f);
+    }
+}
+
+hipError_t launch_stem1(const float* signals, const float* w7x64, const float* bias64, float* out, int n,
+                        int signal_len, int w1, int pad_l_conv, int wa, int pad_l_pool, hipStream_t s)
+{
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(stem1_kernel, dim3(n), dim3(256), signal_len * sizeof(float), s, signals, w7x64, bias64, out,
+                       signal_len, w1, pad_l_conv, wa, pad_l_pool);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void maxpool_s2_kernel(const float4* __restrict__ in, float4* __restrict__ out,
+                                                          long total, int win, int wout, int pad_l, int ch4)
+{
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % ch4);
+        const long r = i / ch4;
+        const int wo = (int)(r % wout);
+        const long site = r / wout;
+        float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            const int wi = 2 * wo + t - pad_l;
+            if (wi >= 0 && wi < win) m = f4max(m, in[(site * win + wi) * ch4 + c]);
+        }
+        out[i] = m;
+    }
+}
+
+hipError_t launch_maxpool_s2(const float* in, float* out, int n, int win, int wout, int pad_l, int ch, hipStream_t s)
+{
+    const long total = (long)n * wout * (ch / 4);
+    if (total <= 0) return hipSuccess;
+    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(maxpool_s2_kernel, dim3(blocks), dim3(256), 0, s, (const float4*)in, (float4*)out, total, win, wout,
+                       pad_l, ch / 4);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void avgpool7_kernel(const float4* __restrict__ in, float4* __restrict__ out, long total,
+                                                        int w, int ch4)
+{
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % ch4);
+        const long r = i / ch4;
+        const int wo = (int)(r % w);
+        const long site = r / w;
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+        int cnt = 0;
+        for (int t = -3; t <= 3; ++t) {
+            const int wi = wo + t;
+            if (wi < 0 || wi >= w) continue;
+            const float4 v = in[(site * w + wi) * ch4 + c];
+            a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+            ++cnt;
+        }
+        const float d = (float)cnt;
+        out[i] = make_float4(a.x / d, a.y / d, a.z / d, a.w / d);
+    }
+}
+
+hipError_t launch_avgpool7(const float* in, float* out, int n, int w, int ch, hipStream_t s)
+{
+    const long total = (long)n * w * (ch / 4);
+    if (total <= 0) return hipSuccess;
+    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(avgpool7_kernel, dim3(blocks), dim3(256), 0, s, (const float4*)in, (float4*)out, total, w, ch / 4);
+    return hipGetLastError();
+}
+
+// fc2 + sigmoid + argmax: one wave per site.
+__global__ __launch_bounds__(256) void head_kernel(const float* __restrict__ fc1, const float* __restrict__ w2,
+                                                    float* __restrict__ logits, float* __restrict__ act,
+                                                    int* __restrict__ pred, int n, int J, int C)
+{
+    const int site = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (site >= n) return;
+    const float* x = fc1 + (size_t)site * J;
+    float best = 0.0f;
+    int bi = 0;
+    for (int c = 0; c < C; ++c) {
+        float a = 0.0f;
+        for (int k = lane; k < J; k += 64) a = fmaf(x[k], w2[(size_t)k * C + c], a);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) a += __shfl_xor(a, off);
+        const float sg = sigmoidf_(a);
+        if (lane == 0) {
+            logits[(size_t)site * C + c] = a;
+            act[(size_t)site * C + c] = sg;
+        }
+        if (c == 0 || sg > best) { best = sg; bi = c; }
+    }
+    if (lane == 0) pred[site] = bi;
+}
+
+hipError_t launch_head(const float* fc1, const float* w2, float* logits, float* act, int* pred, int n, int J,
+                       int class_num, hipStream_t s)
+{
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(head_kernel, dim3((n + 3) / 4), dim3(256), 0, s, fc1, w2, logits, act, pred, n, J, class_num);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void embed_table_kernel(const float* __restrict__ emb, const float* __restrict__ kernel,
+                                                           float* __restrict__ table, int vocab, int esize, int ncol)
+{
+    const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (i >= (long)vocab * ncol) return;
+    const int col = (int)(i % ncol);
+    const int v = (int)(i / ncol);
+    float a = 0.0f;
+    for (int e = 0; e < esize; ++e) a = fmaf(emb[(size_t)v * esize + e], kernel[(size_t)e * ncol + col], a);
+    table[i] = a;
+}
+
+hipError_t launch_embed_table(const float* emb, const float* kernel, float* table, int vocab, int esize, int ncol,
+                              hipStream_t s)
+{
+    const long total = (long)vocab * ncol;
+    hipLaunchKernelGGL(embed_table_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, emb, kernel, table, vocab,
+                       esize, ncol);
+    return hipGetLastError();
+}
+
+}  // namespace ds

@@ -1,0 +1,185 @@
+"""ctypes binding of libdeepsignal_hip.so — the MI355X engine behind `call_mods`.
+
+`Engine` plays the role of the reference's `(Model, tf.Session)` pair
+(/root/reference/deepsignal/call_modifications.py:203-212): construct, restore weights, then
+`run(...)` == `tf_sess.run([model.activation_logits, model.prediction], feed_dict)`
+(call_modifications.py:168-178).
+
+There is NO CPU fallback: if the HIP library is missing or no GPU is visible, construction raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdeepsignal_hip.so")
+
+# every symbol include/deepsignal_hip.h declares
+EXPORTED_SYMBOLS = (
+    "ds_create", "ds_destroy", "ds_last_error", "ds_version", "ds_load_weights", "ds_set_tensor",
+    "ds_finalize_weights", "ds_forward", "ds_forward_device", "ds_sync", "ds_alloc_host", "ds_free_host",
+    "ds_get_intermediate", "ds_set_profiling", "ds_num_stages", "ds_get_stage", "ds_reset_stage_times",
+    "ds_set_graph",
+)
+
+
+class DsConfig(ctypes.Structure):
+    _fields_ = [
+        ("kmer_len", ctypes.c_int32), ("signal_len", ctypes.c_int32), ("class_num", ctypes.c_int32),
+        ("is_cnn", ctypes.c_int32), ("is_rnn", ctypes.c_int32), ("is_base", ctypes.c_int32),
+        ("device", ctypes.c_int32), ("precision", ctypes.c_int32), ("max_batch", ctypes.c_int32),
+        ("reserved", ctypes.c_int32 * 7),
+    ]
+
+
+_lib: Optional[ctypes.CDLL] = None
+
+
+def load_library() -> ctypes.CDLL:
+    """Load the in-tree HIP library; raise (never fall back) when it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C deepsignal_amd/csrc`). There is no CPU fallback." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    vp, i32, i64 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64
+    lib.ds_create.argtypes = [ctypes.POINTER(DsConfig), ctypes.POINTER(vp)]
+    lib.ds_create.restype = ctypes.c_int
+    lib.ds_destroy.argtypes = [vp]
+    lib.ds_destroy.restype = None
+    lib.ds_last_error.argtypes = [vp]
+    lib.ds_last_error.restype = ctypes.c_char_p
+    lib.ds_version.restype = ctypes.c_char_p
+    lib.ds_load_weights.argtypes = [vp, ctypes.c_char_p]
+    lib.ds_set_tensor.argtypes = [vp, ctypes.c_char_p, vp, ctypes.POINTER(i64), i32]
+    lib.ds_finalize_weights.argtypes = [vp]
+    lib.ds_forward.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp]
+    lib.ds_forward_device.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp]
+    lib.ds_sync.argtypes = [vp]
+    lib.ds_alloc_host.argtypes = [ctypes.c_size_t, ctypes.POINTER(vp)]
+    lib.ds_free_host.argtypes = [vp]
+    lib.ds_get_intermediate.argtypes = [vp, ctypes.c_char_p, vp, i64]
+    lib.ds_get_intermediate.restype = i64
+    lib.ds_set_profiling.argtypes = [vp, i32]
+    lib.ds_num_stages.argtypes = [vp]
+    lib.ds_get_stage.argtypes = [vp, i32, ctypes.c_char_p, i32, ctypes.POINTER(i32), ctypes.POINTER(ctypes.c_double),
+                                 ctypes.POINTER(i64), ctypes.POINTER(ctypes.c_double)]
+    lib.ds_reset_stage_times.argtypes = [vp]
+    lib.ds_set_graph.argtypes = [vp, i32]
+    _lib = lib
+    return lib
+
+
+class Engine:
+    """One handle == one GPU == one full weight replica."""
+
+    def __init__(self, kmer_len: int = 17, signal_len: int = 360, class_num: int = 2, device: int = 0,
+                 max_batch: int = 512, is_cnn: bool = True, is_rnn: bool = True, is_base: bool = True,
+                 debug: bool = False):
+        self._lib = load_library()
+        self._h = ctypes.c_void_p()
+        cfg = DsConfig(kmer_len, signal_len, class_num, int(is_cnn), int(is_rnn), int(is_base), device, 0, max_batch)
+        cfg.reserved[0] = 1 if debug else 0
+        rc = self._lib.ds_create(ctypes.byref(cfg), ctypes.byref(self._h))
+        if rc != 0:
+            msg = self._lib.ds_last_error(None).decode()
+            self._h = ctypes.c_void_p()
+            raise RuntimeError("ds_create failed (%d): %s" % (rc, msg))
+        self.kmer_len, self.signal_len, self.class_num = kmer_len, signal_len, class_num
+        self.device, self.max_batch = device, max_batch
+
+    # -- lifecycle -----------------------------------------------------------------------------
+    def close(self) -> None:
+        if getattr(self, "_h", None) and self._h.value:
+            self._lib.ds_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc: int, what: str) -> None:
+        if rc < 0:
+            raise RuntimeError("%s failed (%d): %s" % (what, rc, self._lib.ds_last_error(self._h).decode()))
+
+    # -- weights (Saver.restore, call_modifications.py:210-211) --------------------------------
+    def load_weights_file(self, path: str) -> None:
+        self._check(self._lib.ds_load_weights(self._h, path.encode()), "ds_load_weights")
+
+    def load_weights(self, weights: Dict[str, np.ndarray]) -> None:
+        for name, arr in weights.items():
+            a = np.ascontiguousarray(arr, dtype=np.float32)
+            shape = (ctypes.c_int64 * a.ndim)(*a.shape)
+            self._check(self._lib.ds_set_tensor(self._h, name.encode(), a.ctypes.data, shape, a.ndim), "ds_set_tensor")
+        self._check(self._lib.ds_finalize_weights(self._h), "ds_finalize_weights")
+
+    # -- forward (sess.run, call_modifications.py:177-178) -------------------------------------
+    def run(self, kmer, means, stds, sanums, signals) -> Tuple[np.ndarray, np.ndarray]:
+        """Host arrays in, (activation_logits float32[n,class_num], prediction int32[n]) out."""
+        kmer = np.ascontiguousarray(kmer, dtype=np.int32)
+        n = kmer.shape[0] if kmer.ndim == 2 else 0
+        means = np.ascontiguousarray(means, dtype=np.float32)
+        stds = np.ascontiguousarray(stds, dtype=np.float32)
+        sanums = np.ascontiguousarray(sanums, dtype=np.float32)     # int -> float cast as the TF feed does
+        signals = np.ascontiguousarray(signals, dtype=np.float32)
+        act = np.empty((n, self.class_num), np.float32)
+        pred = np.empty((n,), np.int32)
+        if n == 0:
+            return act, pred
+        if kmer.shape != (n, self.kmer_len) or means.shape != kmer.shape or stds.shape != kmer.shape \
+                or sanums.shape != kmer.shape or signals.shape != (n, self.signal_len):
+            raise ValueError("feature arrays have inconsistent shapes")
+        rc = self._lib.ds_forward(self._h, n, kmer.ctypes.data, means.ctypes.data, stds.ctypes.data,
+                                  sanums.ctypes.data, signals.ctypes.data, act.ctypes.data, pred.ctypes.data)
+        self._check(rc, "ds_forward")
+        return act, pred
+
+    def run_device(self, n: int, d_kmer: int, d_means: int, d_stds: int, d_sanums: int, d_signals: int,
+                   d_act: int, d_pred: int) -> None:
+        """Raw device pointers (e.g. torch tensors' data_ptr()); asynchronous, call sync()."""
+        rc = self._lib.ds_forward_device(self._h, n, d_kmer, d_means, d_stds, d_sanums, d_signals, d_act, d_pred)
+        self._check(rc, "ds_forward_device")
+
+    def sync(self) -> None:
+        self._check(self._lib.ds_sync(self._h), "ds_sync")
+
+    # -- diagnostics ---------------------------------------------------------------------------
+    def intermediate(self, name: str, shape) -> np.ndarray:
+        out = np.empty(shape, np.float32)
+        got = self._lib.ds_get_intermediate(self._h, name.encode(), out.ctypes.data, out.size)
+        self._check(int(got), "ds_get_intermediate(%s)" % name)
+        if got != out.size:
+            raise RuntimeError("intermediate %s: expected %d floats, got %d" % (name, out.size, got))
+        return out
+
+    def set_profiling(self, enable: bool) -> None:
+        self._check(self._lib.ds_set_profiling(self._h, int(enable)), "ds_set_profiling")
+
+    def set_graph(self, enable: bool) -> None:
+        self._check(self._lib.ds_set_graph(self._h, int(enable)), "ds_set_graph")
+
+    def reset_stage_times(self) -> None:
+        self._check(self._lib.ds_reset_stage_times(self._h), "ds_reset_stage_times")
+
+    def stage_times(self) -> List[dict]:
+        out = []
+        for i in range(self._lib.ds_num_stages(self._h)):
+            name = ctypes.create_string_buffer(64)
+            launches = ctypes.c_int32()
+            ms = ctypes.c_double()
+            calls = ctypes.c_int64()
+            flops = ctypes.c_double()
+            self._check(self._lib.ds_get_stage(self._h, i, name, 64, ctypes.byref(launches), ctypes.byref(ms),
+                                               ctypes.byref(calls), ctypes.byref(flops)), "ds_get_stage")
+            out.append({"name": name.value.decode(), "launches": launches.value, "total_ms": ms.value,
+                        "calls": calls.value, "flops_per_site": flops.value})
+        return out

@@ -1,0 +1,104 @@
+/*
+ * deepsignal_hip.h — C ABI of the MI355X (gfx950) call_mods inference engine.
+ *
+ * The reference has no plugin/FFI interface; its de-facto boundary to the compute engine is
+ *   Model(...)                         /root/reference/deepsignal/call_modifications.py:203-205
+ *   tf.Session + Saver.restore(...)    /root/reference/deepsignal/call_modifications.py:207-212
+ *   tf_sess.run([model.activation_logits, model.prediction], feed_dict)
+ *                                      /root/reference/deepsignal/call_modifications.py:168-178
+ * Every entry point below names the piece of that boundary it replaces. Plain pointers and
+ * sizes only; no torch / TensorFlow types. All functions return 0 on success or a negative
+ * DS_ERR_* code; ds_last_error() gives the message. A handle is driven by one host thread at a
+ * time; different handles (one per GPU) may be driven concurrently.
+ */
+#ifndef DEEPSIGNAL_HIP_H
+#define DEEPSIGNAL_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DS_OK 0
+#define DS_ERR_INVALID (-1)      /* bad argument / shape / state        */
+#define DS_ERR_HIP (-2)          /* a HIP runtime call failed           */
+#define DS_ERR_IO (-3)           /* weight file could not be read       */
+#define DS_ERR_UNSUPPORTED (-4)  /* configuration not implemented       */
+#define DS_ERR_NOMEM (-5)
+
+#define DS_PRECISION_FP32 0
+
+typedef struct ds_handle ds_handle;
+
+/* Mirrors Model.__init__'s arguments (model.py:26-27) plus placement. */
+typedef struct ds_config {
+    int32_t kmer_len;     /* base_num,   default 17  (deepsignal.py:258-259) */
+    int32_t signal_len;   /* signal_num, default 360 (deepsignal.py:260-262) */
+    int32_t class_num;    /* default 2 */
+    int32_t is_cnn;       /* model.py:28-29 switches; this round: all three must be 1 */
+    int32_t is_rnn;
+    int32_t is_base;
+    int32_t device;       /* HIP device ordinal */
+    int32_t precision;    /* DS_PRECISION_FP32 */
+    int32_t max_batch;    /* largest n per device pass (workspaces are sized for it); larger n is looped */
+    int32_t reserved[7];
+} ds_config;
+
+/* Replaces Model(...) + tf.Session(): call_modifications.py:203-209. */
+int ds_create(const ds_config *cfg, ds_handle **out);
+void ds_destroy(ds_handle *h);
+const char *ds_last_error(const ds_handle *h);   /* h may be NULL: last ds_create error */
+const char *ds_version(void);
+
+/* Replaces Saver.restore(sess, model_path): call_modifications.py:210-211.
+ * Either a DSAMDW01 file (deepsignal_amd/weights.py) ... */
+int ds_load_weights(ds_handle *h, const char *path);
+/* ... or tensor-by-tensor under the TF variable names of SURVEY.md Appendix B.7, then finalize
+ * (folds BN into the conv kernels, pre-packs MFMA operand panels, uploads). */
+int ds_set_tensor(ds_handle *h, const char *name, const float *data, const int64_t *shape, int32_t ndim);
+int ds_finalize_weights(ds_handle *h);
+
+/* Replaces tf_sess.run([activation_logits, prediction], feed_dict): call_modifications.py:168-178.
+ * Host buffers, row-major: kmer int32[n,kmer_len] (base codes, process_utils.py:21);
+ * means/stds/sanums float[n,kmer_len]; signals float[n,signal_len]. Outputs: act float[n,class_num]
+ * = sigmoid(logits) (NOT normalised — the caller normalises, call_modifications.py:185-187) and
+ * pred int32[n] = argmax (ties -> lowest index). Blocking. */
+int ds_forward(ds_handle *h, int32_t n, const int32_t *kmer, const float *means, const float *stds,
+               const float *sanums, const float *signals, float *act, int32_t *pred);
+
+/* Same contract with every pointer in DEVICE memory of h's GPU (n <= max_batch). Asynchronous on
+ * the handle's streams; ds_sync() waits. Used when features are already resident in HBM. */
+int ds_forward_device(ds_handle *h, int32_t n, const int32_t *d_kmer, const float *d_means,
+                      const float *d_stds, const float *d_sanums, const float *d_signals,
+                      float *d_act, int32_t *d_pred);
+int ds_sync(ds_handle *h);
+
+/* Pinned host allocation helpers for callers that want async H2D/D2H overlap. */
+int ds_alloc_host(size_t bytes, void **out);
+int ds_free_host(void *p);
+
+/* Test/diagnostic access to intermediate tensors of the LAST forward (float32, row-major, same
+ * names/shapes as the oracle taps: stem_pool, stem_conv2, stem_conv3, module1..module11,
+ * signal_feat, lstm_{fw,bw}_l{0,1,2}, joint, fc1, logits). Returns the number of floats written,
+ * or a negative error. */
+int64_t ds_get_intermediate(ds_handle *h, const char *name, float *out, int64_t capacity);
+
+/* Stage timing (HIP events on the engine's own streams). enable!=0 records an event pair around
+ * every stage of each subsequent forward; ds_get_stage_times then reports, for stage index i,
+ * its name, the number of kernel launches it covers, and the accumulated device milliseconds and
+ * call count since the last reset. Returns the number of stages. */
+int ds_set_profiling(ds_handle *h, int32_t enable);
+int ds_num_stages(ds_handle *h);
+int ds_get_stage(ds_handle *h, int32_t index, char *name, int32_t name_cap, int32_t *launches,
+                 double *total_ms, int64_t *calls, double *flops_per_site);
+int ds_reset_stage_times(ds_handle *h);
+
+/* Use a captured hipGraph for the forward (default on). */
+int ds_set_graph(ds_handle *h, int32_t enable);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DEEPSIGNAL_HIP_H */

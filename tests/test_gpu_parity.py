@@ -1,0 +1,142 @@
+"""GPU parity: HIP engine (through the C ABI) vs the CPU oracle on the same seeded inputs.
+
+Tolerances (fp32 everywhere; BASELINE.json north_star: outputs within 1e-4 of the reference):
+  * intermediates: max |gpu - oracle_f32| <= 2e-5 * max(1, max|oracle|)   (different summation order only)
+  * act (sigmoid outputs) and normalised probabilities: <= 1e-5 absolute (10x inside the 1e-4 gate)
+  * labels equal wherever |p1 - p0| > 1e-3
+"""
+import numpy as np
+import pytest
+
+from deepsignal_amd import spec, synth
+
+pytestmark = pytest.mark.gpu
+
+INTERMEDIATE_RTOL = 2e-5
+ACT_ATOL = 1e-5
+
+
+def _engine(weights, **kw):
+    from deepsignal_amd.engine import Engine
+    eng = Engine(**kw)
+    eng.load_weights(weights)
+    return eng
+
+
+def _norm(act):
+    return act / act.sum(axis=1, keepdims=True)
+
+
+def _check_outputs(act, pred, o_act, o_pred):
+    assert np.isfinite(act).all()
+    assert np.abs(act - o_act).max() <= ACT_ATOL
+    assert np.abs(_norm(act) - _norm(o_act)).max() <= ACT_ATOL
+    decided = np.abs(o_act[:, 1] - o_act[:, 0]) > 1e-3
+    assert (pred[decided] == o_pred[decided]).all()
+
+
+@pytest.mark.parametrize("n", [1, 24, 130])
+def test_layerwise_parity_vs_oracle(small_weights, n):
+    from oracle import oracle
+    feats = synth.synthetic_features(n, seed=100 + n)
+    eng = _engine(small_weights, max_batch=160, debug=True)
+    act, pred = eng.run(feats["kmer"], feats["means"], feats["stds"], feats["sanums"], feats["signals"])
+    o_act, o_pred, taps = oracle.forward(small_weights, feats, "f32", taps=True)
+    worst = {}
+    for name, ref in taps.items():
+        got = eng.intermediate(name, ref.shape)
+        err = float(np.abs(got - ref).max())
+        tol = INTERMEDIATE_RTOL * max(1.0, float(np.abs(ref).max()))
+        worst[name] = (err, tol)
+    bad = {k: v for k, v in worst.items() if not v[0] <= v[1]}
+    assert not bad, "intermediates out of tolerance: %s" % bad
+    _check_outputs(act, pred, o_act, o_pred)
+    eng.close()
+
+
+def test_batch_512_and_ragged_tail(small_weights):
+    """n > max_batch is looped inside ds_forward; last chunk is partial (call_modifications.py:157-166)."""
+    from oracle import oracle
+    n = 512 + 37
+    feats = synth.synthetic_features(n, seed=5)
+    eng = _engine(small_weights, max_batch=512)
+    act, pred = eng.run(feats["kmer"], feats["means"], feats["stds"], feats["sanums"], feats["signals"])
+    sel = np.r_[0:40, 500:549]
+    sub = {k: v[sel] for k, v in feats.items()}
+    o_act, o_pred = oracle.forward(small_weights, sub, "f32")
+    _check_outputs(act[sel], pred[sel], o_act, o_pred)
+    # batch-composition independence: the same site gives bit-identical results alone and in a batch
+    a1, p1 = eng.run(*(feats[k][7:8] for k in ("kmer", "means", "stds", "sanums", "signals")))
+    assert np.array_equal(a1[0], act[7]) and p1[0] == pred[7]
+    eng.close()
+
+
+def test_graph_and_eager_agree_and_are_deterministic(small_weights):
+    feats = synth.synthetic_features(96, seed=9)
+    eng = _engine(small_weights, max_batch=128)
+    args = [feats[k] for k in ("kmer", "means", "stds", "sanums", "signals")]
+    a_g, p_g = eng.run(*args)
+    a_g2, _ = eng.run(*args)
+    eng.set_graph(False)
+    a_e, p_e = eng.run(*args)
+    eng.set_profiling(True)
+    a_p, _ = eng.run(*args)
+    assert np.array_equal(a_g, a_g2) and np.array_equal(a_g, a_e) and np.array_equal(a_g, a_p)
+    assert np.array_equal(p_g, p_e)
+    st = {s["name"]: s for s in eng.stage_times()}
+    assert st["fc1"]["calls"] == 1 and st["fc1"]["total_ms"] > 0
+    total = sum(s["flops_per_site"] for s in st.values())
+    # layer-0 input projection is a table lookup, so the LSTM does fewer MACs than the reference graph
+    assert 0.9 * spec.FLOPS_PER_SITE < total <= spec.FLOPS_PER_SITE * 1.001
+    eng.close()
+
+
+def test_edge_inputs(small_weights):
+    """All-N k-mers, zero-padded (short) signal windows, extreme event lengths, empty batch."""
+    from oracle import oracle
+    feats = synth.synthetic_features(16, seed=11)
+    feats["kmer"][0, :] = 4
+    feats["signals"][1, 17:] = 0.0
+    feats["signals"][2, :] = 0.0
+    feats["sanums"][3, :] = 200.0
+    feats["means"][4, :] = 5.0
+    feats["means"][5, :] = -5.0
+    eng = _engine(small_weights, max_batch=64)
+    args = [feats[k] for k in ("kmer", "means", "stds", "sanums", "signals")]
+    act, pred = eng.run(*args)
+    o_act, o_pred = oracle.forward(small_weights, feats, "f32")
+    _check_outputs(act, pred, o_act, o_pred)
+    e_act, e_pred = eng.run(*(a[:0] for a in args))
+    assert e_act.shape == (0, 2) and e_pred.shape == (0,)
+    eng.close()
+
+
+def test_weight_file_roundtrip_matches_in_memory(small_weights, tmp_path):
+    from deepsignal_amd import weights as W
+    from deepsignal_amd.engine import Engine
+    path = str(tmp_path / "w.dsw")
+    W.save_weights(path, small_weights)
+    feats = synth.synthetic_features(8, seed=13)
+    args = [feats[k] for k in ("kmer", "means", "stds", "sanums", "signals")]
+    e1 = _engine(small_weights, max_batch=32)
+    e2 = Engine(max_batch=32)
+    e2.load_weights_file(path)
+    a1, _ = e1.run(*args)
+    a2, _ = e2.run(*args)
+    assert np.array_equal(a1, a2)
+    e1.close(); e2.close()
+
+
+def test_errors_are_loud(small_weights):
+    from deepsignal_amd.engine import Engine
+    eng = Engine(max_batch=8)
+    feats = synth.synthetic_features(4, seed=1)
+    with pytest.raises(RuntimeError):        # weights not loaded
+        eng.run(*(feats[k] for k in ("kmer", "means", "stds", "sanums", "signals")))
+    with pytest.raises(RuntimeError):        # variant not implemented must not silently run something else
+        Engine(is_cnn=False)
+    bad = dict(small_weights)
+    bad.pop("dense/kernel")
+    with pytest.raises(RuntimeError):
+        eng.load_weights(bad)
+    eng.close()
