@@ -1,0 +1,176 @@
+#!/usr/bin/env python3
+"""bench.py — CpG sites/sec of the call_mods forward on MI355X (BASELINE.json metric).
+
+One "step" = one pass of the hot path (ds_forward_device) over one batch of 512 synthetic
+(kmer=17, signal=360) sites whose features are already resident in HBM.  N>1: one process per GPU
+(torch.distributed / RCCL), sites sharded by read with a full weight replica per rank (weak
+scaling, no data-path collective); the only collective is the final result gather to rank 0.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+  roofline      the dominant kernel's achieved TFLOP/s (algorithmic 2*M*N*K per launch / HIP-event
+                duration per launch) against the fp32 MFMA peak
+  cpu_baseline  the CPU oracle (oracle/ds_oracle.c, "port") timed on this box's host cores
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+BATCH = 512
+PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+WORKLOAD = "configs[1]: 1xMI355X, batch=512, random-init CpG model weights, synthetic (17,360) features, fp32"
+
+
+def cpu_baseline(weights, budget_s=15.0):
+    """Bounded sample of the same workload through the CPU oracle on all host cores (kind: port)."""
+    import numpy as np
+    from deepsignal_amd import synth
+    from oracle import oracle
+    cores = os.cpu_count() or 1
+    feats = synth.synthetic_features(2048, seed=synth.FEATURE_SEED)
+    probe = {k: v[:64] for k, v in feats.items()}
+    oracle.forward(weights, probe, "f32", nthreads=cores)          # warm-up (page-in, thread pool)
+    t0 = time.perf_counter()
+    oracle.forward(weights, probe, "f32", nthreads=cores)
+    rate = 64 / (time.perf_counter() - t0)
+    n = int(min(2048, max(64, (rate * budget_s) // 32 * 32)))
+    sample = {k: v[:n] for k, v in feats.items()}
+    t0 = time.perf_counter()
+    oracle.forward(weights, sample, "f32", nthreads=cores)
+    dt = time.perf_counter() - t0
+    return {"value": round(n / dt, 2), "unit": "sites/s", "cores": cores, "kind": "port",
+            "sample": "%d synthetic sites of the same workload through oracle/ds_oracle.c (f32, OpenMP, %d threads), %.1f s"
+                      % (n, cores, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile-pass", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ..."
+                             % (args.gpus, args.gpus))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    from deepsignal_amd import spec, synth, weights as W
+    from deepsignal_amd.engine import Engine
+
+    w = W.random_weights(seed=W.WEIGHT_SEED)          # TF-initializer style, randomised BN
+    eng = Engine(device=local_rank, max_batch=BATCH)
+    eng.load_weights(w)
+
+    # this rank's shard: its own reads (20 sites per read), NPOOL distinct batches resident in HBM
+    NPOOL = 8
+    feats = synth.synthetic_features(NPOOL * BATCH, seed=synth.FEATURE_SEED + rank)
+    d = {k: torch.from_numpy(feats[k]).to(dev) for k in ("kmer", "means", "stds", "sanums", "signals")}
+    K, Wm = args.steps, args.warmup
+    out_act = torch.zeros((max(K, 1), BATCH, 2), dtype=torch.float32, device=dev)
+    out_pred = torch.zeros((max(K, 1), BATCH), dtype=torch.int32, device=dev)
+
+    def step(i, slot):
+        b = (i % NPOOL) * BATCH
+        eng.run_device(BATCH, d["kmer"][b:b + BATCH].data_ptr(), d["means"][b:b + BATCH].data_ptr(),
+                       d["stds"][b:b + BATCH].data_ptr(), d["sanums"][b:b + BATCH].data_ptr(),
+                       d["signals"][b:b + BATCH].data_ptr(), out_act[slot].data_ptr(), out_pred[slot].data_ptr())
+
+    def fence():
+        eng.sync()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for i in range(Wm):
+        step(i, 0)
+    fence()
+    t0 = time.perf_counter()
+    for i in range(K):
+        step(i, i)
+    eng.sync()
+    if dist is not None:
+        # the path's only exchange: gather f32[n,2] + i32[n] (12 B/site) to the writer rank over RCCL
+        packed = torch.cat([out_act.reshape(-1, 2), out_pred.reshape(-1, 1).to(torch.float32)], dim=1).contiguous()
+        gl = [torch.empty_like(packed) for _ in range(world)] if rank == 0 else None
+        dist.gather(packed, gl, dst=0)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert bool(torch.isfinite(out_act).all())
+
+    result = {
+        "metric": "CpG sites/sec (batch=512, k=17, sig=360)",
+        "value": round(world * K * BATCH / elapsed, 1) if K else 0.0,
+        "unit": "sites/s", "n_gpus": world, "steps": K, "warmup": Wm,
+        "ms_per_step": round(1e3 * elapsed / max(K, 1), 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": WORKLOAD, "batch": BATCH, "kmer_len": 17, "signal_len": 360,
+                   "sharding": "by read, %d rank(s), full weight replica per GPU" % world},
+    }
+
+    if rank == 0 and not args.no_profile_pass:
+        # per-launch HIP events on the engine's own streams (eager replay of the same K steps)
+        eng.set_profiling(True)
+        eng.reset_stage_times()
+        tp = time.perf_counter()
+        for i in range(K):
+            step(i, i)
+        eng.sync()
+        prof_ms = 1e3 * (time.perf_counter() - tp) / max(K, 1)
+        eng.set_profiling(False)
+        ks = [k for k in eng.kernel_stats() if k["launches"]]
+        dom = max(ks, key=lambda k: k["total_ms"])
+        per_launch_flops = dom["flops"] / dom["launches"]
+        avg_ms = dom["total_ms"] / dom["launches"]
+        achieved = per_launch_flops / (avg_ms * 1e-3) / 1e12
+        result["roofline"] = {
+            "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+            "kernel": dom["name"], "launches_per_step": dom["launches"] // max(K, 1),
+            "avg_launch_us": round(avg_ms * 1e3, 2), "flops_per_launch": per_launch_flops,
+            "profiled_ms_per_step": round(prof_ms, 4),
+            "whole_path_tflops": round(spec.FLOPS_PER_SITE * result["value"] / world / 1e12, 2),
+        }
+        result["kernels"] = {k["name"]: {"launches_per_step": k["launches"] // max(K, 1),
+                                          "us_per_step": round(1e3 * k["total_ms"] / max(K, 1), 1),
+                                          "tflops": round(k["flops"] / (k["total_ms"] * 1e-3) / 1e12, 2) if k["total_ms"] else 0}
+                             for k in ks}
+        result["stages_us_per_step"] = {s["name"]: round(1e3 * s["total_ms"] / max(s["calls"], 1), 1)
+                                        for s in eng.stage_times()}
+    eng.close()
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(w)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(result))
+
+
+if __name__ == "__main__":
+    main()

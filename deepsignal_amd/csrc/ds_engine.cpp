@@ -55,6 +55,20 @@ struct Op {
     const float* in = nullptr;
     float* out = nullptr;
     int a = 0, b = 0, c = 0, d = 0;
+    double flops = 0;                     // algorithmic FLOPs of this launch
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;   // profiling mode only
+    bool pending = false;
+};
+
+// per-kernel accumulators (one entry per __global__ function / template instantiation)
+enum KernelClass { K_GEMM_CONV = 0, K_GEMM_FC, K_GEMM_LSTM, K_GEMM_CONV_WIDE, K_GEMM_CONV_POOL, K_STEM1, K_MAXPOOL, K_AVGPOOL, K_HEAD, K_COUNT };
+const char* const kKernelNames[K_COUNT] = {"gemm_kernel<1,2,4,1,0,0>", "gemm_kernel<1,3,4,1,0,0>", "gemm_kernel<1,4,4,1,1,0>",
+                                           "gemm_kernel<2,2,2,2,0,0>", "gemm_kernel<1,2,4,1,0,1>", "stem1_kernel",
+                                           "maxpool_s2_kernel", "avgpool7_kernel", "head_kernel"};
+struct KernelStat {
+    int64_t launches = 0;
+    double total_ms = 0;
+    double flops = 0;
 };
 
 struct Stage {
@@ -64,8 +78,6 @@ struct Stage {
     double flops_per_site = 0;
     double total_ms = 0;
     int64_t calls = 0;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    bool pending = false;
 };
 
 struct Plan {
@@ -118,6 +130,7 @@ struct ds_handle {
     int* pred = nullptr;
 
     std::vector<Stage> stages;
+    KernelStat kstat[K_COUNT];
     std::map<int, Plan> plans;
     int last_n = 0;
 };
@@ -415,12 +428,12 @@ int build_plan(ds_handle* h, int n, Plan* plan)
         Op op{};
         op.kind = OP_GEMM; op.stream = stream; op.stage = stage; op.cfg = cfg;
         op.launch_index = (int)LS.size(); op.total_tiles = L.total_tiles;
+        for (int i = 0; i < L.nprob; ++i) op.flops += 2.0 * L.prob[i].M * (double)L.prob[i].N * L.prob[i].K;
         LS.push_back(L);
         list.push_back(op);
         if (first_plan) {
             h->stages[stage].launches += 1;
-            for (int i = 0; i < L.nprob; ++i)
-                h->stages[stage].flops_per_site += 2.0 * L.prob[i].M * (double)L.prob[i].N * L.prob[i].K / n;
+            h->stages[stage].flops_per_site += op.flops / n;
         }
     };
     auto add_ew_op = [&](std::vector<Op>& list, Op op) {
@@ -433,6 +446,7 @@ int build_plan(ds_handle* h, int n, Plan* plan)
     {
         Op op{};
         op.kind = OP_STEM1; op.stream = 0; op.stage = st; op.in = h->d_signals; op.out = h->stem_pool;
+        op.flops = 2.0 * h->w1 * 7 * 64 * n;
         add_ew_op(cnn, op);
         if (first_plan) h->stages[st].flops_per_site += 2.0 * h->w1 * 7 * 64;
         const int M = n * h->wa;
@@ -465,12 +479,14 @@ int build_plan(ds_handle* h, int n, Plan* plan)
             add_out(P, h->tmpS, 48, 48, 48, 0);             // branch5 stem (BN, no ReLU)
             add_out(P, h->tmpA, 96, 96, 96, 1);             // b3a | b4a | b5a
             add_tiles(L, P, CFG_CONV);
+            add_gemm_op(cnn, 0, st, CFG_CONV, L);
+            GemmLaunch L1{};
             GemmProblem Q = base_problem(M, 48, W, h->m_b1[m]);
-            Q.a_mode = 1;
+            Q.a_mode = 1;                                   // maxpool(3, s1) fused into the A load (layers.py:90-91)
             add_seg(Q, x, cin, 0, cin);
             add_out(Q, y, INC_OUT, 0, 48, 1);               // branch1
-            add_tiles(L, Q, CFG_CONV);
-            add_gemm_op(cnn, 0, st, CFG_CONV, L);
+            add_tiles(L1, Q, CFG_CONV_POOL);
+            add_gemm_op(cnn, 0, st, CFG_CONV_POOL, L1);
         }
         {   // second-stage convs from the 32-channel intermediates             layers.py:106-110,115-119,127-131
             GemmLaunch L{};
@@ -558,6 +574,7 @@ int build_plan(ds_handle* h, int n, Plan* plan)
     {
         Op op{};
         op.kind = OP_HEAD; op.stream = 0; op.stage = st;
+        op.flops = 2.0 * h->J * h->C * n;
         add_ew_op(tail, op);
         if (first_plan) h->stages[st].flops_per_site += 2.0 * h->J * h->C;
     }
@@ -602,50 +619,34 @@ int issue_op(ds_handle* h, Plan& plan, const Op& op, hipStream_t s)
 }
 
 // Enqueue the whole forward on (s0, s1): fork after the inputs are in place, join before fc1.
+// timed: bracket every launch with its own HIP event pair on the stream it is launched on.
 int enqueue_forward(ds_handle* h, Plan& plan, bool timed)
 {
     HIPCHK(h, hipEventRecord(h->ev_fork, h->s0));
     HIPCHK(h, hipStreamWaitEvent(h->s1, h->ev_fork, 0));
-    int cur_stage[2] = {-1, -1};
     bool joined = false;
-    auto close_stage = [&](int stream) -> int {
-        if (timed && cur_stage[stream] >= 0) {
-            Stage& S = h->stages[cur_stage[stream]];
-            HIPCHK(h, hipEventRecord(S.ev1, stream == 0 ? h->s0 : h->s1));
-            S.pending = true;
-        }
-        cur_stage[stream] = -1;
-        return DS_OK;
-    };
-    for (const Op& op : plan.ops) {
+    for (Op& op : plan.ops) {
         hipStream_t s = op.stream == 0 ? h->s0 : h->s1;
         const bool is_tail = h->stages[op.stage].name == "fc1" || h->stages[op.stage].name == "head";
         if (is_tail && !joined) {
-            int rc = close_stage(0); if (rc) return rc;
-            rc = close_stage(1); if (rc) return rc;
             HIPCHK(h, hipEventRecord(h->ev_join, h->s1));
             HIPCHK(h, hipStreamWaitEvent(h->s0, h->ev_join, 0));
             joined = true;
         }
-        if (timed && cur_stage[op.stream] != op.stage) {
-            // a stage whose events are still pending (e.g. "pools" runs three separate times) is
-            // flushed first so each interval is accumulated
-            int rc = close_stage(op.stream); if (rc) return rc;
-            Stage& S = h->stages[op.stage];
-            if (S.pending) {
-                HIPCHK(h, hipEventSynchronize(S.ev1));
-                float ms = 0;
-                HIPCHK(h, hipEventElapsedTime(&ms, S.ev0, S.ev1));
-                S.total_ms += ms; S.pending = false;
+        if (timed) {
+            if (!op.ev0) {
+                HIPCHK(h, hipEventCreate(&op.ev0));
+                HIPCHK(h, hipEventCreate(&op.ev1));
             }
-            HIPCHK(h, hipEventRecord(S.ev0, s));
-            cur_stage[op.stream] = op.stage;
+            HIPCHK(h, hipEventRecord(op.ev0, s));
         }
         int rc = issue_op(h, plan, op, s);
         if (rc) return rc;
+        if (timed) {
+            HIPCHK(h, hipEventRecord(op.ev1, s));
+            op.pending = true;
+        }
     }
-    int rc = close_stage(0); if (rc) return rc;
-    rc = close_stage(1); if (rc) return rc;
     if (!joined) {
         HIPCHK(h, hipEventRecord(h->ev_join, h->s1));
         HIPCHK(h, hipStreamWaitEvent(h->s0, h->ev_join, 0));
@@ -653,16 +654,33 @@ int enqueue_forward(ds_handle* h, Plan& plan, bool timed)
     return DS_OK;
 }
 
+int kernel_class(const Op& op)
+{
+    switch (op.kind) {
+    case OP_GEMM:
+        return op.cfg == CFG_CONV ? K_GEMM_CONV : op.cfg == CFG_FC ? K_GEMM_FC : op.cfg == CFG_LSTM ? K_GEMM_LSTM
+               : op.cfg == CFG_CONV_POOL ? K_GEMM_CONV_POOL : K_GEMM_CONV_WIDE;
+    case OP_STEM1: return K_STEM1;
+    case OP_MAXPOOL: return K_MAXPOOL;
+    case OP_AVGPOOL: return K_AVGPOOL;
+    case OP_HEAD: return K_HEAD;
+    }
+    return K_HEAD;
+}
+
 int collect_stage_times(ds_handle* h)
 {
-    for (Stage& S : h->stages) {
-        if (!S.pending) continue;
-        HIPCHK(h, hipEventSynchronize(S.ev1));
-        float ms = 0;
-        HIPCHK(h, hipEventElapsedTime(&ms, S.ev0, S.ev1));
-        S.total_ms += ms;
-        S.pending = false;
-    }
+    for (auto& kv : h->plans)
+        for (Op& op : kv.second.ops) {
+            if (!op.pending) continue;
+            HIPCHK(h, hipEventSynchronize(op.ev1));
+            float ms = 0;
+            HIPCHK(h, hipEventElapsedTime(&ms, op.ev0, op.ev1));
+            h->stages[op.stage].total_ms += ms;
+            KernelStat& K = h->kstat[kernel_class(op)];
+            K.launches += 1; K.total_ms += ms; K.flops += op.flops;
+            op.pending = false;
+        }
     return DS_OK;
 }
 
@@ -674,11 +692,6 @@ int get_plan(ds_handle* h, int n, Plan** out)
         int rc = build_plan(h, n, &p);
         if (rc) return rc;
         it = h->plans.emplace(n, std::move(p)).first;
-        for (Stage& S : h->stages)
-            if (!S.ev0) {
-                HIPCHK(h, hipEventCreate(&S.ev0));
-                HIPCHK(h, hipEventCreate(&S.ev1));
-            }
     }
     *out = &it->second;
     return DS_OK;
@@ -692,6 +705,8 @@ int run_resident(ds_handle* h, int n)
     if (rc) return rc;
     h->last_n = n;
     if (h->profiling) {
+        rc = collect_stage_times(h);      // events of a previous profiled forward are reused below
+        if (rc) return rc;
         rc = enqueue_forward(h, *plan, true);
         if (rc) return rc;
         for (Stage& S : h->stages) S.calls += 1;
@@ -772,7 +787,8 @@ void ds_destroy(ds_handle* h)
     if (h->s1) hipStreamSynchronize(h->s1);
     for (auto& kv : h->plans)
         if (kv.second.graph) hipGraphExecDestroy(kv.second.graph);
-    for (Stage& S : h->stages) { if (S.ev0) hipEventDestroy(S.ev0); if (S.ev1) hipEventDestroy(S.ev1); }
+    for (auto& kv : h->plans)
+        for (Op& op : kv.second.ops) { if (op.ev0) hipEventDestroy(op.ev0); if (op.ev1) hipEventDestroy(op.ev1); }
     for (void* p : h->allocs) hipFree(p);
     if (h->ev_fork) hipEventDestroy(h->ev_fork);
     if (h->ev_join) hipEventDestroy(h->ev_join);
@@ -982,6 +998,20 @@ int ds_reset_stage_times(ds_handle* h)
 {
     if (!h) return DS_ERR_INVALID;
     for (Stage& S : h->stages) { S.total_ms = 0; S.calls = 0; }
+    for (KernelStat& K : h->kstat) K = KernelStat();
+    return DS_OK;
+}
+
+int ds_num_kernels(ds_handle* h) { return h ? (int)K_COUNT : DS_ERR_INVALID; }
+
+int ds_get_kernel_stat(ds_handle* h, int32_t index, char* name, int32_t name_cap, int64_t* launches, double* total_ms,
+                       double* flops)
+{
+    if (!h || index < 0 || index >= K_COUNT) return DS_ERR_INVALID;
+    if (name && name_cap > 0) { strncpy(name, kKernelNames[index], name_cap - 1); name[name_cap - 1] = 0; }
+    if (launches) *launches = h->kstat[index].launches;
+    if (total_ms) *total_ms = h->kstat[index].total_ms;
+    if (flops) *flops = h->kstat[index].flops;
     return DS_OK;
 }
 

@@ -52,7 +52,7 @@ struct LstmEp {
 
 struct GemmProblem {
     int M, N, K, W;             // K = sum of the used segments' klen
-    int a_mode;                 // 0: plain / taps, 1: maxpool(3, stride 1, SAME) of segment 0 on load
+    int a_mode;                 // informational: 1 = maxpool(3, stride 1, SAME) on load (kernel variant CFG_CONV_POOL)
     int nseg;
     int kgroups_stride;         // K-groups (of 8) per packed n-tile panel in Bp
     int nout;
@@ -71,7 +71,7 @@ struct GemmLaunch {
     int pad_[2];
 };
 
-enum GemmCfg { CFG_CONV = 0, CFG_FC = 1, CFG_LSTM = 2, CFG_CONV_WIDE = 3 };
+enum GemmCfg { CFG_CONV = 0, CFG_FC = 1, CFG_LSTM = 2, CFG_CONV_WIDE = 3, CFG_CONV_POOL = 4 };
 
 // tile geometry per config (host needs it for grid sizing)
 struct TileGeom { int bm, bn, threads; };

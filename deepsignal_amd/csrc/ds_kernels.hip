@@ -26,7 +26,22 @@ __device__ __forceinline__ float4 f4max(float4 a, float4 b)
 }
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
-template <int MT, int NT, int WM, int WN, int EPI>
+// Pointers reach the kernels through descriptor structs, so the compiler only knows them as
+// generic; these casts make every access a global_* instruction (flat_* would tie vmcnt and
+// lgkmcnt together and force full drains before each MFMA block).
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(1))) v4f* gptr4;
+typedef const __attribute__((address_space(1))) float* gptr1;
+typedef __attribute__((address_space(1))) float* gptr1w;
+__device__ __forceinline__ float4 gload4(const float* p)
+{
+    const v4f v = *(gptr4)(p);
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ float gload(const float* p) { return *(gptr1)(p); }
+__device__ __forceinline__ void gstore(float* p, float v) { *(gptr1w)(p) = v; }
+
+template <int MT, int NT, int WM, int WN, int EPI, int AMODE>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmLaunch* __restrict__ L)
 {
     constexpr int BM = WM * MT * 32;
@@ -46,27 +61,29 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmLaunch* __
     const int tm = local % P.tiles_m, tn = local / P.tiles_m;
     const int m0 = tm * BM;
     const int M = P.M, W = P.W;
-    const int a_mode = P.a_mode;
     const int nchunks = P.K / KC;
+    const int nseg = P.nseg;
 
-    int sm[SLOTS], sw[SLOTS], sq[SLOTS];
+    // per-slot row bookkeeping (a slot = one float4 of the staged A chunk)
+    int sm[SLOTS], sw[SLOTS];
     bool sin_[SLOTS];
 #pragma unroll
     for (int i = 0; i < SLOTS; ++i) {
         const int idx = tid + i * NTHR;
-        const int r = idx >> 2;
-        sq[i] = idx & 3;
-        sm[i] = m0 + r;
+        sm[i] = m0 + (idx >> 2);
         sin_[i] = (idx < BM * 4) && (sm[i] < M);
         sw[i] = sm[i] % W;
     }
 
     int ntile[NT];
     bool nvalid[NT];
+    const float* bp[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         ntile[nt] = (tn * WN + wn) * NT + nt;
         nvalid[nt] = ntile[nt] < P.ntiles32;
+        const int tcl = nvalid[nt] ? ntile[nt] : P.ntiles32 - 1;   // clamp: loads stay in bounds, result unused
+        bp[nt] = P.Bp + (size_t)tcl * P.kgroups_stride * 256 + lane * 4;
     }
 
     floatx16 acc[MT][NT];
@@ -77,89 +94,129 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmLaunch* __
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.0f;
 
-    int seg_i = 0, seg_k = 0;   // uniform cursor of the chunk being LOADED
-
-    auto load_a = [&](float4(&reg)[SLOTS]) {
-        const float* base = P.seg[seg_i].base;
-        const int ld = P.seg[seg_i].ld;
-        const int shift = P.seg[seg_i].row_shift;
-#pragma unroll
-        for (int i = 0; i < SLOTS; ++i) {
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (a_mode == 0) {
-                const int ws = sw[i] + shift;
-                if (sin_[i] && (unsigned)ws < (unsigned)W)
-                    v = *reinterpret_cast<const float4*>(base + (size_t)(sm[i] + shift) * ld + seg_k + sq[i] * 4);
-            } else if (sin_[i]) {   // maxpool(3, stride 1, SAME): padded taps ignored
-                const float* p = base + (size_t)sm[i] * ld + seg_k + sq[i] * 4;
-                v = *reinterpret_cast<const float4*>(p);
-                if (sw[i] > 0) v = f4max(v, *reinterpret_cast<const float4*>(p - ld));
-                if (sw[i] < W - 1) v = f4max(v, *reinterpret_cast<const float4*>(p + ld));
-            }
-            reg[i] = v;
-        }
-        seg_k += KC;
-        if (seg_k >= P.seg[seg_i].klen) { seg_k = 0; ++seg_i; }
-    };
-    auto store_a = [&](float* dst, const float4(&reg)[SLOTS]) {
+    // A cursor: branch-free loads. Every slot always loads from a legal address (its own row when
+    // valid, the segment base otherwise) and invalid slots are zeroed by a select afterwards.
+    const float* ap[SLOTS];
+    const float* apm[SLOTS];   // AMODE 1: previous / next row (clamped to the own row at site edges)
+    const float* app[SLOTS];
+    bool aok[SLOTS];
+    int seg_i = 0, seg_left = 0;
+    auto seg_begin = [&](int si) {
+        const float* base = P.seg[si].base;
+        const int ld = P.seg[si].ld;
+        const int shift = P.seg[si].row_shift;
+        seg_left = P.seg[si].klen / KC;
 #pragma unroll
         for (int i = 0; i < SLOTS; ++i) {
             const int idx = tid + i * NTHR;
-            if (idx < BM * 4) *reinterpret_cast<float4*>(dst + (idx >> 2) * LDA + (idx & 3) * 4) = reg[i];
+            const int ws = sw[i] + shift;
+            aok[i] = sin_[i] && (unsigned)ws < (unsigned)W;
+            const float* q = base + (size_t)(sm[i] + shift) * ld + (idx & 3) * 4;
+            ap[i] = aok[i] ? q : base;
+            if (AMODE == 1) {
+                apm[i] = (aok[i] && sw[i] > 0) ? q - ld : ap[i];
+                app[i] = (aok[i] && sw[i] < W - 1) ? q + ld : ap[i];
+            }
         }
     };
-    auto load_b = [&](float4(&b)[NT][2], int chunk) {
+    // raw loads only; the SAME-padding select (and the 3-tap max of AMODE 1) is applied when the
+    // chunk is written to LDS one compute phase later, so no load is waited for early
+    float4 areg[SLOTS], aregm[SLOTS], aregp[SLOTS];
+    bool lok[SLOTS];
+    auto load_a = [&]() {
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-            for (int rs = 0; rs < 2; ++rs) {
-                if (nvalid[nt])
-                    b[nt][rs] = *reinterpret_cast<const float4*>(
-                        P.Bp + ((size_t)ntile[nt] * P.kgroups_stride + chunk * 2 + rs) * 256 + lane * 4);
-                else
-                    b[nt][rs] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int i = 0; i < SLOTS; ++i) {
+            areg[i] = gload4(ap[i]);
+            ap[i] += KC;
+            if (AMODE == 1) {
+                aregm[i] = gload4(apm[i]);
+                aregp[i] = gload4(app[i]);
+                apm[i] += KC;
+                app[i] += KC;
             }
+            lok[i] = aok[i];
+        }
+        if (--seg_left == 0 && ++seg_i < nseg) seg_begin(seg_i);
+    };
+    auto store_a = [&](float* dst) {
+#pragma unroll
+        for (int i = 0; i < SLOTS; ++i) {
+            const int idx = tid + i * NTHR;
+            float4 v = areg[i];
+            if (AMODE == 1) v = f4max(f4max(v, aregm[i]), aregp[i]);   // maxpool(3, s1, SAME): padded taps ignored
+            v.x = lok[i] ? v.x : 0.0f;
+            v.y = lok[i] ? v.y : 0.0f;
+            v.z = lok[i] ? v.z : 0.0f;
+            v.w = lok[i] ? v.w : 0.0f;
+            if (SLOTS * NTHR == BM * 4 || idx < BM * 4)
+                *reinterpret_cast<float4*>(dst + (idx >> 2) * LDA + (idx & 3) * 4) = v;
+        }
+    };
+    auto load_b = [&](float4(&b)[NT][2]) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            b[nt][0] = gload4(bp[nt]);
+            b[nt][1] = gload4(bp[nt] + 256);
+            bp[nt] += 512;
+        }
     };
     auto compute = [&](const float* src, const float4(&b)[NT][2]) {
+        float4 a[2][MT];
 #pragma unroll
-        for (int rs = 0; rs < 2; ++rs) {
-            float4 a[MT];
+        for (int rs = 0; rs < 2; ++rs)
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
-                a[mt] = *reinterpret_cast<const float4*>(
+                a[rs][mt] = *reinterpret_cast<const float4*>(
                     src + ((wm * MT + mt) * 32 + (lane & 31)) * LDA + rs * 8 + (lane >> 5) * 4);
+#pragma unroll
+        for (int rs = 0; rs < 2; ++rs)
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt].x, b[nt][rs].x, acc[mt][nt], 0, 0, 0);
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt].y, b[nt][rs].y, acc[mt][nt], 0, 0, 0);
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt].z, b[nt][rs].z, acc[mt][nt], 0, 0, 0);
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt].w, b[nt][rs].w, acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[rs][mt].x, b[nt][rs].x, acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[rs][mt].y, b[nt][rs].y, acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[rs][mt].z, b[nt][rs].z, acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[rs][mt].w, b[nt][rs].w, acc[mt][nt], 0, 0, 0);
                 }
-        }
     };
 
-    float4 areg[SLOTS];
     float4 b0[NT][2], b1[NT][2];
     if (nchunks > 0) {
-        load_a(areg);
-        load_b(b0, 0);
-        store_a(As[0], areg);
+        seg_begin(0);
+        load_a();
+        load_b(b0);
+        store_a(As[0]);
     }
     __syncthreads();
-    for (int c = 0; c < nchunks; c += 2) {
-        const bool more1 = c + 1 < nchunks;
-        if (more1) { load_a(areg); load_b(b1, c + 1); }
+    int c = 0;
+    // steady state: two chunks per trip, no conditionals inside (chunk c in As[0]/b0 on entry)
+    // sched_barrier(0) pins the prefetch loads ABOVE the MFMA block: left alone, hipcc sinks them
+    // below it to shorten live ranges and their latency is then exposed every chunk.
+    while (c + 2 < nchunks) {
+        load_a(); load_b(b1);
+        __builtin_amdgcn_sched_barrier(0);
         compute(As[0], b0);
-        if (more1) store_a(As[1], areg);
+        __builtin_amdgcn_sched_barrier(0);
+        store_a(As[1]);
         __syncthreads();
-        if (!more1) break;
-        const bool more2 = c + 2 < nchunks;
-        if (more2) { load_a(areg); load_b(b0, c + 2); }
+        load_a(); load_b(b0);
+        __builtin_amdgcn_sched_barrier(0);
         compute(As[1], b1);
-        if (more2) store_a(As[0], areg);
+        __builtin_amdgcn_sched_barrier(0);
+        store_a(As[0]);
         __syncthreads();
+        c += 2;
+    }
+    if (nchunks - c == 2) {
+        load_a(); load_b(b1);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(As[0], b0);
+        store_a(As[1]);
+        __syncthreads();
+        compute(As[1], b1);
+    } else if (nchunks - c == 1) {
+        compute(As[0], b0);
     }
 
     // ---------------- epilogue ----------------
@@ -174,7 +231,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmLaunch* __
                 if (col >= P.out[o].col0) sel = o;
             const OSeg os = P.out[sel];
             const int cc = col - os.col0;
-            const float bias = P.bias ? P.bias[col] : 0.0f;
+            const float bias = P.bias ? gload(P.bias + col) : 0.0f;
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -182,9 +239,9 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmLaunch* __
                     const int row = rbase + mt * 32 + (r & 3) + 8 * (r >> 2);
                     if (row < M) {
                         float v = acc[mt][nt][r] + bias;
-                        if (os.add) v += os.add[(size_t)row * os.add_ld + cc];
+                        if (os.add) v += gload(os.add + (size_t)row * os.add_ld + cc);
                         if (os.relu) v = fmaxf(v, 0.0f);
-                        os.base[(size_t)row * os.ld + cc] = v;
+                        gstore(os.base + (size_t)row * os.ld + cc, v);
                     }
                 }
         }
@@ -240,6 +297,7 @@ TileGeom gemm_geom(GemmCfg cfg)
     case CFG_FC: return {128, 96, 256};          // MT1 NT3 WM4 WN1
     case CFG_LSTM: return {128, 128, 256};       // MT1 NT4 WM4 WN1 (one 32-unit gate group per block)
     case CFG_CONV_WIDE: return {128, 128, 256};  // MT2 NT2 WM2 WN2
+    case CFG_CONV_POOL: return {128, 64, 256};   // CFG_CONV with maxpool(3,s1) fused into the A load
     }
     return {0, 0, 0};
 }
@@ -248,10 +306,11 @@ hipError_t launch_gemm(GemmCfg cfg, const GemmLaunch* d_launch, int total_tiles,
 {
     if (total_tiles <= 0) return hipSuccess;
     switch (cfg) {
-    case CFG_CONV: hipLaunchKernelGGL((gemm_kernel<1, 2, 4, 1, 0>), dim3(total_tiles), dim3(256), 0, s, d_launch); break;
-    case CFG_FC: hipLaunchKernelGGL((gemm_kernel<1, 3, 4, 1, 0>), dim3(total_tiles), dim3(256), 0, s, d_launch); break;
-    case CFG_LSTM: hipLaunchKernelGGL((gemm_kernel<1, 4, 4, 1, 1>), dim3(total_tiles), dim3(256), 0, s, d_launch); break;
-    case CFG_CONV_WIDE: hipLaunchKernelGGL((gemm_kernel<2, 2, 2, 2, 0>), dim3(total_tiles), dim3(256), 0, s, d_launch); break;
+    case CFG_CONV: hipLaunchKernelGGL((gemm_kernel<1, 2, 4, 1, 0, 0>), dim3(total_tiles), dim3(256), 0, s, d_launch); break;
+    case CFG_FC: hipLaunchKernelGGL((gemm_kernel<1, 3, 4, 1, 0, 0>), dim3(total_tiles), dim3(256), 0, s, d_launch); break;
+    case CFG_LSTM: hipLaunchKernelGGL((gemm_kernel<1, 4, 4, 1, 1, 0>), dim3(total_tiles), dim3(256), 0, s, d_launch); break;
+    case CFG_CONV_WIDE: hipLaunchKernelGGL((gemm_kernel<2, 2, 2, 2, 0, 0>), dim3(total_tiles), dim3(256), 0, s, d_launch); break;
+    case CFG_CONV_POOL: hipLaunchKernelGGL((gemm_kernel<1, 2, 4, 1, 0, 1>), dim3(total_tiles), dim3(256), 0, s, d_launch); break;
     }
     return hipGetLastError();
 }

@@ -23,7 +23,7 @@ EXPORTED_SYMBOLS = (
     "ds_create", "ds_destroy", "ds_last_error", "ds_version", "ds_load_weights", "ds_set_tensor",
     "ds_finalize_weights", "ds_forward", "ds_forward_device", "ds_sync", "ds_alloc_host", "ds_free_host",
     "ds_get_intermediate", "ds_set_profiling", "ds_num_stages", "ds_get_stage", "ds_reset_stage_times",
-    "ds_set_graph",
+    "ds_set_graph", "ds_num_kernels", "ds_get_kernel_stat",
 )
 
 
@@ -73,6 +73,9 @@ def load_library() -> ctypes.CDLL:
                                  ctypes.POINTER(i64), ctypes.POINTER(ctypes.c_double)]
     lib.ds_reset_stage_times.argtypes = [vp]
     lib.ds_set_graph.argtypes = [vp, i32]
+    lib.ds_num_kernels.argtypes = [vp]
+    lib.ds_get_kernel_stat.argtypes = [vp, i32, ctypes.c_char_p, i32, ctypes.POINTER(i64),
+                                       ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
     _lib = lib
     return lib
 
@@ -182,4 +185,17 @@ class Engine:
                                                ctypes.byref(calls), ctypes.byref(flops)), "ds_get_stage")
             out.append({"name": name.value.decode(), "launches": launches.value, "total_ms": ms.value,
                         "calls": calls.value, "flops_per_site": flops.value})
+        return out
+
+    def kernel_stats(self) -> List[dict]:
+        out = []
+        for i in range(self._lib.ds_num_kernels(self._h)):
+            name = ctypes.create_string_buffer(96)
+            launches = ctypes.c_int64()
+            ms = ctypes.c_double()
+            flops = ctypes.c_double()
+            self._check(self._lib.ds_get_kernel_stat(self._h, i, name, 96, ctypes.byref(launches), ctypes.byref(ms),
+                                                     ctypes.byref(flops)), "ds_get_kernel_stat")
+            out.append({"name": name.value.decode(), "launches": launches.value, "total_ms": ms.value,
+                        "flops": flops.value})
         return out

@@ -43,7 +43,7 @@ typedef struct ds_config {
     int32_t device;       /* HIP device ordinal */
     int32_t precision;    /* DS_PRECISION_FP32 */
     int32_t max_batch;    /* largest n per device pass (workspaces are sized for it); larger n is looped */
-    int32_t reserved[7];
+    int32_t reserved[7];  /* reserved[0] != 0: debug mode — keep every module output for ds_get_intermediate */
 } ds_config;
 
 /* Replaces Model(...) + tf.Session(): call_modifications.py:203-209. */
@@ -94,6 +94,13 @@ int ds_num_stages(ds_handle *h);
 int ds_get_stage(ds_handle *h, int32_t index, char *name, int32_t name_cap, int32_t *launches,
                  double *total_ms, int64_t *calls, double *flops_per_site);
 int ds_reset_stage_times(ds_handle *h);
+/* Per-kernel accumulators of the same profiling mode: every launch is bracketed by its own HIP
+ * event pair on the stream it runs on. name = the __global__ function (as rocprofv3 prints it),
+ * launches / total_ms / flops = launch count, summed device time and summed ALGORITHMIC FLOPs
+ * (2*M*N*K of the GEMMs the launch carries) since the last reset. */
+int ds_num_kernels(ds_handle *h);
+int ds_get_kernel_stat(ds_handle *h, int32_t index, char *name, int32_t name_cap, int64_t *launches,
+                       double *total_ms, double *flops);
 
 /* Use a captured hipGraph for the forward (default on). */
 int ds_set_graph(ds_handle *h, int32_t enable);
