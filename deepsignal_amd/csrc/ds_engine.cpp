@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <map>
@@ -42,7 +43,7 @@ struct PackedGemm {      // device-resident packed weights of one GEMM
     int K = 0, N = 0;
 };
 
-enum OpKind { OP_GEMM, OP_STEM1, OP_MAXPOOL, OP_AVGPOOL, OP_HEAD };
+enum OpKind { OP_GEMM, OP_STEM1, OP_MAXPOOL, OP_AVGPOOL, OP_HEAD, OP_FUSED };
 
 struct Op {
     OpKind kind;
@@ -55,15 +56,18 @@ struct Op {
     const float* in = nullptr;
     float* out = nullptr;
     int a = 0, b = 0, c = 0, d = 0;
+    FusedArgs fa{};                       // OP_FUSED
+    int tm = 0;
     double flops = 0;                     // algorithmic FLOPs of this launch
     hipEvent_t ev0 = nullptr, ev1 = nullptr;   // profiling mode only
     bool pending = false;
 };
 
 // per-kernel accumulators (one entry per __global__ function / template instantiation)
-enum KernelClass { K_GEMM_CONV = 0, K_GEMM_FC, K_GEMM_LSTM, K_GEMM_CONV_WIDE, K_GEMM_CONV_POOL, K_STEM1, K_MAXPOOL, K_AVGPOOL, K_HEAD, K_COUNT };
+enum KernelClass { K_GEMM_CONV = 0, K_GEMM_FC, K_GEMM_LSTM, K_GEMM_CONV_WIDE, K_GEMM_CONV_POOL, K_FUSED1, K_FUSED2, K_FUSED3, K_STEM1, K_MAXPOOL, K_AVGPOOL, K_HEAD, K_COUNT };
 const char* const kKernelNames[K_COUNT] = {"gemm_kernel<1,2,4,1,0,0>", "gemm_kernel<1,3,4,1,0,0>", "gemm_kernel<1,4,4,1,1,0>",
-                                           "gemm_kernel<2,2,2,2,0,0>", "gemm_kernel<1,2,4,1,0,1>", "stem1_kernel",
+                                           "gemm_kernel<2,2,2,2,0,0>", "gemm_kernel<1,2,4,1,0,1>", "inception_fused_kernel<1>",
+                                           "inception_fused_kernel<2>", "inception_fused_kernel<3>", "stem1_kernel",
                                            "maxpool_s2_kernel", "avgpool7_kernel", "head_kernel"};
 struct KernelStat {
     int64_t launches = 0;
@@ -109,6 +113,7 @@ struct ds_handle {
     // packed weights
     float *stem1_w = nullptr, *stem1_b = nullptr;
     PackedGemm conv2, conv3;
+    PackedGemm m_f1[NMOD];   // fused-module stage 1: [b5s|b2|b3a|b4a|b5a|b1]
     PackedGemm m_s1[NMOD], m_b1[NMOD], m_b3b[NMOD], m_b4b[NMOD], m_b5b[NMOD], m_b5c[NMOD];
     PackedGemm lstm[2][NLAYER];
     float* lstm_table[2] = {nullptr, nullptr};
@@ -241,7 +246,7 @@ int upload_concat(ds_handle* h, const std::vector<const FoldedConv*>& parts, Pac
         const FoldedConv* p = parts[owner[col]];
         return p->w[(size_t)k * p->cout + local[col]];
     });
-    std::vector<float> bias(N);
+    std::vector<float> bias((N + 31) / 32 * 32, 0.0f);
     for (int col = 0; col < N; ++col) bias[col] = parts[owner[col]]->b[local[col]];
     pg->K = K; pg->N = N;
     int rc = upload(h, &pg->Bp, packed);
@@ -286,6 +291,7 @@ int finalize_weights(ds_handle* h)
         // the five 1x1 convs that read the module input share one GEMM: [b2 | b5s | b3a | b4a | b5a]
         if ((rc = upload_concat(h, {&b2, &b5s, &b3a, &b4a, &b5a}, &h->m_s1[m]))) return rc;
         if ((rc = upload_concat(h, {&b1}, &h->m_b1[m]))) return rc;
+        if ((rc = upload_concat(h, {&b5s, &b2, &b3a, &b4a, &b5a, &b1}, &h->m_f1[m]))) return rc;
         if ((rc = upload_concat(h, {&b3b}, &h->m_b3b[m]))) return rc;
         if ((rc = upload_concat(h, {&b4b}, &h->m_b4b[m]))) return rc;
         if ((rc = upload_concat(h, {&b5b}, &h->m_b5b[m]))) return rc;
@@ -471,6 +477,30 @@ int build_plan(ds_handle* h, int n, Plan* plan)
         st = stage_id(h, nm, 0);
         const int W = module_width(h, m), M = n * W;
         float* y = h->modout[m];
+        static const bool no_fused = getenv("DS_NO_FUSED") != nullptr;
+        if (!no_fused && W <= 96) {
+            // one fused launch per module; tile = spt whole sites (<= 96 rows). Pick the spt that
+            // minimises padded rows while keeping >= 256 workgroups when the batch allows it.
+            int best_spt = 1; long best_rows = -1;
+            for (int spt = 1; spt * W <= 96; ++spt) {
+                const int tiles = (n + spt - 1) / spt;
+                if (spt > 1 && tiles < std::min(256, n)) break;
+                const long rows = (long)tiles * ((spt * W + 31) / 32) * 32;
+                if (best_rows < 0 || rows < best_rows) { best_rows = rows; best_spt = spt; }
+            }
+            Op op{};
+            op.kind = OP_FUSED; op.stream = 0; op.stage = st;
+            op.tm = (best_spt * W + 31) / 32;
+            op.fa.X = x; op.fa.Y = y; op.fa.n_sites = n; op.fa.W = W; op.fa.cin = cin; op.fa.spt = best_spt;
+            op.fa.Bp1 = h->m_f1[m].Bp; op.fa.bias1 = h->m_f1[m].bias;
+            op.fa.Bp3b = h->m_b3b[m].Bp; op.fa.bias3b = h->m_b3b[m].bias;
+            op.fa.Bp4b = h->m_b4b[m].Bp; op.fa.bias4b = h->m_b4b[m].bias;
+            op.fa.Bp5b = h->m_b5b[m].Bp; op.fa.bias5b = h->m_b5b[m].bias;
+            op.fa.Bp5c = h->m_b5c[m].Bp; op.fa.bias5c = h->m_b5c[m].bias;
+            op.flops = 2.0 * M * ((double)cin * 240 + 96 * 48 + 160 * 48 + 96 * 64 + 64 * 48);
+            if (first_plan) h->stages[st].flops_per_site += op.flops / n;
+            add_ew_op(cnn, op);
+        } else {
         {   // five 1x1 convs on the module input + branch1 (maxpool on load)   layers.py:90-101,103,112,121-126
             GemmLaunch L{};
             GemmProblem P = base_problem(M, 192, W, h->m_s1[m]);
@@ -511,6 +541,7 @@ int build_plan(ds_handle* h, int n, Plan* plan)
             add_out(P, y + 192, INC_OUT, 0, 48, 1, h->tmpS, 48);
             add_tiles(L, P, CFG_CONV);
             add_gemm_op(cnn, 0, st, CFG_CONV, L);
+        }
         }
         x = y; cin = INC_OUT;
         if (m == 2 || m == 7) {   // maxpool_layer2/3                            layers.py:211-213,224-226
@@ -611,6 +642,9 @@ int issue_op(ds_handle* h, Plan& plan, const Op& op, hipStream_t s)
     case OP_AVGPOOL:
         HIPCHK(h, launch_avgpool7(op.in, op.out, n, op.a, op.d, s));
         break;
+    case OP_FUSED:
+        HIPCHK(h, launch_inception_fused(op.tm, op.fa, s));
+        break;
     case OP_HEAD:
         HIPCHK(h, launch_head(h->fc1o, h->fc2, h->logits, h->act, h->pred, n, h->J, h->C, s));
         break;
@@ -625,8 +659,9 @@ int enqueue_forward(ds_handle* h, Plan& plan, bool timed)
     HIPCHK(h, hipEventRecord(h->ev_fork, h->s0));
     HIPCHK(h, hipStreamWaitEvent(h->s1, h->ev_fork, 0));
     bool joined = false;
+    static const bool serial = getenv("DS_SERIAL") != nullptr;   // diagnostic: one stream, no overlap
     for (Op& op : plan.ops) {
-        hipStream_t s = op.stream == 0 ? h->s0 : h->s1;
+        hipStream_t s = (op.stream == 0 || serial) ? h->s0 : h->s1;
         const bool is_tail = h->stages[op.stage].name == "fc1" || h->stages[op.stage].name == "head";
         if (is_tail && !joined) {
             HIPCHK(h, hipEventRecord(h->ev_join, h->s1));
@@ -660,6 +695,7 @@ int kernel_class(const Op& op)
     case OP_GEMM:
         return op.cfg == CFG_CONV ? K_GEMM_CONV : op.cfg == CFG_FC ? K_GEMM_FC : op.cfg == CFG_LSTM ? K_GEMM_LSTM
                : op.cfg == CFG_CONV_POOL ? K_GEMM_CONV_POOL : K_GEMM_CONV_WIDE;
+    case OP_FUSED: return op.tm == 1 ? K_FUSED1 : op.tm == 2 ? K_FUSED2 : K_FUSED3;
     case OP_STEM1: return K_STEM1;
     case OP_MAXPOOL: return K_MAXPOOL;
     case OP_AVGPOOL: return K_AVGPOOL;

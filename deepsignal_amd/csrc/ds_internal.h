@@ -79,6 +79,20 @@ TileGeom gemm_geom(GemmCfg cfg);
 
 hipError_t launch_gemm(GemmCfg cfg, const GemmLaunch* d_launch, int total_tiles, hipStream_t s);
 
+// One fused inception module (layers.py:87-139): every conv+BN(+ReLU) of the module, the
+// stride-1 maxpool of branch 1 and the residual add, with all intermediates kept in LDS.
+struct FusedArgs {
+    const float* X;      // [n_sites*W, cin] NWC input
+    float* Y;            // [n_sites*W, 240] output (concat order b1|b2|b3|b4|b5)
+    int n_sites, W, cin, spt;   // spt = sites per workgroup tile (whole sites only: taps never cross tiles)
+    const float* Bp1;    // packed [cin x 256]: columns b5s(48)|b2(48)|b3a(32)|b4a(32)|b5a(32)|b1(48, pooled input)|pad
+    const float* bias1;  // [256]
+    const float *Bp3b, *bias3b, *Bp4b, *bias4b, *Bp5b, *bias5b, *Bp5c, *bias5c;
+};
+// tm = 32-row m-tiles per workgroup (1..3), spt*W <= 32*tm
+hipError_t launch_inception_fused(int tm, const FusedArgs& a, hipStream_t s);
+size_t inception_fused_lds_bytes(int tm, int W, int spt);
+
 // stem conv1 (K=7, stride 2, Cin=1) + folded BN + ReLU + maxpool(3, stride 2)   layers.py:183-191
 hipError_t launch_stem1(const float* signals, const float* w7x64, const float* bias64, float* out,
                         int n, int signal_len, int w1, int pad_l_conv, int wa, int pad_l_pool, hipStream_t s);

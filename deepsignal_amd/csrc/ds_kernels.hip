@@ -316,6 +316,300 @@ hipError_t launch_gemm(GemmCfg cfg, const GemmLaunch* d_launch, int total_tiles,
 }
 
 // ---------------------------------------------------------------------------------------------
+// Fused inception module. One workgroup (8 waves) owns a tile of whole sites (<= 96 rows):
+//   P1  [rows x cin] x [cin x 256]: the six 1x1 convs that read the module input in ONE pass over
+//       it (branch 1 reads the 3-tap max-pooled rows, staged next to the plain rows). Wave w owns
+//       n-tile w for all m-tiles. b2/b1 go straight to HBM, the three 32-channel intermediates go
+//       to LDS (T1, with zero halo rows = SAME padding), the residual stem stays in accumulators.
+//   P2a 1x3 64-ch conv of branch 5 (T1 -> T2 in LDS) + part of branch 3.
+//   P2b branch 5's last 1x1 accumulates ON TOP of the stem accumulators (waves 0,1) while the other
+//       waves finish the 1x3 / 1x5 convs of branches 3 and 4.
+// HBM traffic per module = read input once + write output once (module-granular bytes).
+constexpr int F_LDA = KC + 4;   // staged chunk row stride (floats)
+constexpr int F_LD1 = 100;      // T1 row stride: 96 channels + 4 pad (25 x 16 B: odd -> conflict-free b128)
+constexpr int F_LD2 = 68;       // T2 row stride: 64 channels + 4 pad
+
+size_t inception_fused_lds_bytes(int tm, int W, int spt)
+{
+    const int tr32 = tm * 32;
+    return (size_t)(4 * tr32 * F_LDA + spt * (W + 4) * F_LD1 + tr32) * sizeof(float);
+}
+
+template <int NTAPS>
+__device__ __forceinline__ void fused_conv_unit(const float* T1, int rm, int coloff, int nt, int lane,
+                                                const float* __restrict__ Bp, floatx16& acc)
+{
+    constexpr int NRS = NTAPS * 4;      // 8-wide k-groups: 4 per 32-channel tap
+    float4 b[NRS];
+#pragma unroll
+    for (int g = 0; g < NRS; ++g) b[g] = gload4(Bp + ((size_t)(nt * NRS + g) * 64 + lane) * 4);
+    const float* base = T1 + rm * F_LD1 + coloff + (lane >> 5) * 4;
+#pragma unroll
+    for (int g = 0; g < NRS; ++g) {
+        const int tap = g / 4 - NTAPS / 2;
+        const float4 a = *reinterpret_cast<const float4*>(base + tap * F_LD1 + (g % 4) * 8);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b[g].x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b[g].y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b[g].z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b[g].w, acc, 0, 0, 0);
+    }
+}
+
+template <int TM>
+__global__ __launch_bounds__(512) void inception_fused_kernel(const FusedArgs a)
+{
+    constexpr int TR32 = TM * 32;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Ad = smem;                         // [2][TR32*F_LDA] plain rows
+    float* Ap = smem + 2 * TR32 * F_LDA;      // [2][TR32*F_LDA] max-pooled rows
+    float* T2 = smem;                         // [TR32*F_LD2], aliases Ad/Ap once P1 is done
+    float* T1 = smem + 4 * TR32 * F_LDA;      // [spt*(W+4)][F_LD1]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int W = a.W, spt = a.spt, cin = a.cin;
+    int* rowmap = reinterpret_cast<int*>(T1 + spt * (W + 4) * F_LD1);   // [TR32] tile row -> T1 row
+    const int site0 = blockIdx.x * spt;
+    const int nhere = min(spt, a.n_sites - site0);
+    const int TRv = nhere * W;                // valid rows of this tile
+    const size_t grow0 = (size_t)site0 * W;
+
+    for (int i = tid; i < spt * (W + 4) * F_LD1; i += 512) T1[i] = 0.0f;   // halos (and everything else) = 0
+    if (tid < TR32) {
+        const int r = tid < TRv ? tid : 0;
+        rowmap[tid] = (r / W) * (W + 4) + 2 + r % W;
+    }
+
+    // ---- P1 staging cursor: thread -> (row, 16-byte slot); rows past the tile end re-read row TRv-1
+    const bool stager = tid < TR32 * 4;
+    const int sr = tid >> 2, sq = tid & 3;
+    const int rr = sr < TRv ? sr : TRv - 1;
+    const int sw = rr % W;
+    const float* pc = a.X + (grow0 + rr) * cin + sq * 4;
+    const float* pm = sw > 0 ? pc - cin : pc;          // maxpool(3, s1, SAME): padded taps ignored
+    const float* pp = sw < W - 1 ? pc + cin : pc;
+    const float* bp = a.Bp1 + ((size_t)wave * (cin / 8) * 64 + lane) * 4;
+
+    floatx16 acc[TM];
+#pragma unroll
+    for (int mt = 0; mt < TM; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mt][r] = 0.0f;
+
+    float4 vc, vm, vp;
+    auto load_a = [&]() {
+        if (stager) {
+            vc = gload4(pc); vm = gload4(pm); vp = gload4(pp);
+            pc += KC; pm += KC; pp += KC;
+        }
+    };
+    auto store_a = [&](int buf) {
+        if (stager) {
+            *reinterpret_cast<float4*>(Ad + buf * TR32 * F_LDA + sr * F_LDA + sq * 4) = vc;
+            *reinterpret_cast<float4*>(Ap + buf * TR32 * F_LDA + sr * F_LDA + sq * 4) = f4max(f4max(vc, vm), vp);
+        }
+    };
+    auto load_b = [&](float4(&b)[2]) {
+        b[0] = gload4(bp);
+        b[1] = gload4(bp + 256);
+        bp += 512;
+    };
+    const float* asrc = wave < 6 ? Ad : Ap;    // n-tiles 6,7 are branch 1 (pooled input)
+    auto compute = [&](int buf, const float4(&b)[2]) {
+        float4 af[2][TM];
+#pragma unroll
+        for (int rs = 0; rs < 2; ++rs)
+#pragma unroll
+            for (int mt = 0; mt < TM; ++mt)
+                af[rs][mt] = *reinterpret_cast<const float4*>(asrc + buf * TR32 * F_LDA + (mt * 32 + (lane & 31)) * F_LDA +
+                                                              rs * 8 + (lane >> 5) * 4);
+#pragma unroll
+        for (int rs = 0; rs < 2; ++rs)
+#pragma unroll
+            for (int mt = 0; mt < TM; ++mt) {
+                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[rs][mt].x, b[rs].x, acc[mt], 0, 0, 0);
+                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[rs][mt].y, b[rs].y, acc[mt], 0, 0, 0);
+                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[rs][mt].z, b[rs].z, acc[mt], 0, 0, 0);
+                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[rs][mt].w, b[rs].w, acc[mt], 0, 0, 0);
+            }
+    };
+
+    const int nchunks = cin / KC;
+    float4 b0[2], b1[2];
+    load_a();
+    load_b(b0);
+    store_a(0);
+    __syncthreads();
+    int c = 0;
+    while (c + 2 < nchunks) {
+        load_a(); load_b(b1);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(0, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        store_a(1);
+        __syncthreads();
+        load_a(); load_b(b0);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(1, b1);
+        __builtin_amdgcn_sched_barrier(0);
+        store_a(0);
+        __syncthreads();
+        c += 2;
+    }
+    if (nchunks - c == 2) {
+        load_a(); load_b(b1);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(0, b0);
+        store_a(1);
+        __syncthreads();
+        compute(1, b1);
+    } else {
+        compute(0, b0);
+    }
+
+    // ---- P1 epilogue: route the 256 columns
+    const int rl = 4 * (lane >> 5);
+    {
+        const int col = wave * 32 + (lane & 31);
+        const float bias = col < 240 ? gload(a.bias1 + col) : 0.0f;
+        if (col >= 48 && col < 240) {
+#pragma unroll
+            for (int mt = 0; mt < TM; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = mt * 32 + rl + (r & 3) + 8 * (r >> 2);
+                    if (row < TRv) {
+                        const float v = fmaxf(acc[mt][r] + bias, 0.0f);
+                        if (col < 96) gstore(a.Y + (grow0 + row) * 240 + col, v);                 // branch 2 -> [48,96)
+                        else if (col < 192) T1[rowmap[row] * F_LD1 + (col - 96)] = v;             // b3a | b4a | b5a
+                        else gstore(a.Y + (grow0 + row) * 240 + (col - 192), v);                  // branch 1 -> [0,48)
+                    }
+                }
+        }
+    }
+    __syncthreads();   // T1 complete; Ad/Ap dead -> T2 may be written
+
+    const int rm_of = lane & 31;
+    auto store_unit_global = [&](const floatx16& u, int mt, int nt, const float* bias, int ybase) {
+        const int col = nt * 32 + (lane & 31);
+        if (col < 48) {
+            const float bv = gload(bias + col);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = mt * 32 + rl + (r & 3) + 8 * (r >> 2);
+                if (row < TRv) gstore(a.Y + (grow0 + row) * 240 + ybase + col, fmaxf(u[r] + bv, 0.0f));
+            }
+        }
+    };
+    auto unit_b5b = [&](int mt, int nt) {        // 1x3, 32 -> 64, ReLU, to T2             layers.py:127-131
+        floatx16 u;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) u[r] = 0.0f;
+        fused_conv_unit<3>(T1, rowmap[mt * 32 + rm_of], 64, nt, lane, a.Bp5b, u);
+        const int col = nt * 32 + (lane & 31);
+        const float bv = gload(a.bias5b + col);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = mt * 32 + rl + (r & 3) + 8 * (r >> 2);
+            T2[row * F_LD2 + col] = fmaxf(u[r] + bv, 0.0f);
+        }
+    };
+    auto unit_b3b = [&](int mt, int nt) {        // 1x3, 32 -> 48, ReLU, to Y[96,144)       layers.py:106-110
+        floatx16 u;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) u[r] = 0.0f;
+        fused_conv_unit<3>(T1, rowmap[mt * 32 + rm_of], 0, nt, lane, a.Bp3b, u);
+        store_unit_global(u, mt, nt, a.bias3b, 96);
+    };
+    auto unit_b4b = [&](int mt, int nt) {        // 1x5, 32 -> 48, ReLU, to Y[144,192)      layers.py:115-119
+        floatx16 u;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) u[r] = 0.0f;
+        fused_conv_unit<5>(T1, rowmap[mt * 32 + rm_of], 32, nt, lane, a.Bp4b, u);
+        store_unit_global(u, mt, nt, a.bias4b, 144);
+    };
+
+    // ---- P2a (static wave -> unit assignment; wave-uniform branches)
+    if (TM == 3) {
+        if (wave < 6) unit_b5b(wave % 3, wave / 3);
+        else { unit_b3b(0, wave - 6); unit_b3b(1, wave - 6); }
+    } else if (TM == 2) {
+        if (wave < 4) unit_b5b(wave & 1, wave >> 1);
+        else unit_b3b(wave & 1, (wave - 4) >> 1);
+    } else {
+        if (wave < 2) unit_b5b(0, wave);
+        else if (wave < 4) unit_b3b(0, wave - 2);
+        else if (wave < 6) unit_b4b(0, wave - 4);
+    }
+    __syncthreads();   // T2 complete
+
+    // ---- P2b
+    if (wave < 2) {
+        // branch 5 tail: 1x1 64 -> 48 (BN, no ReLU) accumulated on top of the stem conv held in acc,
+        // then relu(stem + tail)                                                         layers.py:132-138
+        float4 b[8];
+#pragma unroll
+        for (int g = 0; g < 8; ++g) b[g] = gload4(a.Bp5c + ((size_t)(wave * 8 + g) * 64 + lane) * 4);
+#pragma unroll
+        for (int mt = 0; mt < TM; ++mt) {
+            const float* base = T2 + (mt * 32 + (lane & 31)) * F_LD2 + (lane >> 5) * 4;
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+                const float4 av = *reinterpret_cast<const float4*>(base + g * 8);
+                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, b[g].x, acc[mt], 0, 0, 0);
+                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, b[g].y, acc[mt], 0, 0, 0);
+                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, b[g].z, acc[mt], 0, 0, 0);
+                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, b[g].w, acc[mt], 0, 0, 0);
+            }
+        }
+        const int col = wave * 32 + (lane & 31);
+        if (col < 48) {
+            const float bv = gload(a.bias1 + col) + gload(a.bias5c + col);
+#pragma unroll
+            for (int mt = 0; mt < TM; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = mt * 32 + rl + (r & 3) + 8 * (r >> 2);
+                    if (row < TRv) gstore(a.Y + (grow0 + row) * 240 + 192 + col, fmaxf(acc[mt][r] + bv, 0.0f));
+                }
+        }
+    } else if (TM == 3) {
+        unit_b4b((wave - 2) % 3, (wave - 2) / 3);
+        if (wave < 4) unit_b3b(2, wave - 2);
+    } else if (TM == 2) {
+        if (wave < 6) unit_b4b((wave - 2) & 1, (wave - 2) >> 1);
+    }
+}
+
+hipError_t launch_inception_fused(int tm, const FusedArgs& a, hipStream_t s)
+{
+    if (a.n_sites <= 0) return hipSuccess;
+    const size_t lds = inception_fused_lds_bytes(tm, a.W, a.spt);
+    const int grid = (a.n_sites + a.spt - 1) / a.spt;
+    static bool attr_set[4] = {false, false, false, false};
+    auto set_attr = [&](const void* f) {
+        if (attr_set[tm]) return hipSuccess;
+        attr_set[tm] = true;
+        return hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    };
+    hipError_t e = hipSuccess;
+    switch (tm) {
+    case 1:
+        if ((e = set_attr((const void*)inception_fused_kernel<1>)) != hipSuccess) return e;
+        hipLaunchKernelGGL(inception_fused_kernel<1>, dim3(grid), dim3(512), lds, s, a);
+        break;
+    case 2:
+        if ((e = set_attr((const void*)inception_fused_kernel<2>)) != hipSuccess) return e;
+        hipLaunchKernelGGL(inception_fused_kernel<2>, dim3(grid), dim3(512), lds, s, a);
+        break;
+    case 3:
+        if ((e = set_attr((const void*)inception_fused_kernel<3>)) != hipSuccess) return e;
+        hipLaunchKernelGGL(inception_fused_kernel<3>, dim3(grid), dim3(512), lds, s, a);
+        break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
 // stem conv1: conv(K=7, stride 2, Cin=1 -> 64, SAME) + folded BN + ReLU + maxpool(3, stride 2, SAME)
 // One block per site; the 360-sample window sits in LDS, lane = output channel.
 __global__ __launch_bounds__(256) void stem1_kernel(const float* __restrict__ signals, const float* __restrict__ w,
