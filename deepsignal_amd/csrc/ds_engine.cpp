@@ -65,8 +65,8 @@ struct Op {
 
 // per-kernel accumulators (one entry per __global__ function / template instantiation)
 enum KernelClass { K_GEMM_CONV = 0, K_GEMM_FC, K_GEMM_LSTM, K_GEMM_CONV_WIDE, K_GEMM_CONV_POOL, K_FUSED1, K_FUSED2, K_FUSED3, K_STEM1, K_MAXPOOL, K_AVGPOOL, K_HEAD, K_COUNT };
-const char* const kKernelNames[K_COUNT] = {"gemm_kernel<1,2,4,1,0,0>", "gemm_kernel<1,3,4,1,0,0>", "gemm_kernel<1,4,4,1,1,0>",
-                                           "gemm_kernel<2,2,2,2,0,0>", "gemm_kernel<1,2,4,1,0,1>", "inception_fused_kernel<1>",
+const char* const kKernelNames[K_COUNT] = {"gemm_kernel<1,2,4,1,0,0,1,1>", "gemm_kernel<1,3,4,1,0,0,2,1>", "gemm_kernel<1,4,4,1,1,0,1,1>",
+                                           "gemm_kernel<2,2,2,2,0,0,1,1>", "gemm_kernel<1,2,4,1,0,1,1,1>", "inception_fused_kernel<1>",
                                            "inception_fused_kernel<2>", "inception_fused_kernel<3>", "stem1_kernel",
                                            "maxpool_s2_kernel", "avgpool7_kernel", "head_kernel"};
 struct KernelStat {
@@ -134,6 +134,7 @@ struct ds_handle {
     float *fc1o = nullptr, *logits = nullptr, *act = nullptr;
     int* pred = nullptr;
 
+    const float* zero_seg = nullptr;
     std::vector<Stage> stages;
     KernelStat kstat[K_COUNT];
     std::map<int, Plan> plans;
@@ -177,9 +178,12 @@ int upload(ds_handle* h, float** dst, const std::vector<float>& v)
 
 // Pack a logical [K][N] matrix into MFMA-fragment order: [ntile][kgroup][lane][4] where
 // lane (j = lane&31, half = lane>>5) element s holds W[kgroup*8 + 4*half + s][ntile*32 + j].
-std::vector<float> pack_b(int K, int N, const std::function<float(int, int)>& w)
+std::vector<float> pack_b(int K, int N, const std::function<float(int, int)>& w_in)
 {
-    const int ntiles = (N + 31) / 32, kg = K / 8;
+    // K is padded to a multiple of 32 with zero rows so K-split kernels may run one extra (zero) chunk
+    const int Kp = (K + 31) / 32 * 32;
+    auto w = [&](int k, int col) { return k < K ? w_in(k, col) : 0.0f; };
+    const int ntiles = (N + 31) / 32, kg = Kp / 8;
     std::vector<float> out((size_t)ntiles * kg * 256, 0.0f);
     for (int nt = 0; nt < ntiles; ++nt)
         for (int g = 0; g < kg; ++g)
@@ -380,9 +384,18 @@ int alloc_workspace(ds_handle* h)
 
 int module_width(const ds_handle* h, int m) { return m < 3 ? h->wa : (m < 8 ? h->wb : h->wc); }
 
+const float* g_zero_seg = nullptr;   // 16 zero floats on the device (per process; set by ds_create)
+
 void add_tiles(GemmLaunch& L, GemmProblem& P, GemmCfg cfg)
 {
     const TileGeom g = gemm_geom(cfg);
+    // K-split kernels need a chunk count divisible by the split: append a zero A segment (ld = 0, so
+    // every row reads the same 16 zeros); the packed weights are zero-padded past K as well.
+    while ((P.K / KC) % g.ksplit != 0) {
+        ASeg& z = P.seg[P.nseg++];
+        z.base = g_zero_seg; z.ld = 0; z.row_shift = 0; z.klen = KC;
+        P.K += KC;
+    }
     P.tiles_m = (P.M + g.bm - 1) / g.bm;
     P.tiles_n = (P.N + g.bn - 1) / g.bn;
     P.ntiles32 = (P.N + 31) / 32;
@@ -397,7 +410,7 @@ GemmProblem base_problem(int M, int N, int W, const PackedGemm& pg)
     memset(&P, 0, sizeof P);
     P.M = M; P.N = N; P.W = W;
     P.Bp = pg.Bp; P.bias = pg.bias;
-    P.kgroups_stride = pg.K / 8;
+    P.kgroups_stride = (pg.K + 31) / 32 * 32 / 8;
     return P;
 }
 
@@ -427,6 +440,7 @@ int stage_id(ds_handle* h, const std::string& name, int stream)
 int build_plan(ds_handle* h, int n, Plan* plan)
 {
     plan->n = n;
+    g_zero_seg = h->zero_seg;
     std::vector<Op> cnn, rnn;
     auto& LS = plan->launches;
     const bool first_plan = h->plans.empty();
@@ -810,6 +824,12 @@ int ds_create(const ds_config* cfg, ds_handle** out)
     CK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
 #undef CK
     int rc = alloc_workspace(h);
+    if (!rc) {
+        float* z = nullptr;
+        rc = dalloc(h, &z, 64);
+        if (!rc && hipMemset(z, 0, 256) != hipSuccess) rc = fail(h, DS_ERR_HIP, "hipMemset");
+        h->zero_seg = z;
+    }
     if (rc) { g_create_error = h->err; ds_destroy(h); return rc; }
     *out = h;
     return DS_OK;

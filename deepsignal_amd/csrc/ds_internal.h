@@ -7,7 +7,7 @@
 namespace ds {
 
 constexpr int KC = 16;          // K elements staged per LDS chunk (two 8-wide MFMA read steps)
-constexpr int MAX_SEG = 5;      // A-operand segments (conv taps / concatenated inputs)
+constexpr int MAX_SEG = 6;      // A-operand segments (conv taps / concatenated inputs)
 constexpr int MAX_OUT = 6;      // output column segments of one GEMM
 constexpr int MAX_PROB = 8;     // problems per grouped launch
 
@@ -74,7 +74,7 @@ struct GemmLaunch {
 enum GemmCfg { CFG_CONV = 0, CFG_FC = 1, CFG_LSTM = 2, CFG_CONV_WIDE = 3, CFG_CONV_POOL = 4 };
 
 // tile geometry per config (host needs it for grid sizing)
-struct TileGeom { int bm, bn, threads; };
+struct TileGeom { int bm, bn, threads, ksplit; };
 TileGeom gemm_geom(GemmCfg cfg);
 
 hipError_t launch_gemm(GemmCfg cfg, const GemmLaunch* d_launch, int total_tiles, hipStream_t s);

@@ -25,6 +25,10 @@ __device__ __forceinline__ float4 f4max(float4 a, float4 b)
     return make_float4(fmaxf(a.x, b.x), fmaxf(a.y, b.y), fmaxf(a.z, b.z), fmaxf(a.w, b.w));
 }
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+// LSTM gate non-linearities on the hardware exp (v_exp_f32, ~1 ulp): abs error < 2e-7, far inside the
+// 2e-5 parity budget, at a fraction of the ocml expf/tanhf instruction count.
+__device__ __forceinline__ float fast_sigmoid(float x) { return __fdividef(1.0f, 1.0f + __expf(-x)); }
+__device__ __forceinline__ float fast_tanh(float x) { return 2.0f * fast_sigmoid(2.0f * x) - 1.0f; }
 
 // Pointers reach the kernels through descriptor structs, so the compiler only knows them as
 // generic; these casts make every access a global_* instruction (flat_* would tie vmcnt and
@@ -41,16 +45,27 @@ __device__ __forceinline__ float4 gload4(const float* p)
 __device__ __forceinline__ float gload(const float* p) { return *(gptr1)(p); }
 __device__ __forceinline__ void gstore(float* p, float v) { *(gptr1w)(p) = v; }
 
-template <int MT, int NT, int WM, int WN, int EPI, int AMODE>
-__global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmLaunch* __restrict__ L)
+// KS = in-workgroup K split: KS wave groups ("K-lanes") own the same output tile and take alternate
+// 16-wide K chunks (lane g: chunks g, g+KS, ...), each with its own LDS staging area, and the partial
+// accumulators are exchanged through LDS at the end. It doubles the waves per SIMD for grids that
+// only have ~one workgroup per CU and halves the serial chunk chain of short-K problems.
+template <int MT, int NT, int WM, int WN, int EPI, int AMODE, int BD, int KS>
+__global__ __launch_bounds__(64 * WM * WN * KS) void gemm_kernel(const GemmLaunch* __restrict__ L)
 {
     constexpr int BM = WM * MT * 32;
     constexpr int LDA = KC + 4;
-    constexpr int NTHR = 64 * WM * WN;
+    constexpr int NTHR = 64 * WM * WN;          // threads per K-lane
     constexpr int SLOTS = (BM * 4 + NTHR - 1) / NTHR;
-    __shared__ __attribute__((aligned(16))) float As[2][BM * LDA];
+    constexpr int AS_FLOATS = 2 * KS * BM * LDA;
+    constexpr int RED_FLOATS = KS > 1 ? WM * WN * MT * NT * 16 * 64 : 0;
+    __shared__ __attribute__((aligned(16))) float smem_[AS_FLOATS > RED_FLOATS ? AS_FLOATS : RED_FLOATS];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lane = threadIdx.x & 63, wave_all = threadIdx.x >> 6;
+    const int kl = wave_all / (WM * WN);        // K-lane of this wave
+    const int wave = wave_all % (WM * WN);
+    const int tid = threadIdx.x - kl * NTHR;    // thread index inside the K-lane
+    float* const As0 = smem_ + (0 * KS + kl) * BM * LDA;
+    float* const As1 = smem_ + (1 * KS + kl) * BM * LDA;
     const int wm = wave % WM, wn = wave / WM;
     const int bid = blockIdx.x;
     int pi = 0;
@@ -61,7 +76,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmLaunch* __
     const int tm = local % P.tiles_m, tn = local / P.tiles_m;
     const int m0 = tm * BM;
     const int M = P.M, W = P.W;
-    const int nchunks = P.K / KC;
+    const int nchunks = P.K / KC / KS;          // chunks per K-lane (planner pads K to a multiple of KC*KS)
     const int nseg = P.nseg;
 
     // per-slot row bookkeeping (a slot = one float4 of the staged A chunk)
@@ -83,7 +98,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmLaunch* __
         ntile[nt] = (tn * WN + wn) * NT + nt;
         nvalid[nt] = ntile[nt] < P.ntiles32;
         const int tcl = nvalid[nt] ? ntile[nt] : P.ntiles32 - 1;   // clamp: loads stay in bounds, result unused
-        bp[nt] = P.Bp + (size_t)tcl * P.kgroups_stride * 256 + lane * 4;
+        bp[nt] = P.Bp + ((size_t)tcl * P.kgroups_stride + kl * 2) * 256 + lane * 4;
     }
 
     floatx16 acc[MT][NT];
@@ -119,107 +134,219 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmLaunch* __
             }
         }
     };
-    // raw loads only; the SAME-padding select (and the 3-tap max of AMODE 1) is applied when the
-    // chunk is written to LDS one compute phase later, so no load is waited for early
-    float4 areg[SLOTS], aregm[SLOTS], aregp[SLOTS];
-    bool lok[SLOTS];
-    auto load_a = [&]() {
+    auto advance = [&]() {
+        if (--seg_left == 0 && ++seg_i < nseg) seg_begin(seg_i);
+    };
+    auto skip_chunk = [&]() {     // step the cursor over a chunk that belongs to another K-lane
 #pragma unroll
         for (int i = 0; i < SLOTS; ++i) {
-            areg[i] = gload4(ap[i]);
+            ap[i] += KC;
+            if (AMODE == 1) { apm[i] += KC; app[i] += KC; }
+        }
+        advance();
+    };
+    // Software pipeline (per chunk c, parity X = c&1; chunk k lives in R[k&1] / b[k&1] / As[k&1] / a[k&1]):
+    //   (1) issue global loads: A rows of chunk c+2 -> R[X], weights of chunk c+BD -> b[(c+BD) % (BD+1)]
+    //       (BD = weight prefetch distance in chunks: 1 for L2-resident weights, 2 when they stream from HBM)
+    //   (2) write chunk c+1 (loaded one step ago) to LDS As[X^1] (SAME-padding select / 3-tap max applied here)
+    //   (3) MFMAs of read-step 0 of chunk c
+    //   (4) barrier                       -- everyone's (2) is done
+    //   (5) ds_read chunk c+1 fragments -> a[X^1]   (latency hidden by (6))
+    //   (6) MFMAs of read-step 1 of chunk c
+    // One barrier per chunk, no load / LDS latency on the MFMA critical path.
+    float4 R[2][SLOTS], Rm[2][SLOTS], Rp[2][SLOTS];
+    bool lok[2][SLOTS];
+    float4 bq[2 * BD][NT][2];   // weight ring: 2 buffers (BD=1) or 4 (BD=2), statically indexed
+    float4 af[2][2][MT];
+    auto load_a = [&](int X) {
+#pragma unroll
+        for (int i = 0; i < SLOTS; ++i) {
+            R[X][i] = gload4(ap[i]);
             ap[i] += KC;
             if (AMODE == 1) {
-                aregm[i] = gload4(apm[i]);
-                aregp[i] = gload4(app[i]);
+                Rm[X][i] = gload4(apm[i]);
+                Rp[X][i] = gload4(app[i]);
                 apm[i] += KC;
                 app[i] += KC;
             }
-            lok[i] = aok[i];
+            lok[X][i] = aok[i];
         }
-        if (--seg_left == 0 && ++seg_i < nseg) seg_begin(seg_i);
+        advance();
+#pragma unroll
+        for (int j = 1; j < KS; ++j) skip_chunk();
     };
-    auto store_a = [&](float* dst) {
+    auto store_a = [&](int X) {
+        float* dst = X ? As1 : As0;
 #pragma unroll
         for (int i = 0; i < SLOTS; ++i) {
             const int idx = tid + i * NTHR;
-            float4 v = areg[i];
-            if (AMODE == 1) v = f4max(f4max(v, aregm[i]), aregp[i]);   // maxpool(3, s1, SAME): padded taps ignored
-            v.x = lok[i] ? v.x : 0.0f;
-            v.y = lok[i] ? v.y : 0.0f;
-            v.z = lok[i] ? v.z : 0.0f;
-            v.w = lok[i] ? v.w : 0.0f;
+            float4 v = R[X][i];
+            if (AMODE == 1) v = f4max(f4max(v, Rm[X][i]), Rp[X][i]);   // maxpool(3, s1, SAME): padded taps ignored
+            v.x = lok[X][i] ? v.x : 0.0f;
+            v.y = lok[X][i] ? v.y : 0.0f;
+            v.z = lok[X][i] ? v.z : 0.0f;
+            v.w = lok[X][i] ? v.w : 0.0f;
             if (SLOTS * NTHR == BM * 4 || idx < BM * 4)
                 *reinterpret_cast<float4*>(dst + (idx >> 2) * LDA + (idx & 3) * 4) = v;
         }
     };
-    auto load_b = [&](float4(&b)[NT][2]) {
+    auto load_b = [&](int X) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-            b[nt][0] = gload4(bp[nt]);
-            b[nt][1] = gload4(bp[nt] + 256);
-            bp[nt] += 512;
+            bq[X][nt][0] = gload4(bp[nt]);
+            bq[X][nt][1] = gload4(bp[nt] + 256);
+            bp[nt] += 512 * KS;
         }
     };
-    auto compute = [&](const float* src, const float4(&b)[NT][2]) {
-        float4 a[2][MT];
+    auto read_frags = [&](int X) {
 #pragma unroll
         for (int rs = 0; rs < 2; ++rs)
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
-                a[rs][mt] = *reinterpret_cast<const float4*>(
-                    src + ((wm * MT + mt) * 32 + (lane & 31)) * LDA + rs * 8 + (lane >> 5) * 4);
-#pragma unroll
-        for (int rs = 0; rs < 2; ++rs)
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[rs][mt].x, b[nt][rs].x, acc[mt][nt], 0, 0, 0);
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[rs][mt].y, b[nt][rs].y, acc[mt][nt], 0, 0, 0);
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[rs][mt].z, b[nt][rs].z, acc[mt][nt], 0, 0, 0);
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[rs][mt].w, b[nt][rs].w, acc[mt][nt], 0, 0, 0);
-                }
+                af[X][rs][mt] = *reinterpret_cast<const float4*>(
+                    (X ? As1 : As0) + ((wm * MT + mt) * 32 + (lane & 31)) * LDA + rs * 8 + (lane >> 5) * 4);
     };
+    // X / JC / JN are literals at every call site, so all register arrays are statically indexed
+    auto mfma_rs2 = [&](int X, int J, int rs) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[X][rs][mt].x, bq[J][nt][rs].x, acc[mt][nt], 0, 0, 0);
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[X][rs][mt].y, bq[J][nt][rs].y, acc[mt][nt], 0, 0, 0);
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[X][rs][mt].z, bq[J][nt][rs].z, acc[mt][nt], 0, 0, 0);
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[X][rs][mt].w, bq[J][nt][rs].w, acc[mt][nt], 0, 0, 0);
+            }
+    };
+    // Instruction interleave inside a step (sched_group_barrier, cdna_hip_programming.md T19): with one
+    // wave per SIMD a burst of loads / LDS ops in front of the MFMA block leaves the matrix pipe idle
+    // while they issue, so each non-MFMA instruction is slotted behind one MFMA instead.
+    //   masks: VALU 0x2, MFMA 0x8, VMEM read 0x20, DS read 0x100, DS write 0x200
+    constexpr int N_MFMA_HALF = MT * NT * 4;
+    constexpr int N_ALOADS = SLOTS * (AMODE == 1 ? 3 : 1);
+    constexpr int N_BLOADS = 2 * NT;
+    constexpr int N_VALU_PER_STORE = (AMODE == 1 ? 12 : 4);
+#define DS_STEP(X, JC, JN, HAS1, HAS2, HASB)                                              \
+    do {                                                                                  \
+        if (HAS2) load_a(X);                                                              \
+        if (HASB) load_b(JN);                                                             \
+        if (HAS1) store_a((X) ^ 1);                                                       \
+        mfma_rs2(X, JC, 0);                                                               \
+        if (HAS1) {                                                                       \
+            _Pragma("unroll") for (int i_ = 0; i_ < SLOTS; ++i_) {                        \
+                __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);                          \
+                __builtin_amdgcn_sched_group_barrier(0x2, N_VALU_PER_STORE, 0);           \
+                __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);                        \
+            }                                                                             \
+        }                                                                                 \
+        if (HAS2) {                                                                       \
+            _Pragma("unroll") for (int i_ = 0; i_ < N_ALOADS; ++i_) {                     \
+                __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);                          \
+                __builtin_amdgcn_sched_group_barrier(0x20, 1, 0);                         \
+            }                                                                             \
+        }                                                                                 \
+        if (HASB) {                                                                       \
+            _Pragma("unroll") for (int i_ = 0; i_ < N_BLOADS; ++i_) {                     \
+                __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);                          \
+                __builtin_amdgcn_sched_group_barrier(0x20, 1, 0);                         \
+            }                                                                             \
+        }                                                                                 \
+        __builtin_amdgcn_sched_group_barrier(0x8, N_MFMA_HALF, 0);                        \
+        __builtin_amdgcn_sched_barrier(0);                                                \
+        __syncthreads();                                                                  \
+        if (HAS1) read_frags((X) ^ 1);                                                    \
+        mfma_rs2(X, JC, 1);                                                               \
+        __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);                                  \
+        if (HAS1) __builtin_amdgcn_sched_group_barrier(0x100, 2 * MT, 0);                 \
+        __builtin_amdgcn_sched_group_barrier(0x8, N_MFMA_HALF, 0);                        \
+        __builtin_amdgcn_sched_barrier(0);                                                \
+    } while (0)
 
-    float4 b0[NT][2], b1[NT][2];
     if (nchunks > 0) {
         seg_begin(0);
-        load_a();
-        load_b(b0);
-        store_a(As[0]);
-    }
-    __syncthreads();
-    int c = 0;
-    // steady state: two chunks per trip, no conditionals inside (chunk c in As[0]/b0 on entry)
-    // sched_barrier(0) pins the prefetch loads ABOVE the MFMA block: left alone, hipcc sinks them
-    // below it to shorten live ranges and their latency is then exposed every chunk.
-    while (c + 2 < nchunks) {
-        load_a(); load_b(b1);
-        __builtin_amdgcn_sched_barrier(0);
-        compute(As[0], b0);
-        __builtin_amdgcn_sched_barrier(0);
-        store_a(As[1]);
+#pragma unroll
+        for (int j = 0; j < KS - 1; ++j)
+            if (j < kl) skip_chunk();
+        load_a(0);
+        load_b(0);
+        store_a(0);
+        if (nchunks > 1) load_a(1);
+        if (BD == 2 && nchunks > 1) load_b(1);
         __syncthreads();
-        load_a(); load_b(b0);
-        __builtin_amdgcn_sched_barrier(0);
-        compute(As[1], b1);
-        __builtin_amdgcn_sched_barrier(0);
-        store_a(As[0]);
-        __syncthreads();
-        c += 2;
+        read_frags(0);
+        int c = 0;
+        if (BD == 1) {
+            while (c + 3 < nchunks) {      // steady state: every look-ahead exists, no conditionals
+                DS_STEP(0, 0, 1, true, true, true);
+                DS_STEP(1, 1, 0, true, true, true);
+                c += 2;
+            }
+            const int left = nchunks - c;  // 1..3
+            if (left == 3) {
+                DS_STEP(0, 0, 1, true, true, true);
+                DS_STEP(1, 1, 0, true, false, true);
+                DS_STEP(0, 0, 1, false, false, false);
+            } else if (left == 2) {
+                DS_STEP(0, 0, 1, true, false, true);
+                DS_STEP(1, 1, 0, false, false, false);
+            } else {
+                DS_STEP(0, 0, 1, false, false, false);
+            }
+        } else {
+            while (c + 5 < nchunks) {
+                DS_STEP(0, 0, 2, true, true, true);
+                DS_STEP(1, 1, 3, true, true, true);
+                DS_STEP(0, 2, 0, true, true, true);
+                DS_STEP(1, 3, 1, true, true, true);
+                c += 4;
+            }
+            // tail: 1..5 chunks, runtime (wave-uniform) look-ahead flags
+            DS_STEP(0, 0, 2, c + 1 < nchunks, c + 2 < nchunks, c + 2 < nchunks);
+            if (++c < nchunks) {
+                DS_STEP(1, 1, 3, c + 1 < nchunks, c + 2 < nchunks, c + 2 < nchunks);
+                if (++c < nchunks) {
+                    DS_STEP(0, 2, 0, c + 1 < nchunks, c + 2 < nchunks, c + 2 < nchunks);
+                    if (++c < nchunks) {
+                        DS_STEP(1, 3, 1, c + 1 < nchunks, c + 2 < nchunks, c + 2 < nchunks);
+                        if (++c < nchunks) DS_STEP(0, 0, 2, false, false, false);
+                    }
+                }
+            }
+        }
     }
-    if (nchunks - c == 2) {
-        load_a(); load_b(b1);
-        __builtin_amdgcn_sched_barrier(0);
-        compute(As[0], b0);
-        store_a(As[1]);
-        __syncthreads();
-        compute(As[1], b1);
-    } else if (nchunks - c == 1) {
-        compute(As[0], b0);
-    }
+#undef DS_STEP
 
-    // ---------------- epilogue ----------------
+    // ---------------- K-lane exchange: each lane ends up owning half of the accumulator rows ----------------
+    constexpr int R0 = 0;
+    int r_lo = 0, r_hi = 16;
+    if (KS == 2) {
+        __syncthreads();                       // staging buffers are dead; reuse them for the exchange
+        float* red = smem_ + (size_t)wave * MT * NT * 16 * 64;
+        const int give_lo = kl == 0 ? 8 : 0;   // registers this lane hands to the other lane
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    const float v = kl == 0 ? acc[mt][nt][8 + r] : acc[mt][nt][r];
+                    red[((mt * NT + nt) * 16 + give_lo + r) * 64 + lane] = v;
+                }
+        __syncthreads();
+        const int take_lo = kl == 0 ? 0 : 8;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    const float v = red[((mt * NT + nt) * 16 + take_lo + r) * 64 + lane];
+                    if (kl == 0) acc[mt][nt][r] += v; else acc[mt][nt][8 + r] += v;
+                }
+        r_lo = take_lo; r_hi = take_lo + 8;
+    }
+    (void)R0;
+    // ---------------- epilogue (rows r_lo..r_hi-1 of every 16-register accumulator) ----------------
     const int rbase = m0 + wm * MT * 32 + 4 * (lane >> 5);
     if (EPI == 0) {
 #pragma unroll
@@ -237,7 +364,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmLaunch* __
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = rbase + mt * 32 + (r & 3) + 8 * (r >> 2);
-                    if (row < M) {
+                    if (row < M && r >= r_lo && r < r_hi) {
                         float v = acc[mt][nt][r] + bias;
                         if (os.add) v += gload(os.add + (size_t)row * os.add_ld + cc);
                         if (os.relu) v = fmaxf(v, 0.0f);
@@ -267,7 +394,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmLaunch* __
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = rbase + mt * 32 + (r & 3) + 8 * (r >> 2);
-                    if (row < M) {
+                    if (row < M && r >= r_lo && r < r_hi) {
                         float zi = acc[mt][0 % NT][r] + bi, zj = acc[mt][1 % NT][r] + bj;
                         float zf = acc[mt][2 % NT][r] + bf, zo = acc[mt][3 % NT][r] + bo;
                         if (E.table) {
@@ -281,9 +408,9 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmLaunch* __
                         }
                         const size_t ix = (size_t)row * 256 + u;
                         const float cp = E.c_zero ? 0.0f : E.c[ix];
-                        const float cn = sigmoidf_(zf + 1.0f) * cp + sigmoidf_(zi) * tanhf(zj);
+                        const float cn = fast_sigmoid(zf + 1.0f) * cp + fast_sigmoid(zi) * fast_tanh(zj);
                         E.c[ix] = cn;
-                        E.h_out[ix] = sigmoidf_(zo) * tanhf(cn);
+                        E.h_out[ix] = fast_sigmoid(zo) * fast_tanh(cn);
                     }
                 }
         }
@@ -293,24 +420,24 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmLaunch* __
 TileGeom gemm_geom(GemmCfg cfg)
 {
     switch (cfg) {
-    case CFG_CONV: return {128, 64, 256};        // MT1 NT2 WM4 WN1
-    case CFG_FC: return {128, 96, 256};          // MT1 NT3 WM4 WN1
-    case CFG_LSTM: return {128, 128, 256};       // MT1 NT4 WM4 WN1 (one 32-unit gate group per block)
-    case CFG_CONV_WIDE: return {128, 128, 256};  // MT2 NT2 WM2 WN2
-    case CFG_CONV_POOL: return {128, 64, 256};   // CFG_CONV with maxpool(3,s1) fused into the A load
+    case CFG_CONV: return {128, 64, 256, 1};        // MT1 NT2 WM4 WN1
+    case CFG_FC: return {128, 96, 256, 1};          // MT1 NT3 WM4 WN1, weights prefetched 2 chunks ahead
+    case CFG_LSTM: return {128, 128, 256, 1};       // MT1 NT4 WM4 WN1 (one 32-unit gate group per block)
+    case CFG_CONV_WIDE: return {128, 128, 256, 1};  // MT2 NT2 WM2 WN2
+    case CFG_CONV_POOL: return {128, 64, 256, 1};   // CFG_CONV with maxpool(3,s1) fused into the A load
     }
-    return {0, 0, 0};
+    return {0, 0, 0, 1};
 }
 
 hipError_t launch_gemm(GemmCfg cfg, const GemmLaunch* d_launch, int total_tiles, hipStream_t s)
 {
     if (total_tiles <= 0) return hipSuccess;
     switch (cfg) {
-    case CFG_CONV: hipLaunchKernelGGL((gemm_kernel<1, 2, 4, 1, 0, 0>), dim3(total_tiles), dim3(256), 0, s, d_launch); break;
-    case CFG_FC: hipLaunchKernelGGL((gemm_kernel<1, 3, 4, 1, 0, 0>), dim3(total_tiles), dim3(256), 0, s, d_launch); break;
-    case CFG_LSTM: hipLaunchKernelGGL((gemm_kernel<1, 4, 4, 1, 1, 0>), dim3(total_tiles), dim3(256), 0, s, d_launch); break;
-    case CFG_CONV_WIDE: hipLaunchKernelGGL((gemm_kernel<2, 2, 2, 2, 0, 0>), dim3(total_tiles), dim3(256), 0, s, d_launch); break;
-    case CFG_CONV_POOL: hipLaunchKernelGGL((gemm_kernel<1, 2, 4, 1, 0, 1>), dim3(total_tiles), dim3(256), 0, s, d_launch); break;
+    case CFG_CONV: hipLaunchKernelGGL((gemm_kernel<1, 2, 4, 1, 0, 0, 1, 1>), dim3(total_tiles), dim3(256), 0, s, d_launch); break;
+    case CFG_FC: hipLaunchKernelGGL((gemm_kernel<1, 3, 4, 1, 0, 0, 2, 1>), dim3(total_tiles), dim3(256), 0, s, d_launch); break;
+    case CFG_LSTM: hipLaunchKernelGGL((gemm_kernel<1, 4, 4, 1, 1, 0, 1, 1>), dim3(total_tiles), dim3(256), 0, s, d_launch); break;
+    case CFG_CONV_WIDE: hipLaunchKernelGGL((gemm_kernel<2, 2, 2, 2, 0, 0, 1, 1>), dim3(total_tiles), dim3(256), 0, s, d_launch); break;
+    case CFG_CONV_POOL: hipLaunchKernelGGL((gemm_kernel<1, 2, 4, 1, 0, 1, 1, 1>), dim3(total_tiles), dim3(256), 0, s, d_launch); break;
     }
     return hipGetLastError();
 }
@@ -386,7 +513,7 @@ __global__ __launch_bounds__(512) void inception_fused_kernel(const FusedArgs a)
     const float* pc = a.X + (grow0 + rr) * cin + sq * 4;
     const float* pm = sw > 0 ? pc - cin : pc;          // maxpool(3, s1, SAME): padded taps ignored
     const float* pp = sw < W - 1 ? pc + cin : pc;
-    const float* bp = a.Bp1 + ((size_t)wave * (cin / 8) * 64 + lane) * 4;
+    const float* bp = a.Bp1 + ((size_t)wave * ((cin + 31) / 32 * 4) * 64 + lane) * 4;   // K padded to 32 in the pack
 
     floatx16 acc[TM];
 #pragma unroll
