@@ -738,14 +738,20 @@ hipError_t launch_inception_fused(int tm, const FusedArgs& a, hipStream_t s)
 
 // ---------------------------------------------------------------------------------------------
 // stem conv1: conv(K=7, stride 2, Cin=1 -> 64, SAME) + folded BN + ReLU + maxpool(3, stride 2, SAME)
-// One block per site; the 360-sample window sits in LDS, lane = output channel.
+// One block per site; the window sits in LDS with a zero halo (SAME padding, no bounds checks in the
+// tap loop); lane = output channel, so the 64-float output rows are written as whole 256-B lines.
+constexpr int STEM_HALO = 8;
 __global__ __launch_bounds__(256) void stem1_kernel(const float* __restrict__ signals, const float* __restrict__ w,
                                                      const float* __restrict__ bias, float* __restrict__ out,
                                                      int signal_len, int w1, int pad_l_conv, int wa, int pad_l_pool)
 {
-    extern __shared__ __attribute__((aligned(16))) float sig[];
+    extern __shared__ __attribute__((aligned(16))) float sig[];   // [STEM_HALO + signal_len + STEM_HALO + 8]
     const int site = blockIdx.x;
-    for (int i = threadIdx.x; i < signal_len; i += blockDim.x) sig[i] = signals[(size_t)site * signal_len + i];
+    const int total = signal_len + 2 * STEM_HALO + 8;
+    for (int i = threadIdx.x; i < total; i += blockDim.x) {
+        const int k = i - STEM_HALO;
+        sig[i] = (k >= 0 && k < signal_len) ? signals[(size_t)site * signal_len + k] : 0.0f;
+    }
     __syncthreads();
     const int c = threadIdx.x & 63;
     float wk[7];
@@ -753,18 +759,20 @@ __global__ __launch_bounds__(256) void stem1_kernel(const float* __restrict__ si
     for (int t = 0; t < 7; ++t) wk[t] = w[t * 64 + c];
     const float b = bias[c];
     for (int p = threadIdx.x >> 6; p < wa; p += blockDim.x >> 6) {
+        // conv positions wc = 2p - pad_l_pool + {0,1,2}; each reads sig[2*wc - pad_l_conv + 0..6]
+        const int wc0 = 2 * p - pad_l_pool;
+        const float* s0 = sig + STEM_HALO + 2 * wc0 - pad_l_conv;
+        float v[11];
+#pragma unroll
+        for (int i = 0; i < 11; ++i) v[i] = s0[i];
         float best = -INFINITY;
 #pragma unroll
         for (int pt = 0; pt < 3; ++pt) {
-            const int wc = 2 * p + pt - pad_l_pool;
-            if (wc < 0 || wc >= w1) continue;
             float a = 0.0f;
 #pragma unroll
-            for (int t = 0; t < 7; ++t) {
-                const int si = 2 * wc + t - pad_l_conv;
-                if (si >= 0 && si < signal_len) a = fmaf(sig[si], wk[t], a);
-            }
-            best = fmaxf(best, a);
+            for (int t = 0; t < 7; ++t) a = fmaf(v[2 * pt + t], wk[t], a);
+            const int wc = wc0 + pt;
+            best = (wc >= 0 && wc < w1) ? fmaxf(best, a) : best;     // padded pool taps are ignored
         }
         out[((size_t)site * wa + p) * 64 + c] = fmaxf(best + b, 0.0f);
     }
@@ -774,7 +782,8 @@ hipError_t launch_stem1(const float* signals, const float* w7x64, const float* b
                         int signal_len, int w1, int pad_l_conv, int wa, int pad_l_pool, hipStream_t s)
 {
     if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(stem1_kernel, dim3(n), dim3(256), signal_len * sizeof(float), s, signals, w7x64, bias64, out,
+    const size_t lds = (signal_len + 2 * STEM_HALO + 8) * sizeof(float);
+    hipLaunchKernelGGL(stem1_kernel, dim3(n), dim3(256), lds, s, signals, w7x64, bias64, out,
                        signal_len, w1, pad_l_conv, wa, pad_l_pool);
     return hipGetLastError();
 }
@@ -838,37 +847,63 @@ hipError_t launch_avgpool7(const float* in, float* out, int n, int w, int ch, hi
     return hipGetLastError();
 }
 
-// fc2 + sigmoid + argmax: one wave per site.
+// fc2 + sigmoid + argmax: one 256-thread block per site, float4 sweeps of the fc1 row, block reduce.
 __global__ __launch_bounds__(256) void head_kernel(const float* __restrict__ fc1, const float* __restrict__ w2,
                                                     float* __restrict__ logits, float* __restrict__ act,
                                                     int* __restrict__ pred, int n, int J, int C)
 {
-    const int site = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    if (site >= n) return;
-    const float* x = fc1 + (size_t)site * J;
-    float best = 0.0f;
-    int bi = 0;
-    for (int c = 0; c < C; ++c) {
-        float a = 0.0f;
-        for (int k = lane; k < J; k += 64) a = fmaf(x[k], w2[(size_t)k * C + c], a);
+    __shared__ float part[4][16];
+    const int site = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float4* x4 = reinterpret_cast<const float4*>(fc1 + (size_t)site * J);
+    float accv[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) accv[c] = 0.0f;
+    const int J4 = J >> 2;
+    for (int k4 = tid; k4 < J4; k4 += 256) {
+        const float4 x = x4[k4];
+        const float* w = w2 + (size_t)k4 * 4 * C;
+        if (C == 2) {
+            const float4 wa = *reinterpret_cast<const float4*>(w);
+            const float4 wb = *reinterpret_cast<const float4*>(w + 4);
+            accv[0] = fmaf(x.x, wa.x, fmaf(x.y, wa.z, fmaf(x.z, wb.x, fmaf(x.w, wb.z, accv[0]))));
+            accv[1] = fmaf(x.x, wa.y, fmaf(x.y, wa.w, fmaf(x.z, wb.y, fmaf(x.w, wb.w, accv[1]))));
+        } else {
+#pragma unroll
+            for (int c = 0; c < 16; ++c)
+                if (c < C) accv[c] += x.x * w[c] + x.y * w[C + c] + x.z * w[2 * C + c] + x.w * w[3 * C + c];
+        }
+    }
+    for (int k = (J4 << 2) + tid; k < J; k += 256)      // J not a multiple of 4
+        for (int c = 0; c < C; ++c) accv[c] += fc1[(size_t)site * J + k] * w2[(size_t)k * C + c];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        if (c >= C) break;
+        float a = accv[c];
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) a += __shfl_xor(a, off);
-        const float sg = sigmoidf_(a);
-        if (lane == 0) {
+        if (lane == 0) part[wave][c] = a;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        float best = 0.0f;
+        int bi = 0;
+        for (int c = 0; c < C; ++c) {
+            const float a = (part[0][c] + part[1][c]) + (part[2][c] + part[3][c]);
+            const float sg = sigmoidf_(a);
             logits[(size_t)site * C + c] = a;
             act[(size_t)site * C + c] = sg;
+            if (c == 0 || sg > best) { best = sg; bi = c; }
         }
-        if (c == 0 || sg > best) { best = sg; bi = c; }
+        pred[site] = bi;
     }
-    if (lane == 0) pred[site] = bi;
 }
 
 hipError_t launch_head(const float* fc1, const float* w2, float* logits, float* act, int* pred, int n, int J,
                        int class_num, hipStream_t s)
 {
     if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(head_kernel, dim3((n + 3) / 4), dim3(256), 0, s, fc1, w2, logits, act, pred, n, J, class_num);
+    hipLaunchKernelGGL(head_kernel, dim3(n), dim3(256), 0, s, fc1, w2, logits, act, pred, n, J, class_num);
     return hipGetLastError();
 }
 
