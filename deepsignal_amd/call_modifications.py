@@ -1,0 +1,173 @@
+"""call modifications from extracted feature files with the MI355X engine.
+
+Host-side mirror of the reference's batch harness (deepsignal/call_modifications.py): the same
+function names, argument meaning, queue-item layout, "kill" sentinel and output row text — with
+`(tf_sess, model)` replaced by a `deepsignal_amd.engine.Engine` (anything with a
+`run(kmer, means, stds, sanums, signals) -> (activation_logits, prediction)` method).
+
+output format: chromosome, pos, strand, pos_in_strand, read_name, read_strand,
+prob_0, prob_1, called_label, seq          (reference call_modifications.py:4-5, README.md:170-180)
+"""
+from __future__ import absolute_import
+
+import os
+import sys
+import time
+from typing import Iterator, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from .utils.process_utils import base2code_dna, code2base_dna, str2bool
+
+# a queue item, exactly as the reference builds it (call_modifications.py:62-67):
+#   (sampleinfo, kmers, base_means, base_stds, base_signal_lens, cent_signals, labels)
+FeaturesBatch = Tuple[list, list, list, list, list, list, list]
+
+KILL = "kill"     # sentinel the reader appends and the writer stops on (call_modifications.py:90,291)
+
+
+def _parse_line(line: str):
+    words = line.strip().split("\t")
+    return (words[4], "\t".join(words[0:6]), [base2code_dna[x] for x in words[6]],
+            [float(x) for x in words[7].split(",")], [float(x) for x in words[8].split(",")],
+            [int(x) for x in words[9].split(",")], [float(x) for x in words[10].split(",")], int(words[11]))
+
+
+def iter_features_batches(features_file: str, f5_batch_num: int = 20) -> Iterator[FeaturesBatch]:
+    """Yield queue items: consecutive rows grouped by read id, one item every f5_batch_num reads.
+
+    Same grouping rule as the reference reader (call_modifications.py:35-91): rows of one read are
+    never split across items, so results of each read are written together."""
+    cur: List[list] = [[], [], [], [], [], [], []]
+    r_num = 0
+    readid_pre = None
+    with open(features_file, "r") as rf:
+        for line in rf:
+            if not line.strip():
+                continue
+            readid, info, kmer, means, stds, lens, sig, label = _parse_line(line)
+            if readid_pre is None:
+                readid_pre = readid
+            elif readid != readid_pre:
+                r_num += 1
+                readid_pre = readid
+                if r_num % f5_batch_num == 0:
+                    yield tuple(cur)
+                    cur = [[], [], [], [], [], [], []]
+            for lst, v in zip(cur, (info, kmer, means, stds, lens, sig, label)):
+                lst.append(v)
+    if len(cur[0]) > 0:
+        yield tuple(cur)
+
+
+def _read_features_file(features_file, features_batch_q, f5_batch_num=20):
+    """Queue-feeding form of the reader (reference signature, call_modifications.py:35)."""
+    print("read_features process {} starts".format(os.getpid()))
+    for item in iter_features_batches(features_file, f5_batch_num):
+        features_batch_q.put(item)
+    features_batch_q.put(KILL)
+    print("read_features process {} ending".format(os.getpid()))
+
+
+def _call_mods(features_batch: FeaturesBatch, engine, batch_size: int):
+    """One queue item -> output rows. Reference: call_modifications.py:149-194.
+
+    Slices the item into batch_size chunks (last one partial), runs the engine on each, normalises
+    the two sigmoid outputs in float32 (p_k / (p_0 + p_1)) and formats
+    sampleinfo \\t prob_0 \\t prob_1 \\t called_label \\t kmer."""
+    sampleinfo, kmers, base_means, base_stds, base_signal_lens, cent_signals, labels = features_batch
+    labels = np.reshape(labels, (len(labels)))
+    pred_str: List[str] = []
+    accuracys = []
+    batch_num = 0
+    for i in np.arange(0, len(sampleinfo), batch_size):
+        batch_s, batch_e = i, i + batch_size
+        b_sampleinfo = sampleinfo[batch_s:batch_e]
+        b_kmers = kmers[batch_s:batch_e]
+        b_labels = labels[batch_s:batch_e]
+        if len(b_sampleinfo) > 0:
+            activation_logits, prediction = engine.run(
+                b_kmers, base_means[batch_s:batch_e], base_stds[batch_s:batch_e],
+                base_signal_lens[batch_s:batch_e], cent_signals[batch_s:batch_e])
+            accuracys.append(float(np.mean(np.asarray(b_labels) == np.asarray(prediction))))
+            for idx in range(b_labels.shape[0]):
+                prob_0, prob_1 = activation_logits[idx][0], activation_logits[idx][1]
+                prob_0_norm = prob_0 / (prob_0 + prob_1)
+                prob_1_norm = prob_1 / (prob_0 + prob_1)
+                pred_str.append("\t".join([b_sampleinfo[idx], str(prob_0_norm), str(prob_1_norm),
+                                           str(prediction[idx]),
+                                           "".join([code2base_dna[x] for x in b_kmers[idx]])]))
+            batch_num += 1
+    accuracy = np.mean(accuracys) if accuracys else float("nan")
+    return pred_str, accuracy, batch_num
+
+
+def _call_mods_q(engine, features_batch_q, pred_str_q, batch_size):
+    """Consume queue items until the sentinel (reference _call_mods_q, call_modifications.py:197-236)."""
+    print("call_mods process {} starts".format(os.getpid()))
+    count = 0
+    while True:
+        features_batch = features_batch_q.get()
+        if isinstance(features_batch, str) and features_batch == KILL:
+            break
+        pred_str, _, batch_num = _call_mods(features_batch, engine, batch_size)
+        pred_str_q.put(pred_str)
+        count += batch_num
+    print("call_mods process {} ending, proceed {} batches".format(os.getpid(), count))
+
+
+def _write_predstr_to_file(write_fp, predstr_q):
+    """Writer (reference call_modifications.py:283-297): one flush per queue item."""
+    print("write process {} starts".format(os.getpid()))
+    with open(write_fp, "w") as wf:
+        while True:
+            pred_str = predstr_q.get()
+            if isinstance(pred_str, str) and pred_str == KILL:
+                break
+            for one_pred_str in pred_str:
+                wf.write(one_pred_str + "\n")
+            wf.flush()
+    print("write process {} ending".format(os.getpid()))
+
+
+def make_engine(model_path: str, kmer_len: int, cent_signals_len: int, class_num: int, batch_size: int,
+                is_cnn: bool = True, is_rnn: bool = True, is_base: bool = True, device: int = 0):
+    """Model(...) + Session + Saver.restore (reference call_modifications.py:203-212)."""
+    from .engine import Engine
+    eng = Engine(kmer_len=kmer_len, signal_len=cent_signals_len, class_num=class_num, device=device,
+                 max_batch=batch_size, is_cnn=is_cnn, is_rnn=is_rnn, is_base=is_base)
+    eng.load_weights_file(model_path)
+    return eng
+
+
+def call_mods(input_path, model_path, result_file, kmer_len, cent_signals_len,
+              batch_size, learning_rate, class_num, nproc, is_gpu, is_rnn, is_base, is_cnn,
+              f5_args, engine=None, f5_batch_num=None):
+    """Feature-file mode of the reference's call_mods (call_modifications.py:417-495).
+
+    learning_rate / nproc / is_gpu are accepted for signature compatibility: inference ignores the
+    learning rate and the engine always runs on the GPU. `f5_args` is the reference's
+    tuple (its first element is f5_batch_num); fast5 directories need the feature extractor, which is
+    a "next" row of the scope table."""
+    start = time.time()
+    if os.path.isdir(input_path):
+        raise NotImplementedError("fast5 directory input needs the feature extractor (scope row f2); "
+                                  "run `deepsignal extract` first and pass the feature file")
+    if f5_batch_num is None:
+        f5_batch_num = f5_args[0] if f5_args else 50
+    own = engine is None
+    if own:
+        engine = make_engine(model_path, kmer_len, cent_signals_len, class_num, batch_size,
+                             is_cnn=is_cnn, is_rnn=is_rnn, is_base=is_base)
+    nsites = 0
+    with open(result_file, "w") as wf:
+        for item in iter_features_batches(input_path, f5_batch_num):
+            pred_str, _, _ = _call_mods(item, engine, batch_size)
+            for row in pred_str:
+                wf.write(row + "\n")
+            wf.flush()
+            nsites += len(pred_str)
+    if own:
+        engine.close()
+    print("call_mods costs %.2f seconds.. (%d sites)" % (time.time() - start, nsites))
+    return nsites

@@ -1,0 +1,69 @@
+"""`deepsignal call_mods` command line — the reference's flag surface for this sub-command
+(reference deepsignal/deepsignal.py:236-326, defaults included), driving the MI355X engine."""
+from __future__ import absolute_import
+
+import argparse
+import sys
+
+from .utils.process_utils import display_args, str2bool
+
+
+def main_call_mods(args):
+    from .call_modifications import call_mods
+    display_args(args)
+    f5_args = (args.f5_batch_num, str2bool(args.recursively), args.corrected_group, args.basecall_subgroup,
+               str2bool(args.is_dna), args.normalize_method, args.motifs, args.mod_loc, 1, args.positions,
+               args.reference_path)
+    call_mods(args.input_path, args.model_path, args.result_file, args.kmer_len, args.cent_signals_len,
+              args.batch_size, args.learning_rate, args.class_num, args.nproc, str2bool(args.is_gpu),
+              str2bool(args.is_rnn), str2bool(args.is_base), str2bool(args.is_cnn), f5_args)
+
+
+def build_parser():
+    parser = argparse.ArgumentParser(prog="deepsignal", description="call_mods on MI355X (gfx950)")
+    sub = parser.add_subparsers(title="modules", dest="module")
+    p = sub.add_parser("call_mods", description="call modifications")
+    g = p.add_argument_group("INPUT")
+    g.add_argument("--input_path", "-i", required=True,
+                   help="a file of extracted features (fast5 dirs need `extract` first)")
+    g.add_argument("--f5_batch_num", type=int, default=50)
+    g = p.add_argument_group("CALL")
+    g.add_argument("--model_path", "-m", required=True, help="weight file (DSAMDW01)")
+    g.add_argument("--is_cnn", default="yes")
+    g.add_argument("--is_rnn", default="yes")
+    g.add_argument("--is_base", default="yes")
+    g.add_argument("--kmer_len", "-x", type=int, default=17)
+    g.add_argument("--cent_signals_len", "-y", type=int, default=360)
+    g.add_argument("--batch_size", "-b", type=int, default=512)
+    g.add_argument("--learning_rate", "-l", type=float, default=0.001)
+    g.add_argument("--class_num", "-c", type=int, default=2)
+    g = p.add_argument_group("OUTPUT")
+    g.add_argument("--result_file", "-o", required=True)
+    g = p.add_argument_group("EXTRACTION")
+    g.add_argument("--recursively", "-r", default="yes")
+    g.add_argument("--corrected_group", default="RawGenomeCorrected_000")
+    g.add_argument("--basecall_subgroup", default="BaseCalled_template")
+    g.add_argument("--is_dna", default="yes")
+    g.add_argument("--normalize_method", default="mad", choices=["mad", "zscore"])
+    g.add_argument("--motifs", default="CG")
+    g.add_argument("--mod_loc", type=int, default=0)
+    g.add_argument("--positions", default=None)
+    g.add_argument("--reference_path", default=None)
+    p.add_argument("--nproc", "-p", type=int, default=1)
+    p.add_argument("--is_gpu", default="no", choices=["yes", "no"])
+    p.set_defaults(func=main_call_mods)
+    return parser
+
+
+def main(argv=None):
+    parser = build_parser()
+    args = parser.parse_args(argv)
+    if not getattr(args, "func", None):
+        parser.print_help()
+        return 1
+    args.func(args)
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

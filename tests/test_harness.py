@@ -1,0 +1,113 @@
+"""CPU: the from-scratch call_mods harness against golden vectors captured from the REFERENCE's
+own harness (tests/golden/make_harness_golden.py ran deepsignal/call_modifications.py under
+stub-TensorFlow): TSV parsing, read grouping, batch slicing, feed contents, float32 probability
+normalisation and the exact output row text."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from deepsignal_amd import call_modifications as cm
+from deepsignal_amd.utils.process_utils import base2code_dna, code2base_dna, str2bool
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "harness_golden.json")
+
+
+@pytest.fixture(scope="module")
+def cases():
+    with open(GOLD) as f:
+        return json.load(f)["cases"]
+
+
+class ReplayEngine:
+    """Returns the activations the reference's fake session returned, and records the feeds."""
+
+    def __init__(self, calls):
+        self.calls = list(calls)
+        self.i = 0
+        self.seen = []
+
+    def run(self, kmer, means, stds, sanums, signals):
+        c = self.calls[self.i]
+        self.i += 1
+        assert len(kmer) == c["n"]
+        self.seen.append({"kmer_first": [int(x) for x in kmer[0]], "sanums_first": [float(x) for x in sanums[0]],
+                          "means_first": [float(x) for x in means[0]],
+                          "signals_first_head": [float(x) for x in signals[0][:5]]})
+        act = np.asarray(c["act"], dtype=np.float32)
+        return act, np.argmax(act, axis=1)
+
+
+class ListQueue(list):
+    def put(self, x):
+        self.append(x)
+
+
+@pytest.mark.parametrize("idx", [0, 1, 2])
+def test_reader_and_call_mods_match_reference(cases, idx, tmp_path):
+    case = cases[idx]
+    path = str(tmp_path / "features.tsv")
+    with open(path, "w") as f:
+        f.write("\n".join(case["tsv_rows"]) + "\n")
+    q = ListQueue()
+    cm._read_features_file(path, q, case["f5_batch_num"])
+    assert q[-1] == "kill"
+    items = q[:-1]
+    assert len(items) == len(case["queue_items"])
+    for it, ref in zip(items, case["queue_items"]):
+        assert len(it[0]) == ref["n"] and it[0] == ref["sampleinfo"] and it[1] == ref["kmers"]
+        assert [int(x) for x in it[6]] == ref["labels"] and [int(x) for x in it[4][0]] == ref["lens_first"]
+    eng = ReplayEngine(case["session_calls"])
+    for it, ref in zip(items, case["outputs"]):
+        pred_str, accuracy, batch_num = cm._call_mods(it, eng, case["batch_size"])
+        assert pred_str == ref["pred_str"]            # exact text, incl. str(np.float32) and tie -> label 0
+        assert batch_num == ref["batch_num"] and abs(accuracy - ref["accuracy"]) < 1e-12
+    assert eng.i == len(case["session_calls"])
+    for seen, ref in zip(eng.seen, case["session_calls"]):
+        for k in seen:
+            assert seen[k] == ref[k], k
+
+
+def test_call_mods_end_to_end_file(cases, tmp_path):
+    """Feature file -> result file through call_mods(), order and grouping preserved."""
+    case = cases[0]
+    path, out = str(tmp_path / "f.tsv"), str(tmp_path / "r.tsv")
+    with open(path, "w") as f:
+        f.write("\n".join(case["tsv_rows"]) + "\n")
+    eng = ReplayEngine(case["session_calls"])
+    n = cm.call_mods(path, "unused", out, 17, 360, case["batch_size"], 0.001, 2, 1, False, True, True, True,
+                     (case["f5_batch_num"],), engine=eng)
+    expect = [r for o in case["outputs"] for r in o["pred_str"]]
+    assert n == len(expect)
+    assert open(out).read().splitlines() == expect
+    with pytest.raises(NotImplementedError):
+        cm.call_mods(str(tmp_path), "unused", out, 17, 360, 4, 0.001, 2, 1, False, True, True, True, (2,), engine=eng)
+
+
+def test_writer_and_sentinel(tmp_path):
+    import queue
+    q = queue.Queue()
+    q.put(["a\t1", "b\t2"])
+    q.put(["c\t3"])
+    q.put("kill")
+    out = str(tmp_path / "w.tsv")
+    cm._write_predstr_to_file(out, q)
+    assert open(out).read() == "a\t1\nb\t2\nc\t3\n"
+
+
+def test_alphabet_and_flags():
+    assert base2code_dna == {"A": 0, "C": 1, "G": 2, "T": 3, "N": 4}
+    assert "".join(code2base_dna[i] for i in range(5)) == "ACGTN"
+    assert str2bool("yes") and str2bool("True") and str2bool("1") and not str2bool("no")
+
+
+def test_cli_flag_surface():
+    """Same flags / defaults as reference deepsignal.py:236-326."""
+    from deepsignal_amd.deepsignal import build_parser
+    a = build_parser().parse_args(["call_mods", "-i", "x", "-m", "w", "-o", "o"])
+    assert (a.f5_batch_num, a.kmer_len, a.cent_signals_len, a.batch_size, a.class_num) == (50, 17, 360, 512, 2)
+    assert (a.is_cnn, a.is_rnn, a.is_base, a.is_gpu, a.nproc) == ("yes", "yes", "yes", "no", 1)
+    assert (a.corrected_group, a.basecall_subgroup, a.normalize_method, a.motifs, a.mod_loc) == \
+        ("RawGenomeCorrected_000", "BaseCalled_template", "mad", "CG", 0)
+    assert a.learning_rate == 0.001 and a.positions is None and a.reference_path is None

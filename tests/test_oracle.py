@@ -1,0 +1,119 @@
+"""CPU (-m "not gpu"): the oracle against the committed golden vectors, the independent torch
+statement, and the properties the domain offers. Parity is UNPINNED by the reference (no TF1, no
+reference tests); these are the strongest pins available."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from deepsignal_amd import spec, synth, weights
+from oracle import oracle
+import torch_statement
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "forward_golden.npz")
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return dict(np.load(GOLD))
+
+
+@pytest.fixture(scope="module")
+def gold_weights(gold):
+    return weights.random_weights(seed=int(gold["weight_seed"]), lstm_bias_std=float(gold["lstm_bias_std"]))
+
+
+def _feats(gold):
+    return {k[3:]: gold[k] for k in gold if k.startswith("in_")}
+
+
+def test_spec_counts():
+    d = spec.net_dims()
+    assert (d.w_conv1, d.w_a, d.w_b, d.w_c) == (180, 90, 45, 23)
+    assert d.pad_conv1 == (2, 3) and d.pad_pool1 == (0, 1) and d.pad_pool2 == (0, 1) and d.pad_pool3 == (1, 1)
+    assert d.joint == 6032 and spec.param_count() == 40_426_464
+    assert len(spec.tensor_table()) == 580
+    # FLOP contract of SURVEY.md 8(d): recompute MACs from the spec
+    conv = 180 * 7 * 64 + 90 * 64 * 128 + 90 * 3 * 128 * 256
+    for n in range(1, 12):
+        w, cin = d.module_width(n), d.module_cin(n)
+        conv += w * (cin * 240 + 96 * 48 + 160 * 48 + 96 * 64 + 64 * 48)
+    assert 2 * conv == spec.FLOPS_CONV_PER_SITE
+    lstm = 2 * 17 * ((131 + 256) * 1024 + 2 * 512 * 1024)
+    assert 2 * lstm == spec.FLOPS_LSTM_PER_SITE
+    assert 2 * (6032 * 6032 + 6032 * 2) == spec.FLOPS_FC_PER_SITE
+
+
+def test_oracle_f64_matches_golden(gold, gold_weights):
+    act, pred, taps = oracle.forward(gold_weights, _feats(gold), "f64", taps=True)
+    assert np.array_equal(pred, gold["pred"])
+    assert np.abs(act - gold["act"]).max() == 0.0
+    assert np.abs(taps["logits"] - gold["logits"]).max() == 0.0
+    assert np.abs(taps["module11"] - gold["module11"]).max() == 0.0
+    assert np.abs(taps["stem_pool"][0] - gold["stem_pool_site0"]).max() == 0.0
+    assert np.abs(taps["module4"][1] - gold["module4_site1"]).max() == 0.0
+    assert np.abs(taps["lstm_fw_l2"][:, -1] - gold["lstm_fw_l2_last"]).max() == 0.0
+    assert np.abs(taps["lstm_bw_l2"][:, 0] - gold["lstm_bw_l2_first"]).max() == 0.0
+    assert np.abs(taps["fc1"][:, :512] - gold["fc1_head"]).max() == 0.0
+
+
+def test_oracle_f32_close_to_golden(gold, gold_weights):
+    act, pred, taps = oracle.forward(gold_weights, _feats(gold), "f32", taps=True)
+    assert np.abs(act - gold["act"]).max() < 2e-6
+    assert np.abs(taps["module11"] - gold["module11"]).max() < 2e-5
+    assert np.abs(taps["fc1"][:, :512] - gold["fc1_head"]).max() < 2e-5
+    decided = np.abs(gold["act"][:, 1] - gold["act"][:, 0]) > 1e-3
+    assert (pred[decided] == gold["pred"][decided]).all()
+
+
+def test_independent_torch_statement_agrees(gold, gold_weights):
+    """Two independent statements of the TF-1.x semantics (C loops vs torch library ops)."""
+    feats = _feats(gold)
+    o_act, o_pred, o_taps = oracle.forward(gold_weights, feats, "f64", taps=True)
+    t_act, t_pred, t_taps = torch_statement.forward(gold_weights, feats, torch.float64, True)
+    assert np.abs(o_act - t_act).max() < 1e-7 and np.array_equal(o_pred, t_pred)
+    for k, v in o_taps.items():
+        assert np.abs(v - t_taps[k]).max() <= 1e-6 * max(1.0, np.abs(v).max()), k
+
+
+def test_site_independence_and_batch_order(gold, gold_weights):
+    """Every site is an independent forward (no cross-site state): permuting / slicing the batch
+    permutes / slices the output bit-exactly."""
+    feats = _feats(gold)
+    act, pred = oracle.forward(gold_weights, feats, "f32")
+    perm = np.random.default_rng(0).permutation(len(pred))
+    p_act, p_pred = oracle.forward(gold_weights, {k: v[perm] for k, v in feats.items()}, "f32")
+    assert np.array_equal(p_act, act[perm]) and np.array_equal(p_pred, pred[perm])
+    one_act, _ = oracle.forward(gold_weights, {k: v[3:4] for k, v in feats.items()}, "f32")
+    assert np.array_equal(one_act[0], act[3])
+
+
+def test_semantics_spot_checks(gold_weights):
+    """Points where TF-1.x semantics are easy to get wrong."""
+    # labels / learning-rate do not influence inference; sigmoid (not softmax) head: outputs need not sum to 1
+    feats = synth.synthetic_features(4, seed=5)
+    act, pred = oracle.forward(gold_weights, feats, "f64")
+    assert ((act > 0) & (act < 1)).all() and np.abs(act.sum(axis=1) - 1).max() > 1e-3
+    assert np.array_equal(pred, np.argmax(act, axis=1))
+    # a short window zero-padded on the right is just an input (extract_features.py:157-160)
+    f2 = {k: v.copy() for k, v in feats.items()}
+    f2["signals"][:, 100:] = 0
+    a2, _ = oracle.forward(gold_weights, f2, "f64")
+    assert np.isfinite(a2).all()
+    # avg-pool divisor = in-bounds taps: a constant module-11 map must stay constant after pooling
+    x = np.ones((23, 4))
+    out = np.stack([x[max(0, w - 3):w + 4].mean(axis=0) for w in range(23)])
+    assert np.allclose(out, 1.0)
+
+
+def test_weight_file_roundtrip(tmp_path, gold_weights):
+    sub = {k: gold_weights[k] for k in list(gold_weights)[:40]}
+    p = str(tmp_path / "w.dsw")
+    weights.save_weights(p, sub)
+    back = weights.load_weights(p)
+    assert list(back) == list(sub)
+    for k in sub:
+        assert np.array_equal(back[k], sub[k]) and back[k].dtype == np.float32
+    with pytest.raises(KeyError):
+        weights.check_weights(sub)
