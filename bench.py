@@ -27,24 +27,25 @@ WORKLOAD = "configs[1]: 1xMI355X, batch=512, random-init CpG model weights, synt
 
 def cpu_baseline(weights, budget_s=15.0):
     """Bounded sample of the same workload through the CPU oracle on all host cores (kind: port)."""
-    import numpy as np
     from deepsignal_amd import synth
     from oracle import oracle
     cores = os.cpu_count() or 1
-    feats = synth.synthetic_features(2048, seed=synth.FEATURE_SEED)
-    probe = {k: v[:64] for k, v in feats.items()}
+    nmax = 16384
+    feats = synth.synthetic_features(nmax, seed=synth.FEATURE_SEED)
+    nprobe = min(nmax, max(256, 4 * cores))
+    probe = {k: v[:nprobe] for k, v in feats.items()}
     oracle.forward(weights, probe, "f32", nthreads=cores)          # warm-up (page-in, thread pool)
     t0 = time.perf_counter()
     oracle.forward(weights, probe, "f32", nthreads=cores)
-    rate = 64 / (time.perf_counter() - t0)
-    n = int(min(2048, max(64, (rate * budget_s) // 32 * 32)))
+    rate = nprobe / (time.perf_counter() - t0)
+    n = int(min(nmax, max(nprobe, (rate * budget_s) // 512 * 512)))
     sample = {k: v[:n] for k, v in feats.items()}
     t0 = time.perf_counter()
     oracle.forward(weights, sample, "f32", nthreads=cores)
     dt = time.perf_counter() - t0
     return {"value": round(n / dt, 2), "unit": "sites/s", "cores": cores, "kind": "port",
-            "sample": "%d synthetic sites of the same workload through oracle/ds_oracle.c (f32, OpenMP, %d threads), %.1f s"
-                      % (n, cores, dt)}
+            "sample": "%d synthetic sites of the same workload (batches of 512) through oracle/ds_oracle.c "
+                      "(f32, OpenMP, %d threads), %.1f s" % (n, cores, dt)}
 
 
 def main():
@@ -111,9 +112,11 @@ def main():
     eng.sync()
     if dist is not None:
         # the path's only exchange: gather f32[n,2] + i32[n] (12 B/site) to the writer rank over RCCL
-        packed = torch.cat([out_act.reshape(-1, 2), out_pred.reshape(-1, 1).to(torch.float32)], dim=1).contiguous()
-        gl = [torch.empty_like(packed) for _ in range(world)] if rank == 0 else None
-        dist.gather(packed, gl, dst=0)
+        from deepsignal_amd import sharding
+        gidx = torch.arange(rank, world * K * BATCH, world, dtype=torch.int64, device=dev)   # this rank's global site ids
+        g_act, g_pred = sharding.gather_results(out_act.reshape(-1, 2), out_pred.reshape(-1), gidx, dist, dst=0, device=dev)
+        if rank == 0:
+            assert g_act.shape[0] == world * K * BATCH
     fence()
     elapsed = time.perf_counter() - t0
     if dist is not None:
