@@ -64,9 +64,10 @@ struct Op {
 };
 
 // per-kernel accumulators (one entry per __global__ function / template instantiation)
-enum KernelClass { K_GEMM_CONV = 0, K_GEMM_FC, K_GEMM_LSTM, K_GEMM_CONV_WIDE, K_GEMM_CONV_POOL, K_FUSED1, K_FUSED2, K_FUSED3, K_STEM1, K_MAXPOOL, K_AVGPOOL, K_HEAD, K_COUNT };
+enum KernelClass { K_GEMM_CONV = 0, K_GEMM_FC, K_GEMM_LSTM, K_GEMM_CONV_WIDE, K_GEMM_CONV_POOL, K_GEMM_FC_DENSE, K_GEMM_LSTM_DENSE, K_FUSED1, K_FUSED2, K_FUSED3, K_STEM1, K_MAXPOOL, K_AVGPOOL, K_HEAD, K_COUNT };
 const char* const kKernelNames[K_COUNT] = {"gemm_kernel<1,2,4,1,0,0,1,1>", "gemm_kernel<1,3,4,1,0,0,2,1>", "gemm_kernel<1,4,4,1,1,0,1,1>",
-                                           "gemm_kernel<2,2,2,2,0,0,1,1>", "gemm_kernel<1,2,4,1,0,1,1,1>", "inception_fused_kernel<1>",
+                                           "gemm_kernel<2,2,2,2,0,0,1,1>", "gemm_kernel<1,2,4,1,0,1,1,1>", "gemm_kernel<1,3,4,1,0,2,2,1>",
+                                           "gemm_kernel<1,4,4,1,1,2,1,1>", "inception_fused_kernel<1>",
                                            "inception_fused_kernel<2>", "inception_fused_kernel<3>", "stem1_kernel",
                                            "maxpool_s2_kernel", "avgpool7_kernel", "head_kernel"};
 struct KernelStat {
@@ -579,6 +580,9 @@ int build_plan(ds_handle* h, int n, Plan* plan)
     // grouped launch; cell (l,s) depends only on (l-1,s) and (l,s-1), both on diagonal d-1.
     st = stage_id(h, "bilstm", 1);
     const int T = h->T;
+    // dense variants skip the per-row validity selects; legal when every tile row is a real site
+    const GemmCfg lstm_cfg = n % 128 == 0 ? CFG_LSTM_DENSE : CFG_LSTM;
+    const GemmCfg fc_cfg = n % 128 == 0 ? CFG_FC_DENSE : CFG_FC;
     for (int d = 0; d < T + NLAYER - 1; ++d) {
         GemmLaunch L{};
         for (int dir = 0; dir < 2; ++dir)
@@ -596,9 +600,9 @@ int build_plan(ds_handle* h, int n, Plan* plan)
                 P.lstm.c = h->Cst[dir][l];
                 P.lstm.h_out = h->H[dir][l] + (size_t)t * h->B * HID;
                 P.lstm.t = t; P.lstm.T = T; P.lstm.c_zero = s == 0;
-                add_tiles(L, P, CFG_LSTM);
+                add_tiles(L, P, lstm_cfg);
             }
-        add_gemm_op(rnn, 1, st, CFG_LSTM, L);
+        add_gemm_op(rnn, 1, st, lstm_cfg, L);
     }
 
     // ================= joint model (stream 0 after join) — layers.py:247-264 =================
@@ -612,8 +616,8 @@ int build_plan(ds_handle* h, int n, Plan* plan)
         add_seg(P, h->H[1][NLAYER - 1] + 0, HID, 0, HID);
         add_seg(P, h->sigfeat, h->SF, 0, h->SF);
         add_out(P, h->fc1o, h->J, 0, h->J, 0);
-        add_tiles(L, P, CFG_FC);
-        add_gemm_op(tail, 0, st, CFG_FC, L);
+        add_tiles(L, P, fc_cfg);
+        add_gemm_op(tail, 0, st, fc_cfg, L);
     }
     st = stage_id(h, "head", 0);
     {
@@ -708,7 +712,8 @@ int kernel_class(const Op& op)
     switch (op.kind) {
     case OP_GEMM:
         return op.cfg == CFG_CONV ? K_GEMM_CONV : op.cfg == CFG_FC ? K_GEMM_FC : op.cfg == CFG_LSTM ? K_GEMM_LSTM
-               : op.cfg == CFG_CONV_POOL ? K_GEMM_CONV_POOL : K_GEMM_CONV_WIDE;
+               : op.cfg == CFG_CONV_POOL ? K_GEMM_CONV_POOL : op.cfg == CFG_FC_DENSE ? K_GEMM_FC_DENSE
+               : op.cfg == CFG_LSTM_DENSE ? K_GEMM_LSTM_DENSE : K_GEMM_CONV_WIDE;
     case OP_FUSED: return op.tm == 1 ? K_FUSED1 : op.tm == 2 ? K_FUSED2 : K_FUSED3;
     case OP_STEM1: return K_STEM1;
     case OP_MAXPOOL: return K_MAXPOOL;

@@ -71,7 +71,7 @@ struct GemmLaunch {
     int pad_[2];
 };
 
-enum GemmCfg { CFG_CONV = 0, CFG_FC = 1, CFG_LSTM = 2, CFG_CONV_WIDE = 3, CFG_CONV_POOL = 4 };
+enum GemmCfg { CFG_CONV = 0, CFG_FC = 1, CFG_LSTM = 2, CFG_CONV_WIDE = 3, CFG_CONV_POOL = 4, CFG_FC_DENSE = 5, CFG_LSTM_DENSE = 6 };
 
 // tile geometry per config (host needs it for grid sizing)
 struct TileGeom { int bm, bn, threads, ksplit; };

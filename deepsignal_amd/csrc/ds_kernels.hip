@@ -60,7 +60,9 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void gemm_kernel(const GemmLaunc
     constexpr int RED_FLOATS = KS > 1 ? WM * WN * MT * NT * 16 * 64 : 0;
     __shared__ __attribute__((aligned(16))) float smem_[AS_FLOATS > RED_FLOATS ? AS_FLOATS : RED_FLOATS];
 
-    const int lane = threadIdx.x & 63, wave_all = threadIdx.x >> 6;
+    // the wave index is wave-uniform, but hipcc cannot prove it from threadIdx: readfirstlane keeps the
+    // K-lane / segment-cursor logic on the scalar unit (otherwise it becomes exec-masked vector code)
+    const int lane = threadIdx.x & 63, wave_all = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int kl = wave_all / (WM * WN);        // K-lane of this wave
     const int wave = wave_all % (WM * WN);
     const int tid = threadIdx.x - kl * NTHR;    // thread index inside the K-lane
@@ -169,7 +171,7 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void gemm_kernel(const GemmLaunc
                 apm[i] += KC;
                 app[i] += KC;
             }
-            lok[X][i] = aok[i];
+            if (AMODE != 2) lok[X][i] = aok[i];
         }
         advance();
 #pragma unroll
@@ -182,10 +184,12 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void gemm_kernel(const GemmLaunc
             const int idx = tid + i * NTHR;
             float4 v = R[X][i];
             if (AMODE == 1) v = f4max(f4max(v, Rm[X][i]), Rp[X][i]);   // maxpool(3, s1, SAME): padded taps ignored
-            v.x = lok[X][i] ? v.x : 0.0f;
-            v.y = lok[X][i] ? v.y : 0.0f;
-            v.z = lok[X][i] ? v.z : 0.0f;
-            v.w = lok[X][i] ? v.w : 0.0f;
+            if (AMODE != 2) {     // AMODE 2 = dense: every row of every tile is valid, no taps -> no select
+                v.x = lok[X][i] ? v.x : 0.0f;
+                v.y = lok[X][i] ? v.y : 0.0f;
+                v.z = lok[X][i] ? v.z : 0.0f;
+                v.w = lok[X][i] ? v.w : 0.0f;
+            }
             if (SLOTS * NTHR == BM * 4 || idx < BM * 4)
                 *reinterpret_cast<float4*>(dst + (idx >> 2) * LDA + (idx & 3) * 4) = v;
         }
@@ -225,7 +229,7 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void gemm_kernel(const GemmLaunc
     constexpr int N_MFMA_HALF = MT * NT * 4;
     constexpr int N_ALOADS = SLOTS * (AMODE == 1 ? 3 : 1);
     constexpr int N_BLOADS = 2 * NT;
-    constexpr int N_VALU_PER_STORE = (AMODE == 1 ? 12 : 4);
+    constexpr int N_VALU_PER_STORE = (AMODE == 1 ? 12 : AMODE == 2 ? 0 : 4);
 #define DS_STEP(X, JC, JN, HAS1, HAS2, HASB)                                              \
     do {                                                                                  \
         if (HAS2) load_a(X);                                                              \
@@ -235,7 +239,7 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void gemm_kernel(const GemmLaunc
         if (HAS1) {                                                                       \
             _Pragma("unroll") for (int i_ = 0; i_ < SLOTS; ++i_) {                        \
                 __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);                          \
-                __builtin_amdgcn_sched_group_barrier(0x2, N_VALU_PER_STORE, 0);           \
+                if (N_VALU_PER_STORE) __builtin_amdgcn_sched_group_barrier(0x2, N_VALU_PER_STORE, 0); \
                 __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);                        \
             }                                                                             \
         }                                                                                 \
@@ -425,6 +429,8 @@ TileGeom gemm_geom(GemmCfg cfg)
     case CFG_LSTM: return {128, 128, 256, 1};       // MT1 NT4 WM4 WN1 (one 32-unit gate group per block)
     case CFG_CONV_WIDE: return {128, 128, 256, 1};  // MT2 NT2 WM2 WN2
     case CFG_CONV_POOL: return {128, 64, 256, 1};   // CFG_CONV with maxpool(3,s1) fused into the A load
+    case CFG_FC_DENSE: return {128, 96, 256, 1};    // CFG_FC / CFG_LSTM for M % 128 == 0 (no row masks)
+    case CFG_LSTM_DENSE: return {128, 128, 256, 1};
     }
     return {0, 0, 0, 1};
 }
@@ -438,6 +444,8 @@ hipError_t launch_gemm(GemmCfg cfg, const GemmLaunch* d_launch, int total_tiles,
     case CFG_LSTM: hipLaunchKernelGGL((gemm_kernel<1, 4, 4, 1, 1, 0, 1, 1>), dim3(total_tiles), dim3(256), 0, s, d_launch); break;
     case CFG_CONV_WIDE: hipLaunchKernelGGL((gemm_kernel<2, 2, 2, 2, 0, 0, 1, 1>), dim3(total_tiles), dim3(256), 0, s, d_launch); break;
     case CFG_CONV_POOL: hipLaunchKernelGGL((gemm_kernel<1, 2, 4, 1, 0, 1, 1, 1>), dim3(total_tiles), dim3(256), 0, s, d_launch); break;
+    case CFG_FC_DENSE: hipLaunchKernelGGL((gemm_kernel<1, 3, 4, 1, 0, 2, 2, 1>), dim3(total_tiles), dim3(256), 0, s, d_launch); break;
+    case CFG_LSTM_DENSE: hipLaunchKernelGGL((gemm_kernel<1, 4, 4, 1, 1, 2, 1, 1>), dim3(total_tiles), dim3(256), 0, s, d_launch); break;
     }
     return hipGetLastError();
 }
@@ -452,6 +460,9 @@ hipError_t launch_gemm(GemmCfg cfg, const GemmLaunch* d_launch, int total_tiles,
 //   P2b branch 5's last 1x1 accumulates ON TOP of the stem accumulators (waves 0,1) while the other
 //       waves finish the 1x3 / 1x5 convs of branches 3 and 4.
 // HBM traffic per module = read input once + write output once (module-granular bytes).
+#ifndef DS_FUSED_WPS
+#define DS_FUSED_WPS 2
+#endif
 constexpr int F_LDA = KC + 4;   // staged chunk row stride (floats)
 constexpr int F_LD1 = 100;      // T1 row stride: 96 channels + 4 pad (25 x 16 B: odd -> conflict-free b128)
 constexpr int F_LD2 = 68;       // T2 row stride: 64 channels + 4 pad
@@ -466,24 +477,32 @@ template <int NTAPS>
 __device__ __forceinline__ void fused_conv_unit(const float* T1, int rm, int coloff, int nt, int lane,
                                                 const float* __restrict__ Bp, floatx16& acc)
 {
-    constexpr int NRS = NTAPS * 4;      // 8-wide k-groups: 4 per 32-channel tap
-    float4 b[NRS];
-#pragma unroll
-    for (int g = 0; g < NRS; ++g) b[g] = gload4(Bp + ((size_t)(nt * NRS + g) * 64 + lane) * 4);
+    // one tap = 32 input channels = 4 k-groups; weights of tap t+1 are prefetched while tap t computes
+    const float* bsrc = Bp + ((size_t)(nt * NTAPS * 4) * 64 + lane) * 4;
     const float* base = T1 + rm * F_LD1 + coloff + (lane >> 5) * 4;
+    float4 b[2][4];
 #pragma unroll
-    for (int g = 0; g < NRS; ++g) {
-        const int tap = g / 4 - NTAPS / 2;
-        const float4 a = *reinterpret_cast<const float4*>(base + tap * F_LD1 + (g % 4) * 8);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b[g].x, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b[g].y, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b[g].z, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b[g].w, acc, 0, 0, 0);
+    for (int g = 0; g < 4; ++g) b[0][g] = gload4(bsrc + g * 256);
+#pragma unroll
+    for (int t = 0; t < NTAPS; ++t) {
+        if (t + 1 < NTAPS) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) b[(t + 1) & 1][g] = gload4(bsrc + ((t + 1) * 4 + g) * 256);
+        }
+        const float* arow = base + (t - NTAPS / 2) * F_LD1;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 a = *reinterpret_cast<const float4*>(arow + g * 8);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b[t & 1][g].x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b[t & 1][g].y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b[t & 1][g].z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b[t & 1][g].w, acc, 0, 0, 0);
+        }
     }
 }
 
 template <int TM>
-__global__ __launch_bounds__(512) void inception_fused_kernel(const FusedArgs a)
+__global__ __launch_bounds__(512, DS_FUSED_WPS) void inception_fused_kernel(const FusedArgs a)
 {
     constexpr int TR32 = TM * 32;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -491,7 +510,7 @@ __global__ __launch_bounds__(512) void inception_fused_kernel(const FusedArgs a)
     float* Ap = smem + 2 * TR32 * F_LDA;      // [2][TR32*F_LDA] max-pooled rows
     float* T2 = smem;                         // [TR32*F_LD2], aliases Ad/Ap once P1 is done
     float* T1 = smem + 4 * TR32 * F_LDA;      // [spt*(W+4)][F_LD1]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int W = a.W, spt = a.spt, cin = a.cin;
     int* rowmap = reinterpret_cast<int*>(T1 + spt * (W + 4) * F_LD1);   // [TR32] tile row -> T1 row
     const int site0 = blockIdx.x * spt;
