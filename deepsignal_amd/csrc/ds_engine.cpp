@@ -497,7 +497,8 @@ int build_plan(ds_handle* h, int n, Plan* plan)
             // one fused launch per module; tile = spt whole sites (<= 96 rows). Pick the spt that
             // minimises padded rows while keeping >= 256 workgroups when the batch allows it.
             int best_spt = 1; long best_rows = -1;
-            for (int spt = 1; spt * W <= 96; ++spt) {
+            static const int max_spt = getenv("DS_FUSE_MAX_SPT") ? atoi(getenv("DS_FUSE_MAX_SPT")) : 8;   // tuning knob
+            for (int spt = 1; spt * W <= 96 && spt <= max_spt; ++spt) {
                 const int tiles = (n + spt - 1) / spt;
                 if (spt > 1 && tiles < std::min(256, n)) break;
                 const long rows = (long)tiles * ((spt * W + 31) / 32) * 32;

@@ -540,76 +540,87 @@ __global__ __launch_bounds__(512, DS_FUSED_WPS) void inception_fused_kernel(cons
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[mt][r] = 0.0f;
 
-    float4 vc, vm, vp;
-    auto load_a = [&]() {
+    // P1 main loop: same software pipeline as gemm_kernel (fragments of chunk c+1 are read into
+    // registers behind the second half of chunk c's MFMAs; one barrier per chunk).
+    float4 vc[2], vm[2], vp[2];
+    float4 bq[2][2];
+    float4 af[2][2][TM];
+    auto load_a = [&](int X) {
         if (stager) {
-            vc = gload4(pc); vm = gload4(pm); vp = gload4(pp);
+            vc[X] = gload4(pc); vm[X] = gload4(pm); vp[X] = gload4(pp);
             pc += KC; pm += KC; pp += KC;
         }
     };
-    auto store_a = [&](int buf) {
+    auto store_a = [&](int X) {
         if (stager) {
-            *reinterpret_cast<float4*>(Ad + buf * TR32 * F_LDA + sr * F_LDA + sq * 4) = vc;
-            *reinterpret_cast<float4*>(Ap + buf * TR32 * F_LDA + sr * F_LDA + sq * 4) = f4max(f4max(vc, vm), vp);
+            *reinterpret_cast<float4*>(Ad + X * TR32 * F_LDA + sr * F_LDA + sq * 4) = vc[X];
+            *reinterpret_cast<float4*>(Ap + X * TR32 * F_LDA + sr * F_LDA + sq * 4) = f4max(f4max(vc[X], vm[X]), vp[X]);
         }
     };
-    auto load_b = [&](float4(&b)[2]) {
-        b[0] = gload4(bp);
-        b[1] = gload4(bp + 256);
+    auto load_b = [&](int X) {
+        bq[X][0] = gload4(bp);
+        bq[X][1] = gload4(bp + 256);
         bp += 512;
     };
     const float* asrc = wave < 6 ? Ad : Ap;    // n-tiles 6,7 are branch 1 (pooled input)
-    auto compute = [&](int buf, const float4(&b)[2]) {
-        float4 af[2][TM];
+    auto read_frags = [&](int X) {
 #pragma unroll
         for (int rs = 0; rs < 2; ++rs)
 #pragma unroll
             for (int mt = 0; mt < TM; ++mt)
-                af[rs][mt] = *reinterpret_cast<const float4*>(asrc + buf * TR32 * F_LDA + (mt * 32 + (lane & 31)) * F_LDA +
-                                                              rs * 8 + (lane >> 5) * 4);
-#pragma unroll
-        for (int rs = 0; rs < 2; ++rs)
-#pragma unroll
-            for (int mt = 0; mt < TM; ++mt) {
-                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[rs][mt].x, b[rs].x, acc[mt], 0, 0, 0);
-                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[rs][mt].y, b[rs].y, acc[mt], 0, 0, 0);
-                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[rs][mt].z, b[rs].z, acc[mt], 0, 0, 0);
-                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[rs][mt].w, b[rs].w, acc[mt], 0, 0, 0);
-            }
+                af[X][rs][mt] = *reinterpret_cast<const float4*>(asrc + X * TR32 * F_LDA + (mt * 32 + (lane & 31)) * F_LDA +
+                                                                 rs * 8 + (lane >> 5) * 4);
     };
+    auto mfma_rs = [&](int X, int rs) {
+#pragma unroll
+        for (int mt = 0; mt < TM; ++mt) {
+            acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[X][rs][mt].x, bq[X][rs].x, acc[mt], 0, 0, 0);
+            acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[X][rs][mt].y, bq[X][rs].y, acc[mt], 0, 0, 0);
+            acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[X][rs][mt].z, bq[X][rs].z, acc[mt], 0, 0, 0);
+            acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[X][rs][mt].w, bq[X][rs].w, acc[mt], 0, 0, 0);
+        }
+    };
+#define DS_FSTEP(X, HAS1, HAS2)                                   \
+    do {                                                          \
+        if (HAS2) load_a(X);                                      \
+        if (HAS1) load_b((X) ^ 1);                                \
+        if (HAS1) store_a((X) ^ 1);                               \
+        mfma_rs(X, 0);                                            \
+        __builtin_amdgcn_sched_barrier(0);                        \
+        __syncthreads();                                          \
+        if (HAS1) read_frags((X) ^ 1);                            \
+        mfma_rs(X, 1);                                            \
+        __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);          \
+        if (HAS1) __builtin_amdgcn_sched_group_barrier(0x100, 2 * TM, 0); \
+        __builtin_amdgcn_sched_group_barrier(0x8, 4 * TM, 0);     \
+        __builtin_amdgcn_sched_barrier(0);                        \
+    } while (0)
 
-    const int nchunks = cin / KC;
-    float4 b0[2], b1[2];
-    load_a();
-    load_b(b0);
+    const int nchunks = cin / KC;      // >= 15
+    load_a(0);
+    load_b(0);
     store_a(0);
+    load_a(1);
     __syncthreads();
+    read_frags(0);
     int c = 0;
-    while (c + 2 < nchunks) {
-        load_a(); load_b(b1);
-        __builtin_amdgcn_sched_barrier(0);
-        compute(0, b0);
-        __builtin_amdgcn_sched_barrier(0);
-        store_a(1);
-        __syncthreads();
-        load_a(); load_b(b0);
-        __builtin_amdgcn_sched_barrier(0);
-        compute(1, b1);
-        __builtin_amdgcn_sched_barrier(0);
-        store_a(0);
-        __syncthreads();
+    while (c + 3 < nchunks) {
+        DS_FSTEP(0, true, true);
+        DS_FSTEP(1, true, true);
         c += 2;
     }
-    if (nchunks - c == 2) {
-        load_a(); load_b(b1);
-        __builtin_amdgcn_sched_barrier(0);
-        compute(0, b0);
-        store_a(1);
-        __syncthreads();
-        compute(1, b1);
+    if (nchunks - c == 3) {
+        DS_FSTEP(0, true, true);
+        DS_FSTEP(1, true, false);
+        DS_FSTEP(0, false, false);
+    } else if (nchunks - c == 2) {
+        DS_FSTEP(0, true, false);
+        DS_FSTEP(1, false, false);
     } else {
-        compute(0, b0);
+        DS_FSTEP(0, false, false);
     }
+#undef DS_FSTEP
+    __syncthreads();   // all fragment reads of the staging area are done before T2 aliases it
 
     // ---- P1 epilogue: route the 256 columns
     const int rl = 4 * (lane >> 5);
