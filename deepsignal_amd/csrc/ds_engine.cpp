@@ -136,6 +136,7 @@ struct ds_handle {
     int* pred = nullptr;
 
     const float* zero_seg = nullptr;
+    unsigned long long* dbg_stamps = nullptr;   // [NMOD][1024 wgs][2 waves][8] when DS_DEBUG_STAMPS is set
     std::vector<Stage> stages;
     KernelStat kstat[K_COUNT];
     std::map<int, Plan> plans;
@@ -513,6 +514,7 @@ int build_plan(ds_handle* h, int n, Plan* plan)
             op.fa.Bp4b = h->m_b4b[m].Bp; op.fa.bias4b = h->m_b4b[m].bias;
             op.fa.Bp5b = h->m_b5b[m].Bp; op.fa.bias5b = h->m_b5b[m].bias;
             op.fa.Bp5c = h->m_b5c[m].Bp; op.fa.bias5c = h->m_b5c[m].bias;
+            op.fa.dbg = h->dbg_stamps ? h->dbg_stamps + (size_t)m * 1024 * 16 : nullptr;
             op.flops = 2.0 * M * ((double)cin * 240 + 96 * 48 + 160 * 48 + 96 * 64 + 64 * 48);
             if (first_plan) h->stages[st].flops_per_site += op.flops / n;
             add_ew_op(cnn, op);
@@ -835,6 +837,10 @@ int ds_create(const ds_config* cfg, ds_handle** out)
         rc = dalloc(h, &z, 64);
         if (!rc && hipMemset(z, 0, 256) != hipSuccess) rc = fail(h, DS_ERR_HIP, "hipMemset");
         h->zero_seg = z;
+        if (!rc && getenv("DS_DEBUG_STAMPS")) {
+            rc = dalloc(h, &h->dbg_stamps, (size_t)NMOD * 1024 * 16);
+            if (!rc) hipMemset(h->dbg_stamps, 0, (size_t)NMOD * 1024 * 16 * 8);
+        }
     }
     if (rc) { g_create_error = h->err; ds_destroy(h); return rc; }
     *out = h;
@@ -1015,6 +1021,24 @@ int64_t ds_get_intermediate(ds_handle* h, const char* name, float* out, int64_t 
             for (int t = 0; t < h->T; ++t)
                 memcpy(out + ((size_t)i * h->T + t) * HID, tmp.data() + ((size_t)t * h->B + i) * HID, HID * 4);
         return count;
+    }
+    if (s.rfind("stamps", 0) == 0) {   // "stampsN": phase stamp deltas (cycles) of fused module N, wave 0 and wave 7, averaged over workgroups
+        if (!h->dbg_stamps) return fail(h, DS_ERR_INVALID, "set DS_DEBUG_STAMPS=1");
+        const int m = atoi(s.c_str() + 6) - 1;
+        if (m < 0 || m >= NMOD || capacity < 16) return fail(h, DS_ERR_INVALID, "bad stamps request");
+        std::vector<unsigned long long> st(1024 * 16);
+        if (hipMemcpy(st.data(), h->dbg_stamps + (size_t)m * 1024 * 16, st.size() * 8, hipMemcpyDeviceToHost) != hipSuccess) return fail(h, DS_ERR_HIP, "hipMemcpy D2H");
+        double sum[16] = {0};
+        int cnt = 0;
+        for (int wg = 0; wg < 1024; ++wg) {
+            if (!st[wg * 16 + 7]) continue;
+            ++cnt;
+            for (int wv = 0; wv < 2; ++wv)
+                for (int i = 1; i < 8; ++i) sum[wv * 8 + i] += (double)(st[wg * 16 + wv * 8 + i] - st[wg * 16 + wv * 8 + i - 1]);
+        }
+        for (int i = 0; i < 16; ++i) out[i] = cnt ? (float)(sum[i] / cnt) : 0.0f;
+        out[0] = (float)cnt;
+        return 16;
     }
     if (s == "joint") {
         const int64_t count = (int64_t)n * h->J;

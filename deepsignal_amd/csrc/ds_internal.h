@@ -88,6 +88,7 @@ struct FusedArgs {
     const float* Bp1;    // packed [cin x 256]: columns b5s(48)|b2(48)|b3a(32)|b4a(32)|b5a(32)|b1(48, pooled input)|pad
     const float* bias1;  // [256]
     const float *Bp3b, *bias3b, *Bp4b, *bias4b, *Bp5b, *bias5b, *Bp5c, *bias5c;
+    unsigned long long* dbg;   // diagnostic: per-workgroup phase time stamps (null in normal runs)
 };
 // tm = 32-row m-tiles per workgroup (1..3), spt*W <= 32*tm
 hipError_t launch_inception_fused(int tm, const FusedArgs& a, hipStream_t s);

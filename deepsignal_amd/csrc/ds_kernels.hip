@@ -378,43 +378,72 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void gemm_kernel(const GemmLaunc
         }
     } else {
         // NT == 4: the wave's four n-tiles are gates i,j,f,o of unit group ug (weights packed so).
+        // Uniform (SGPR) base pointers + 32-bit per-lane offsets keep the address math off the VALU;
+        // each half of the rows issues all its loads before any gate math or store.
         const LstmEp E = P.lstm;
         const int ug = tn * WN + wn;
-        const int u = ug * 32 + (lane & 31);
+        const unsigned u = ug * 32 + (lane & 31);
         if (nvalid[0]) {
-            float bi = P.bias[u], bj = P.bias[256 + u], bf = P.bias[512 + u], bo = P.bias[768 + u];
-            float wi[3], wj[3], wf[3], wo[3];
-            if (E.table) {
+            const gptr1 biasg = (gptr1)P.bias;
+            const float bi = biasg[u], bj = biasg[256 + u], bf = biasg[512 + u] + 1.0f, bo = biasg[768 + u];   // forget_bias folded
+            const bool has_table = E.table != nullptr;
+            float wi[3] = {0, 0, 0}, wj[3] = {0, 0, 0}, wf[3] = {0, 0, 0}, wo[3] = {0, 0, 0};
+            if (has_table) {
+                const gptr1 wg = (gptr1)E.wfeat;
 #pragma unroll
                 for (int q = 0; q < 3; ++q) {
-                    wi[q] = E.wfeat[q * 1024 + u];
-                    wj[q] = E.wfeat[q * 1024 + 256 + u];
-                    wf[q] = E.wfeat[q * 1024 + 512 + u];
-                    wo[q] = E.wfeat[q * 1024 + 768 + u];
+                    wi[q] = wg[q * 1024 + u];
+                    wj[q] = wg[q * 1024 + 256 + u];
+                    wf[q] = wg[q * 1024 + 512 + u];
+                    wo[q] = wg[q * 1024 + 768 + u];
                 }
             }
+            const gptr1 cg = (gptr1)E.c;
+            const gptr1w cgw = (gptr1w)E.c;
+            const gptr1w hg = (gptr1w)E.h_out;
+            const gptr1 tabg = (gptr1)E.table;
+            const gptr1 meang = (gptr1)E.means, stdg = (gptr1)E.stds, leng = (gptr1)E.lens;
+            const __attribute__((address_space(1))) int* codeg = (const __attribute__((address_space(1))) int*)E.codes;
+            const bool c_zero = E.c_zero != 0;
+            const unsigned Tt = E.T, tt = E.t;
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = rbase + mt * 32 + (r & 3) + 8 * (r >> 2);
-                    if (row < M && r >= r_lo && r < r_hi) {
-                        float zi = acc[mt][0 % NT][r] + bi, zj = acc[mt][1 % NT][r] + bj;
-                        float zf = acc[mt][2 % NT][r] + bf, zo = acc[mt][3 % NT][r] + bo;
-                        if (E.table) {
-                            const size_t it = (size_t)row * E.T + E.t;
-                            const float* trow = E.table + (size_t)E.codes[it] * 1024;
-                            const float f0 = E.means[it], f1 = E.stds[it], f2 = E.lens[it];
-                            zi += trow[u] + f0 * wi[0] + f1 * wi[1] + f2 * wi[2];
-                            zj += trow[256 + u] + f0 * wj[0] + f1 * wj[1] + f2 * wj[2];
-                            zf += trow[512 + u] + f0 * wf[0] + f1 * wf[1] + f2 * wf[2];
-                            zo += trow[768 + u] + f0 * wo[0] + f1 * wo[1] + f2 * wo[2];
+                for (int hb = 0; hb < 2; ++hb) {
+                    if (hb * 8 < r_lo || hb * 8 >= r_hi) continue;      // rows owned by the other K-lane
+                    float cp[8], xi[8], xj[8], xf[8], xo[8];
+                    unsigned off[8];
+                    bool ok[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const int r = hb * 8 + k;
+                        const int row = rbase + mt * 32 + (r & 3) + 8 * (r >> 2);
+                        ok[k] = AMODE == 2 || row < M;
+                        const unsigned rowc = ok[k] ? row : 0;
+                        off[k] = rowc * 256u + u;
+                        cp[k] = c_zero ? 0.0f : cg[off[k]];
+                        xi[k] = xj[k] = xf[k] = xo[k] = 0.0f;
+                        if (has_table) {
+                            const unsigned it = rowc * Tt + tt;
+                            const unsigned tb = (unsigned)codeg[it] * 1024u + u;
+                            const float f0 = meang[it], f1 = stdg[it], f2 = leng[it];
+                            xi[k] = tabg[tb] + f0 * wi[0] + f1 * wi[1] + f2 * wi[2];
+                            xj[k] = tabg[tb + 256] + f0 * wj[0] + f1 * wj[1] + f2 * wj[2];
+                            xf[k] = tabg[tb + 512] + f0 * wf[0] + f1 * wf[1] + f2 * wf[2];
+                            xo[k] = tabg[tb + 768] + f0 * wo[0] + f1 * wo[1] + f2 * wo[2];
                         }
-                        const size_t ix = (size_t)row * 256 + u;
-                        const float cp = E.c_zero ? 0.0f : E.c[ix];
-                        const float cn = fast_sigmoid(zf + 1.0f) * cp + fast_sigmoid(zi) * fast_tanh(zj);
-                        E.c[ix] = cn;
-                        E.h_out[ix] = fast_sigmoid(zo) * fast_tanh(cn);
+                    }
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const int r = hb * 8 + k;
+                        const float zi = acc[mt][0 % NT][r] + bi + xi[k], zj = acc[mt][1 % NT][r] + bj + xj[k];
+                        const float zf = acc[mt][2 % NT][r] + bf + xf[k], zo = acc[mt][3 % NT][r] + bo + xo[k];
+                        const float cn = fast_sigmoid(zf) * cp[k] + fast_sigmoid(zi) * fast_tanh(zj);
+                        const float hn = fast_sigmoid(zo) * fast_tanh(cn);
+                        if (ok[k]) {
+                            cgw[off[k]] = cn;
+                            hg[off[k]] = hn;
+                        }
                     }
                 }
         }
@@ -517,7 +546,13 @@ __global__ __launch_bounds__(512, DS_FUSED_WPS) void inception_fused_kernel(cons
     const int nhere = min(spt, a.n_sites - site0);
     const int TRv = nhere * W;                // valid rows of this tile
     const size_t grow0 = (size_t)site0 * W;
+    const gptr1w Yg = (gptr1w)(a.Y + grow0 * 240);     // wave-uniform base; per-lane offsets stay 32-bit
 
+    // diagnostic phase stamps (wave 0 and wave 7, lane 0): only when a debug buffer is attached
+    const bool stamp = a.dbg != nullptr && lane == 0 && (wave == 0 || wave == 7);
+    unsigned long long* sdst = a.dbg + ((size_t)blockIdx.x * 2 + (wave == 7)) * 8;
+#define DS_STAMP(i) do { if (stamp) sdst[i] = __builtin_amdgcn_s_memtime(); } while (0)
+    DS_STAMP(0);
     for (int i = tid; i < spt * (W + 4) * F_LD1; i += 512) T1[i] = 0.0f;   // halos (and everything else) = 0
     if (tid < TR32) {
         const int r = tid < TRv ? tid : 0;
@@ -620,7 +655,9 @@ __global__ __launch_bounds__(512, DS_FUSED_WPS) void inception_fused_kernel(cons
         DS_FSTEP(0, false, false);
     }
 #undef DS_FSTEP
+    DS_STAMP(1);
     __syncthreads();   // all fragment reads of the staging area are done before T2 aliases it
+    DS_STAMP(2);
 
     // ---- P1 epilogue: route the 256 columns
     const int rl = 4 * (lane >> 5);
@@ -635,14 +672,16 @@ __global__ __launch_bounds__(512, DS_FUSED_WPS) void inception_fused_kernel(cons
                     const int row = mt * 32 + rl + (r & 3) + 8 * (r >> 2);
                     if (row < TRv) {
                         const float v = fmaxf(acc[mt][r] + bias, 0.0f);
-                        if (col < 96) gstore(a.Y + (grow0 + row) * 240 + col, v);                 // branch 2 -> [48,96)
+                        if (col < 96) Yg[(unsigned)(row * 240 + col)] = v;                        // branch 2 -> [48,96)
                         else if (col < 192) T1[rowmap[row] * F_LD1 + (col - 96)] = v;             // b3a | b4a | b5a
-                        else gstore(a.Y + (grow0 + row) * 240 + (col - 192), v);                  // branch 1 -> [0,48)
+                        else Yg[(unsigned)(row * 240 + col - 192)] = v;                           // branch 1 -> [0,48)
                     }
                 }
         }
     }
+    DS_STAMP(3);
     __syncthreads();   // T1 complete; Ad/Ap dead -> T2 may be written
+    DS_STAMP(4);
 
     const int rm_of = lane & 31;
     auto store_unit_global = [&](const floatx16& u, int mt, int nt, const float* bias, int ybase) {
@@ -652,7 +691,7 @@ __global__ __launch_bounds__(512, DS_FUSED_WPS) void inception_fused_kernel(cons
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = mt * 32 + rl + (r & 3) + 8 * (r >> 2);
-                if (row < TRv) gstore(a.Y + (grow0 + row) * 240 + ybase + col, fmaxf(u[r] + bv, 0.0f));
+                if (row < TRv) Yg[(unsigned)(row * 240 + ybase + col)] = fmaxf(u[r] + bv, 0.0f);
             }
         }
     };
@@ -696,7 +735,9 @@ __global__ __launch_bounds__(512, DS_FUSED_WPS) void inception_fused_kernel(cons
         else if (wave < 4) unit_b3b(0, wave - 2);
         else if (wave < 6) unit_b4b(0, wave - 4);
     }
+    DS_STAMP(5);
     __syncthreads();   // T2 complete
+    DS_STAMP(6);
 
     // ---- P2b
     if (wave < 2) {
@@ -725,7 +766,7 @@ __global__ __launch_bounds__(512, DS_FUSED_WPS) void inception_fused_kernel(cons
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = mt * 32 + rl + (r & 3) + 8 * (r >> 2);
-                    if (row < TRv) gstore(a.Y + (grow0 + row) * 240 + 192 + col, fmaxf(acc[mt][r] + bv, 0.0f));
+                    if (row < TRv) Yg[(unsigned)(row * 240 + 192 + col)] = fmaxf(acc[mt][r] + bv, 0.0f);
                 }
         }
     } else if (TM == 3) {
@@ -734,6 +775,8 @@ __global__ __launch_bounds__(512, DS_FUSED_WPS) void inception_fused_kernel(cons
     } else if (TM == 2) {
         if (wave < 6) unit_b4b((wave - 2) & 1, (wave - 2) >> 1);
     }
+    DS_STAMP(7);
+#undef DS_STAMP
 }
 
 hipError_t launch_inception_fused(int tm, const FusedArgs& a, hipStream_t s)
