@@ -499,33 +499,34 @@ constexpr int F_LD2 = 68;       // T2 row stride: 64 channels + 4 pad
 size_t inception_fused_lds_bytes(int tm, int W, int spt)
 {
     const int tr32 = tm * 32;
-    return (size_t)(4 * tr32 * F_LDA + spt * (W + 4) * F_LD1 + tr32) * sizeof(float);
+    // region A (chunk staging, later the b1|b2 output tile) | T1 | T2 | rowmap
+    return (size_t)(tr32 * F_LD1 + (spt * (W + 4) + 5) * F_LD1 + tr32 * F_LD2 + tr32) * sizeof(float);
+}
+
+// All weights of a conv unit (ntaps x 4 k-groups, <= 20 float4): requested EARLY — before the barrier or
+// the epilogue in front of the unit — so their L2 latency is off the unit's critical path.
+__device__ __forceinline__ void fused_unit_prefetch(const float* __restrict__ Bp, int ntaps, int nt, int lane, float4 (&ub)[20])
+{
+    const float* bsrc = Bp + ((size_t)(nt * ntaps * 4) * 64 + lane) * 4;
+#pragma unroll
+    for (int g = 0; g < 20; ++g)
+        if (g < ntaps * 4) ub[g] = gload4(bsrc + g * 256);
 }
 
 template <int NTAPS>
-__device__ __forceinline__ void fused_conv_unit(const float* T1, int rm, int coloff, int nt, int lane,
-                                                const float* __restrict__ Bp, floatx16& acc)
+__device__ __forceinline__ void fused_conv_unit(const float* T1, int rm, int coloff, int lane, const float4 (&ub)[20], floatx16& acc)
 {
-    // one tap = 32 input channels = 4 k-groups; weights of tap t+1 are prefetched while tap t computes
-    const float* bsrc = Bp + ((size_t)(nt * NTAPS * 4) * 64 + lane) * 4;
     const float* base = T1 + rm * F_LD1 + coloff + (lane >> 5) * 4;
-    float4 b[2][4];
-#pragma unroll
-    for (int g = 0; g < 4; ++g) b[0][g] = gload4(bsrc + g * 256);
 #pragma unroll
     for (int t = 0; t < NTAPS; ++t) {
-        if (t + 1 < NTAPS) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) b[(t + 1) & 1][g] = gload4(bsrc + ((t + 1) * 4 + g) * 256);
-        }
         const float* arow = base + (t - NTAPS / 2) * F_LD1;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const float4 a = *reinterpret_cast<const float4*>(arow + g * 8);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b[t & 1][g].x, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b[t & 1][g].y, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b[t & 1][g].z, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b[t & 1][g].w, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, ub[t * 4 + g].x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, ub[t * 4 + g].y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, ub[t * 4 + g].z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, ub[t * 4 + g].w, acc, 0, 0, 0);
         }
     }
 }
@@ -537,11 +538,12 @@ __global__ __launch_bounds__(512, DS_FUSED_WPS) void inception_fused_kernel(cons
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Ad = smem;                         // [2][TR32*F_LDA] plain rows
     float* Ap = smem + 2 * TR32 * F_LDA;      // [2][TR32*F_LDA] max-pooled rows
-    float* T2 = smem;                         // [TR32*F_LD2], aliases Ad/Ap once P1 is done
-    float* T1 = smem + 4 * TR32 * F_LDA;      // [spt*(W+4)][F_LD1]
+    float* Ys = smem;                         // [TR32][F_LD1] b1|b2 output tile, aliases Ad/Ap once P1 is done
+    float* T1 = smem + TR32 * F_LD1;          // [spt*(W+4)][F_LD1]   (TR32*F_LD1 >= 4*TR32*F_LDA)
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int W = a.W, spt = a.spt, cin = a.cin;
-    int* rowmap = reinterpret_cast<int*>(T1 + spt * (W + 4) * F_LD1);   // [TR32] tile row -> T1 row
+    float* T2 = T1 + (spt * (W + 4) + 5) * F_LD1;   // [TR32*F_LD2]  (T1 has 5 spare rows: a dump row for padding rows + its halo)
+    int* rowmap = reinterpret_cast<int*>(T2 + TR32 * F_LD2);   // [TR32] tile row -> T1 row
     const int site0 = blockIdx.x * spt;
     const int nhere = min(spt, a.n_sites - site0);
     const int TRv = nhere * W;                // valid rows of this tile
@@ -553,11 +555,9 @@ __global__ __launch_bounds__(512, DS_FUSED_WPS) void inception_fused_kernel(cons
     unsigned long long* sdst = a.dbg + ((size_t)blockIdx.x * 2 + (wave == 7)) * 8;
 #define DS_STAMP(i) do { if (stamp) sdst[i] = __builtin_amdgcn_s_memtime(); } while (0)
     DS_STAMP(0);
-    for (int i = tid; i < spt * (W + 4) * F_LD1; i += 512) T1[i] = 0.0f;   // halos (and everything else) = 0
-    if (tid < TR32) {
-        const int r = tid < TRv ? tid : 0;
-        rowmap[tid] = (r / W) * (W + 4) + 2 + r % W;
-    }
+    for (int i = tid; i < (spt * (W + 4) + 5) * F_LD1; i += 512) T1[i] = 0.0f;   // halos (and everything else) = 0
+    if (tid < TR32)   // rows past the tile's last site map to the dump row, so LDS writes need no predicate
+        rowmap[tid] = tid < TRv ? (tid / W) * (W + 4) + 2 + tid % W : spt * (W + 4) + 2;
 
     // ---- P1 staging cursor: thread -> (row, 16-byte slot); rows past the tile end re-read row TRv-1
     const bool stager = tid < TR32 * 4;
@@ -631,6 +631,8 @@ __global__ __launch_bounds__(512, DS_FUSED_WPS) void inception_fused_kernel(cons
         __builtin_amdgcn_sched_barrier(0);                        \
     } while (0)
 
+    const float bias_p1 = (wave * 32 + (lane & 31)) < 240 ? gload(a.bias1 + wave * 32 + (lane & 31)) : 0.0f;
+    const float bias_tail = (wave < 2 && (wave * 32 + (lane & 31)) < 48) ? gload(a.bias5c + wave * 32 + (lane & 31)) : 0.0f;
     const int nchunks = cin / KC;      // >= 15
     load_a(0);
     load_b(0);
@@ -659,81 +661,116 @@ __global__ __launch_bounds__(512, DS_FUSED_WPS) void inception_fused_kernel(cons
     __syncthreads();   // all fragment reads of the staging area are done before T2 aliases it
     DS_STAMP(2);
 
-    // ---- P1 epilogue: route the 256 columns
+    // ---- static wave -> unit assignment of P2 (wave-uniform). kind: 0 none, 1 b5b, 2 b3b, 3 b4b
+    int a1k = 0, a1m = 0, a1n = 0, a2k = 0, a2m = 0, a2n = 0;      // P2a units
+    int b1k = 0, b1m = 0, b1n = 0, b2k = 0, b2m = 0, b2n = 0;      // P2b units (waves 0,1 run the residual tail instead)
+    if (TM == 3) {
+        if (wave < 6) { a1k = 1; a1m = wave % 3; a1n = wave / 3; }
+        else { a1k = 2; a1m = 0; a1n = wave - 6; a2k = 2; a2m = 1; a2n = wave - 6; }
+        if (wave >= 2) { b1k = 3; b1m = (wave - 2) % 3; b1n = (wave - 2) / 3; }
+        if (wave == 2 || wave == 3) { b2k = 2; b2m = 2; b2n = wave - 2; }
+    } else if (TM == 2) {
+        if (wave < 4) { a1k = 1; a1m = wave & 1; a1n = wave >> 1; }
+        else { a1k = 2; a1m = wave & 1; a1n = (wave - 4) >> 1; }
+        if (wave >= 2 && wave < 6) { b1k = 3; b1m = (wave - 2) & 1; b1n = (wave - 2) >> 1; }
+    } else {
+        if (wave < 2) { a1k = 1; a1n = wave; }
+        else if (wave < 4) { a1k = 2; a1n = wave - 2; }
+        else if (wave < 6) { a1k = 3; a1n = wave - 4; }
+    }
+    auto unit_Bp = [&](int k) { return k == 1 ? a.Bp5b : k == 2 ? a.Bp3b : a.Bp4b; };
+    auto unit_taps = [&](int k) { return k == 3 ? 5 : 3; };
+    auto unit_bias = [&](int k, int nt) -> float {
+        const int col = nt * 32 + (lane & 31);
+        if (k == 1) return gload(a.bias5b + col);
+        if (k == 0 || col >= 48) return 0.0f;
+        return gload((k == 2 ? a.bias3b : a.bias4b) + col);
+    };
+    // every bias this wave will need, requested now (off the critical path of the unit epilogues)
+    const float ba1 = unit_bias(a1k, a1n), ba2 = unit_bias(a2k, a2n), bb1 = unit_bias(b1k, b1n), bb2 = unit_bias(b2k, b2n);
+    float4 pf[20];                                   // prefetched weights of the next unit
+    if (a1k) fused_unit_prefetch(unit_Bp(a1k), unit_taps(a1k), a1n, lane, pf);
+
+    // ---- P1 epilogue: route the 256 columns. b1|b2 go through an LDS tile and leave as whole
+    // 384-B row segments (16-B stores) instead of 48 scalar stores per lane.
     const int rl = 4 * (lane >> 5);
-    {
+    if (wave >= 3 && wave <= 5) {            // wave-uniform: n-tiles 3,4,5 = b3a | b4a | b5a -> T1
+        const int c = wave * 32 + (lane & 31) - 96;
+        int rmv[TM][16];
+#pragma unroll
+        for (int mt = 0; mt < TM; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) rmv[mt][r] = rowmap[mt * 32 + rl + (r & 3) + 8 * (r >> 2)];
+#pragma unroll
+        for (int mt = 0; mt < TM; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) T1[rmv[mt][r] * F_LD1 + c] = fmaxf(acc[mt][r] + bias_p1, 0.0f);
+    } else if (wave != 0) {                  // n-tiles 1,2 (b5s tail | b2) and 6,7 (b1 | padding) -> output tile
         const int col = wave * 32 + (lane & 31);
-        const float bias = col < 240 ? gload(a.bias1 + col) : 0.0f;
+        const int ycol = col < 96 ? col : col - 192;        // position inside Y[:, 0:96) (b1 first, then b2)
         if (col >= 48 && col < 240) {
 #pragma unroll
             for (int mt = 0; mt < TM; ++mt)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = mt * 32 + rl + (r & 3) + 8 * (r >> 2);
-                    if (row < TRv) {
-                        const float v = fmaxf(acc[mt][r] + bias, 0.0f);
-                        if (col < 96) Yg[(unsigned)(row * 240 + col)] = v;                        // branch 2 -> [48,96)
-                        else if (col < 192) T1[rowmap[row] * F_LD1 + (col - 96)] = v;             // b3a | b4a | b5a
-                        else Yg[(unsigned)(row * 240 + col - 192)] = v;                           // branch 1 -> [0,48)
-                    }
-                }
+                for (int r = 0; r < 16; ++r)
+                    Ys[(mt * 32 + rl + (r & 3) + 8 * (r >> 2)) * F_LD1 + ycol] = fmaxf(acc[mt][r] + bias_p1, 0.0f);
         }
     }
     DS_STAMP(3);
-    __syncthreads();   // T1 complete; Ad/Ap dead -> T2 may be written
+    __syncthreads();   // T1 and the b1|b2 tile complete
     DS_STAMP(4);
+    for (int idx = tid; idx < TR32 * 24; idx += 512) {
+        const int row = idx / 24, q = idx - row * 24;
+        if (row < TRv) {
+            const float4 v = *reinterpret_cast<const float4*>(Ys + row * F_LD1 + q * 4);
+            v4f o = {v.x, v.y, v.z, v.w};
+            *(__attribute__((address_space(1))) v4f*)(Yg + (unsigned)(row * 240 + q * 4)) = o;
+        }
+    }
 
     const int rm_of = lane & 31;
-    auto store_unit_global = [&](const floatx16& u, int mt, int nt, const float* bias, int ybase) {
+    auto run_unit = [&](int kind, int mt, int nt, float bv) {
+        floatx16 u;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) u[r] = 0.0f;
+        const int rm = rowmap[mt * 32 + rm_of];
         const int col = nt * 32 + (lane & 31);
-        if (col < 48) {
-            const float bv = gload(bias + col);
+        if (kind == 1) {          // 1x3, 32 -> 64, ReLU, to T2                            layers.py:127-131
+            fused_conv_unit<3>(T1, rm, 64, lane, pf, u);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = mt * 32 + rl + (r & 3) + 8 * (r >> 2);
-                if (row < TRv) Yg[(unsigned)(row * 240 + ybase + col)] = fmaxf(u[r] + bv, 0.0f);
+                T2[row * F_LD2 + col] = fmaxf(u[r] + bv, 0.0f);
+            }
+        } else {
+            // kind 2: 1x3, 32 -> 48, ReLU, to Y[96,144)   layers.py:106-110
+            // kind 3: 1x5, 32 -> 48, ReLU, to Y[144,192)  layers.py:115-119
+            if (kind == 2) fused_conv_unit<3>(T1, rm, 0, lane, pf, u);
+            else fused_conv_unit<5>(T1, rm, 32, lane, pf, u);
+            if (col < 48) {
+                const int ybase = kind == 2 ? 96 : 144;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = mt * 32 + rl + (r & 3) + 8 * (r >> 2);
+                    if (row < TRv) Yg[(unsigned)(row * 240 + ybase + col)] = fmaxf(u[r] + bv, 0.0f);
+                }
             }
         }
     };
-    auto unit_b5b = [&](int mt, int nt) {        // 1x3, 32 -> 64, ReLU, to T2             layers.py:127-131
-        floatx16 u;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) u[r] = 0.0f;
-        fused_conv_unit<3>(T1, rowmap[mt * 32 + rm_of], 64, nt, lane, a.Bp5b, u);
-        const int col = nt * 32 + (lane & 31);
-        const float bv = gload(a.bias5b + col);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = mt * 32 + rl + (r & 3) + 8 * (r >> 2);
-            T2[row * F_LD2 + col] = fmaxf(u[r] + bv, 0.0f);
-        }
-    };
-    auto unit_b3b = [&](int mt, int nt) {        // 1x3, 32 -> 48, ReLU, to Y[96,144)       layers.py:106-110
-        floatx16 u;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) u[r] = 0.0f;
-        fused_conv_unit<3>(T1, rowmap[mt * 32 + rm_of], 0, nt, lane, a.Bp3b, u);
-        store_unit_global(u, mt, nt, a.bias3b, 96);
-    };
-    auto unit_b4b = [&](int mt, int nt) {        // 1x5, 32 -> 48, ReLU, to Y[144,192)      layers.py:115-119
-        floatx16 u;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) u[r] = 0.0f;
-        fused_conv_unit<5>(T1, rowmap[mt * 32 + rm_of], 32, nt, lane, a.Bp4b, u);
-        store_unit_global(u, mt, nt, a.bias4b, 144);
-    };
 
-    // ---- P2a (static wave -> unit assignment; wave-uniform branches)
-    if (TM == 3) {
-        if (wave < 6) unit_b5b(wave % 3, wave / 3);
-        else { unit_b3b(0, wave - 6); unit_b3b(1, wave - 6); }
-    } else if (TM == 2) {
-        if (wave < 4) unit_b5b(wave & 1, wave >> 1);
-        else unit_b3b(wave & 1, (wave - 4) >> 1);
-    } else {
-        if (wave < 2) unit_b5b(0, wave);
-        else if (wave < 4) unit_b3b(0, wave - 2);
-        else if (wave < 6) unit_b4b(0, wave - 4);
+    // ---- P2a
+    if (a1k) run_unit(a1k, a1m, a1n, ba1);
+    if (a2k) {
+        fused_unit_prefetch(unit_Bp(a2k), unit_taps(a2k), a2n, lane, pf);
+        run_unit(a2k, a2m, a2n, ba2);
+    }
+    // weights of the first P2b job are requested before the barrier
+    float4 b5c[8];
+    if (wave < 2) {
+#pragma unroll
+        for (int g = 0; g < 8; ++g) b5c[g] = gload4(a.Bp5c + ((size_t)(wave * 8 + g) * 64 + lane) * 4);
+    } else if (b1k) {
+        fused_unit_prefetch(unit_Bp(b1k), unit_taps(b1k), b1n, lane, pf);
     }
     DS_STAMP(5);
     __syncthreads();   // T2 complete
@@ -743,24 +780,21 @@ __global__ __launch_bounds__(512, DS_FUSED_WPS) void inception_fused_kernel(cons
     if (wave < 2) {
         // branch 5 tail: 1x1 64 -> 48 (BN, no ReLU) accumulated on top of the stem conv held in acc,
         // then relu(stem + tail)                                                         layers.py:132-138
-        float4 b[8];
-#pragma unroll
-        for (int g = 0; g < 8; ++g) b[g] = gload4(a.Bp5c + ((size_t)(wave * 8 + g) * 64 + lane) * 4);
 #pragma unroll
         for (int mt = 0; mt < TM; ++mt) {
             const float* base = T2 + (mt * 32 + (lane & 31)) * F_LD2 + (lane >> 5) * 4;
 #pragma unroll
             for (int g = 0; g < 8; ++g) {
                 const float4 av = *reinterpret_cast<const float4*>(base + g * 8);
-                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, b[g].x, acc[mt], 0, 0, 0);
-                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, b[g].y, acc[mt], 0, 0, 0);
-                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, b[g].z, acc[mt], 0, 0, 0);
-                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, b[g].w, acc[mt], 0, 0, 0);
+                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, b5c[g].x, acc[mt], 0, 0, 0);
+                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, b5c[g].y, acc[mt], 0, 0, 0);
+                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, b5c[g].z, acc[mt], 0, 0, 0);
+                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, b5c[g].w, acc[mt], 0, 0, 0);
             }
         }
         const int col = wave * 32 + (lane & 31);
         if (col < 48) {
-            const float bv = gload(a.bias1 + col) + gload(a.bias5c + col);
+            const float bv = bias_p1 + bias_tail;
 #pragma unroll
             for (int mt = 0; mt < TM; ++mt)
 #pragma unroll
@@ -769,11 +803,12 @@ __global__ __launch_bounds__(512, DS_FUSED_WPS) void inception_fused_kernel(cons
                     if (row < TRv) Yg[(unsigned)(row * 240 + 192 + col)] = fmaxf(acc[mt][r] + bv, 0.0f);
                 }
         }
-    } else if (TM == 3) {
-        unit_b4b((wave - 2) % 3, (wave - 2) / 3);
-        if (wave < 4) unit_b3b(2, wave - 2);
-    } else if (TM == 2) {
-        if (wave < 6) unit_b4b((wave - 2) & 1, (wave - 2) >> 1);
+    } else {
+        if (b1k) run_unit(b1k, b1m, b1n, bb1);
+        if (b2k) {
+            fused_unit_prefetch(unit_Bp(b2k), unit_taps(b2k), b2n, lane, pf);
+            run_unit(b2k, b2m, b2n, bb2);
+        }
     }
     DS_STAMP(7);
 #undef DS_STAMP
