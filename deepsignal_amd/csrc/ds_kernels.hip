@@ -531,14 +531,16 @@ __device__ __forceinline__ void fused_conv_unit(const float* T1, int rm, int col
     }
 }
 
+struct FusedTagT { static constexpr bool value = true; };
+struct FusedTagF { static constexpr bool value = false; };
+
 template <int TM>
 __global__ __launch_bounds__(512, DS_FUSED_WPS) void inception_fused_kernel(const FusedArgs a)
 {
     constexpr int TR32 = TM * 32;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* Ad = smem;                         // [2][TR32*F_LDA] plain rows
-    float* Ap = smem + 2 * TR32 * F_LDA;      // [2][TR32*F_LDA] max-pooled rows
-    float* Ys = smem;                         // [TR32][F_LD1] b1|b2 output tile, aliases Ad/Ap once P1 is done
+    float* Ad = smem;                         // [2][TR32*F_LDA] staged input rows
+    float* Ys = smem;                         // [TR32][F_LD1] b1|b2 output tile, aliases Ad once P1 is done
     float* T1 = smem + TR32 * F_LD1;          // [spt*(W+4)][F_LD1]   (TR32*F_LD1 >= 4*TR32*F_LDA)
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int W = a.W, spt = a.spt, cin = a.cin;
@@ -563,10 +565,7 @@ __global__ __launch_bounds__(512, DS_FUSED_WPS) void inception_fused_kernel(cons
     const bool stager = tid < TR32 * 4;
     const int sr = tid >> 2, sq = tid & 3;
     const int rr = sr < TRv ? sr : TRv - 1;
-    const int sw = rr % W;
     const float* pc = a.X + (grow0 + rr) * cin + sq * 4;
-    const float* pm = sw > 0 ? pc - cin : pc;          // maxpool(3, s1, SAME): padded taps ignored
-    const float* pp = sw < W - 1 ? pc + cin : pc;
     const float* bp = a.Bp1 + ((size_t)wave * ((cin + 31) / 32 * 4) * 64 + lane) * 4;   // K padded to 32 in the pack
 
     floatx16 acc[TM];
@@ -575,46 +574,60 @@ __global__ __launch_bounds__(512, DS_FUSED_WPS) void inception_fused_kernel(cons
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[mt][r] = 0.0f;
 
+    // branch 1's maxpool(3, stride 1, SAME): waves 6,7 build their A fragments as the max of three staged
+    // rows (previous / own / next; at a site edge the missing neighbour is the own row = "padded taps
+    // ignored"), so the input is read from HBM once and staged once.
+    int offm[TM], offp[TM];
+#pragma unroll
+    for (int mt = 0; mt < TM; ++mt) {
+        const int row = mt * 32 + (lane & 31);
+        const int w = row % W;
+        offm[mt] = (row < TRv && w > 0) ? -F_LDA : 0;
+        offp[mt] = (row < TRv && w < W - 1) ? F_LDA : 0;
+    }
+
+    const float bias_p1 = (wave * 32 + (lane & 31)) < 240 ? gload(a.bias1 + wave * 32 + (lane & 31)) : 0.0f;
+    const float bias_tail = (wave < 2 && (wave * 32 + (lane & 31)) < 48) ? gload(a.bias5c + wave * 32 + (lane & 31)) : 0.0f;
+    const int nchunks = cin / KC;      // >= 15
+
     // P1 main loop: same software pipeline as gemm_kernel (fragments of chunk c+1 are read into
     // registers behind the second half of chunk c's MFMAs; one barrier per chunk).
-    float4 vc[2], vm[2], vp[2];
-    float4 bq[2][2];
-    float4 af[2][2][TM];
-    auto load_a = [&](int X) {
-        if (stager) {
-            vc[X] = gload4(pc); vm[X] = gload4(pm); vp[X] = gload4(pp);
-            pc += KC; pm += KC; pp += KC;
-        }
-    };
-    auto store_a = [&](int X) {
-        if (stager) {
-            *reinterpret_cast<float4*>(Ad + X * TR32 * F_LDA + sr * F_LDA + sq * 4) = vc[X];
-            *reinterpret_cast<float4*>(Ap + X * TR32 * F_LDA + sr * F_LDA + sq * 4) = f4max(f4max(vc[X], vm[X]), vp[X]);
-        }
-    };
-    auto load_b = [&](int X) {
-        bq[X][0] = gload4(bp);
-        bq[X][1] = gload4(bp + 256);
-        bp += 512;
-    };
-    const float* asrc = wave < 6 ? Ad : Ap;    // n-tiles 6,7 are branch 1 (pooled input)
-    auto read_frags = [&](int X) {
+    auto run_p1 = [&](auto pool_tag) {
+        constexpr bool POOL = decltype(pool_tag)::value;
+        float4 vc[2];
+        float4 bq[2][2];
+        float4 af[2][2][TM];
+        auto load_a = [&](int X) {
+            if (stager) { vc[X] = gload4(pc); pc += KC; }
+        };
+        auto store_a = [&](int X) {
+            if (stager) *reinterpret_cast<float4*>(Ad + X * TR32 * F_LDA + sr * F_LDA + sq * 4) = vc[X];
+        };
+        auto load_b = [&](int X) {
+            bq[X][0] = gload4(bp);
+            bq[X][1] = gload4(bp + 256);
+            bp += 512;
+        };
+        auto read_frags = [&](int X) {
 #pragma unroll
-        for (int rs = 0; rs < 2; ++rs)
+            for (int rs = 0; rs < 2; ++rs)
 #pragma unroll
-            for (int mt = 0; mt < TM; ++mt)
-                af[X][rs][mt] = *reinterpret_cast<const float4*>(asrc + X * TR32 * F_LDA + (mt * 32 + (lane & 31)) * F_LDA +
-                                                                 rs * 8 + (lane >> 5) * 4);
-    };
-    auto mfma_rs = [&](int X, int rs) {
+                for (int mt = 0; mt < TM; ++mt) {
+                    const float* q = Ad + X * TR32 * F_LDA + (mt * 32 + (lane & 31)) * F_LDA + rs * 8 + (lane >> 5) * 4;
+                    float4 v = *reinterpret_cast<const float4*>(q);
+                    if (POOL) v = f4max(f4max(v, *reinterpret_cast<const float4*>(q + offm[mt])), *reinterpret_cast<const float4*>(q + offp[mt]));
+                    af[X][rs][mt] = v;
+                }
+        };
+        auto mfma_rs = [&](int X, int rs) {
 #pragma unroll
-        for (int mt = 0; mt < TM; ++mt) {
-            acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[X][rs][mt].x, bq[X][rs].x, acc[mt], 0, 0, 0);
-            acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[X][rs][mt].y, bq[X][rs].y, acc[mt], 0, 0, 0);
-            acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[X][rs][mt].z, bq[X][rs].z, acc[mt], 0, 0, 0);
-            acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[X][rs][mt].w, bq[X][rs].w, acc[mt], 0, 0, 0);
-        }
-    };
+            for (int mt = 0; mt < TM; ++mt) {
+                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[X][rs][mt].x, bq[X][rs].x, acc[mt], 0, 0, 0);
+                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[X][rs][mt].y, bq[X][rs].y, acc[mt], 0, 0, 0);
+                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[X][rs][mt].z, bq[X][rs].z, acc[mt], 0, 0, 0);
+                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[X][rs][mt].w, bq[X][rs].w, acc[mt], 0, 0, 0);
+            }
+        };
 #define DS_FSTEP(X, HAS1, HAS2)                                   \
     do {                                                          \
         if (HAS2) load_a(X);                                      \
@@ -626,37 +639,35 @@ __global__ __launch_bounds__(512, DS_FUSED_WPS) void inception_fused_kernel(cons
         if (HAS1) read_frags((X) ^ 1);                            \
         mfma_rs(X, 1);                                            \
         __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);          \
-        if (HAS1) __builtin_amdgcn_sched_group_barrier(0x100, 2 * TM, 0); \
+        if (HAS1) __builtin_amdgcn_sched_group_barrier(0x100, (POOL ? 6 : 2) * TM, 0); \
         __builtin_amdgcn_sched_group_barrier(0x8, 4 * TM, 0);     \
         __builtin_amdgcn_sched_barrier(0);                        \
     } while (0)
-
-    const float bias_p1 = (wave * 32 + (lane & 31)) < 240 ? gload(a.bias1 + wave * 32 + (lane & 31)) : 0.0f;
-    const float bias_tail = (wave < 2 && (wave * 32 + (lane & 31)) < 48) ? gload(a.bias5c + wave * 32 + (lane & 31)) : 0.0f;
-    const int nchunks = cin / KC;      // >= 15
-    load_a(0);
-    load_b(0);
-    store_a(0);
-    load_a(1);
-    __syncthreads();
-    read_frags(0);
-    int c = 0;
-    while (c + 3 < nchunks) {
-        DS_FSTEP(0, true, true);
-        DS_FSTEP(1, true, true);
-        c += 2;
-    }
-    if (nchunks - c == 3) {
-        DS_FSTEP(0, true, true);
-        DS_FSTEP(1, true, false);
-        DS_FSTEP(0, false, false);
-    } else if (nchunks - c == 2) {
-        DS_FSTEP(0, true, false);
-        DS_FSTEP(1, false, false);
-    } else {
-        DS_FSTEP(0, false, false);
-    }
+        load_a(0);
+        load_b(0);
+        store_a(0);
+        load_a(1);
+        __syncthreads();
+        read_frags(0);
+        int c = 0;
+        while (c + 3 < nchunks) {
+            DS_FSTEP(0, true, true);
+            DS_FSTEP(1, true, true);
+            c += 2;
+        }
+        if (nchunks - c == 3) {
+            DS_FSTEP(0, true, true);
+            DS_FSTEP(1, true, false);
+            DS_FSTEP(0, false, false);
+        } else if (nchunks - c == 2) {
+            DS_FSTEP(0, true, false);
+            DS_FSTEP(1, false, false);
+        } else {
+            DS_FSTEP(0, false, false);
+        }
 #undef DS_FSTEP
+    };
+    if (wave >= 6) run_p1(FusedTagT{}); else run_p1(FusedTagF{});     // wave-uniform
     DS_STAMP(1);
     __syncthreads();   // all fragment reads of the staging area are done before T2 aliases it
     DS_STAMP(2);
