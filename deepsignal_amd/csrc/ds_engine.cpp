@@ -61,6 +61,8 @@ struct Op {
     double flops = 0;                     // algorithmic FLOPs of this launch
     hipEvent_t ev0 = nullptr, ev1 = nullptr;   // profiling mode only
     bool pending = false;
+    int run_launches = 0;                 // profiling mode 1: launches / FLOPs bracketed by this op's event pair
+    double run_flops = 0;
 };
 
 // per-kernel accumulators (one entry per __global__ function / template instantiation)
@@ -104,7 +106,7 @@ struct ds_handle {
     int B = 512;
     bool finalized = false;
     bool debug = false;
-    bool profiling = false;
+    int profiling = 0;    // 0 off | 1 one event pair per run of same-kernel launches on a stream | 2 per launch
     bool use_graph = true;
     hipStream_t s0 = nullptr, s1 = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -675,34 +677,59 @@ int issue_op(ds_handle* h, Plan& plan, const Op& op, hipStream_t s)
 
 // Enqueue the whole forward on (s0, s1): fork after the inputs are in place, join before fc1.
 // timed: bracket every launch with its own HIP event pair on the stream it is launched on.
-int enqueue_forward(ds_handle* h, Plan& plan, bool timed)
+int kernel_class(const Op& op);
+
+int enqueue_forward(ds_handle* h, Plan& plan, int timed)
 {
     HIPCHK(h, hipEventRecord(h->ev_fork, h->s0));
     HIPCHK(h, hipStreamWaitEvent(h->s1, h->ev_fork, 0));
     bool joined = false;
     static const bool serial = getenv("DS_SERIAL") != nullptr;   // diagnostic: one stream, no overlap
+    Op* head[2] = {nullptr, nullptr};       // open run per stream (timed == 1)
+    auto close_run = [&](int si) -> int {
+        if (head[si]) {
+            HIPCHK(h, hipEventRecord(head[si]->ev1, si == 0 ? h->s0 : h->s1));
+            head[si]->pending = true;
+            head[si] = nullptr;
+        }
+        return DS_OK;
+    };
     for (Op& op : plan.ops) {
-        hipStream_t s = (op.stream == 0 || serial) ? h->s0 : h->s1;
+        const int si = (op.stream == 0 || serial) ? 0 : 1;
+        hipStream_t s = si == 0 ? h->s0 : h->s1;
         const bool is_tail = h->stages[op.stage].name == "fc1" || h->stages[op.stage].name == "head";
         if (is_tail && !joined) {
+            int rc = close_run(0); if (rc) return rc;
+            rc = close_run(1); if (rc) return rc;
             HIPCHK(h, hipEventRecord(h->ev_join, h->s1));
             HIPCHK(h, hipStreamWaitEvent(h->s0, h->ev_join, 0));
             joined = true;
         }
-        if (timed) {
-            if (!op.ev0) {
-                HIPCHK(h, hipEventCreate(&op.ev0));
-                HIPCHK(h, hipEventCreate(&op.ev1));
-            }
+        if (timed && !op.ev0) {
+            HIPCHK(h, hipEventCreate(&op.ev0));
+            HIPCHK(h, hipEventCreate(&op.ev1));
+        }
+        if (timed == 2) {
             HIPCHK(h, hipEventRecord(op.ev0, s));
+            op.run_launches = 1; op.run_flops = op.flops;
+        } else if (timed == 1) {
+            if (head[si] && kernel_class(*head[si]) != kernel_class(op)) { int rc = close_run(si); if (rc) return rc; }
+            if (!head[si]) {
+                head[si] = &op;
+                op.run_launches = 0; op.run_flops = 0;
+                HIPCHK(h, hipEventRecord(op.ev0, s));
+            }
+            head[si]->run_launches += 1;
+            head[si]->run_flops += op.flops;
         }
         int rc = issue_op(h, plan, op, s);
         if (rc) return rc;
-        if (timed) {
+        if (timed == 2) {
             HIPCHK(h, hipEventRecord(op.ev1, s));
             op.pending = true;
         }
     }
+    { int rc = close_run(0); if (rc) return rc; rc = close_run(1); if (rc) return rc; }
     if (!joined) {
         HIPCHK(h, hipEventRecord(h->ev_join, h->s1));
         HIPCHK(h, hipStreamWaitEvent(h->s0, h->ev_join, 0));
@@ -734,9 +761,9 @@ int collect_stage_times(ds_handle* h)
             HIPCHK(h, hipEventSynchronize(op.ev1));
             float ms = 0;
             HIPCHK(h, hipEventElapsedTime(&ms, op.ev0, op.ev1));
-            h->stages[op.stage].total_ms += ms;
+            h->stages[op.stage].total_ms += ms;     // per-stage times are only meaningful in mode 2
             KernelStat& K = h->kstat[kernel_class(op)];
-            K.launches += 1; K.total_ms += ms; K.flops += op.flops;
+            K.launches += op.run_launches; K.total_ms += ms; K.flops += op.run_flops;
             op.pending = false;
         }
     return DS_OK;
@@ -765,7 +792,7 @@ int run_resident(ds_handle* h, int n)
     if (h->profiling) {
         rc = collect_stage_times(h);      // events of a previous profiled forward are reused below
         if (rc) return rc;
-        rc = enqueue_forward(h, *plan, true);
+        rc = enqueue_forward(h, *plan, h->profiling);
         if (rc) return rc;
         for (Stage& S : h->stages) S.calls += 1;
         return DS_OK;
@@ -774,7 +801,7 @@ int run_resident(ds_handle* h, int n)
         if (!plan->graph) {
             hipGraph_t g = nullptr;
             HIPCHK(h, hipStreamBeginCapture(h->s0, hipStreamCaptureModeThreadLocal));
-            rc = enqueue_forward(h, *plan, false);
+            rc = enqueue_forward(h, *plan, 0);
             hipError_t e = hipStreamEndCapture(h->s0, &g);
             if (rc) { if (g) hipGraphDestroy(g); return rc; }
             if (e != hipSuccess) return fail(h, DS_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
@@ -785,7 +812,7 @@ int run_resident(ds_handle* h, int n)
         HIPCHK(h, hipGraphLaunch(plan->graph, h->s0));
         return DS_OK;
     }
-    return enqueue_forward(h, *plan, false);
+    return enqueue_forward(h, *plan, 0);
 }
 
 }  // namespace
@@ -1061,7 +1088,7 @@ int ds_set_profiling(ds_handle* h, int32_t enable)
 {
     if (!h) return DS_ERR_INVALID;
     int rc = ds_sync(h);
-    h->profiling = enable != 0;
+    h->profiling = enable < 0 ? 0 : (enable > 2 ? 2 : enable);
     return rc;
 }
 

@@ -164,8 +164,10 @@ class Engine:
             raise RuntimeError("intermediate %s: expected %d floats, got %d" % (name, out.size, got))
         return out
 
-    def set_profiling(self, enable: bool) -> None:
-        self._check(self._lib.ds_set_profiling(self._h, int(enable)), "ds_set_profiling")
+    def set_profiling(self, mode) -> None:
+        """0/False off, 1 per-kernel runs, 2/True per launch (see include/deepsignal_hip.h)."""
+        mode = 2 if mode is True else int(mode)
+        self._check(self._lib.ds_set_profiling(self._h, mode), "ds_set_profiling")
 
     def set_graph(self, enable: bool) -> None:
         self._check(self._lib.ds_set_graph(self._h, int(enable)), "ds_set_graph")

@@ -85,11 +85,14 @@ int ds_free_host(void *p);
  * or a negative error. */
 int64_t ds_get_intermediate(ds_handle *h, const char *name, float *out, int64_t capacity);
 
-/* Stage timing (HIP events on the engine's own streams). enable!=0 records an event pair around
- * every stage of each subsequent forward; ds_get_stage_times then reports, for stage index i,
- * its name, the number of kernel launches it covers, and the accumulated device milliseconds and
- * call count since the last reset. Returns the number of stages. */
-int ds_set_profiling(ds_handle *h, int32_t enable);
+/* Timing with HIP events on the engine's own streams (forwards run eagerly while it is on).
+ *   mode 1: one event pair around every RUN of consecutive launches of the same kernel on a stream
+ *           (per-kernel statistics with negligible bracketing overhead; inter-launch gaps included);
+ *   mode 2: one event pair per launch (per-stage breakdown; ~10 us of bracketing per launch);
+ *   mode 0: off.
+ * ds_get_stage reports, for stage index i, its name, launches per forward, accumulated device
+ * milliseconds (mode 2) and forward count since the last reset. */
+int ds_set_profiling(ds_handle *h, int32_t mode);
 int ds_num_stages(ds_handle *h);
 int ds_get_stage(ds_handle *h, int32_t index, char *name, int32_t name_cap, int32_t *launches,
                  double *total_ms, int64_t *calls, double *flops_per_site);
