@@ -1,0 +1,63 @@
+"""GPU: BASELINE.json configs[0] — the whole `deepsignal call_mods` plumbing on 1,000 pre-extracted
+synthetic feature rows (k=17, sig=360, 20 rows x 50 reads), batch_size 32: feature TSV -> reader ->
+batcher -> HIP engine (weights from a DSAMDW01 file) -> writer, diffed numerically against the same
+harness driven by the CPU oracle. Row order, grouping by read and the 10-column contract are exact;
+probabilities within 1e-5 (north-star gate 1e-4)."""
+import numpy as np
+import pytest
+
+from deepsignal_amd import synth, weights as W
+from deepsignal_amd.utils.process_utils import code2base_dna
+
+pytestmark = pytest.mark.gpu
+
+
+def _write_feature_tsv(path, feats, reads):
+    with open(path, "w") as f:
+        for i in range(len(reads)):
+            kmer = "".join(code2base_dna[int(c)] for c in feats["kmer"][i])
+            cols = ["chr%d" % (1 + i % 5), str(100 + i), "+-"[i % 2], str(9000 - i), reads[i], "tc"[i % 2], kmer,
+                    ",".join("%s" % np.float32(x) for x in feats["means"][i]),
+                    ",".join("%s" % np.float32(x) for x in feats["stds"][i]),
+                    ",".join(str(int(x)) for x in feats["sanums"][i]),
+                    ",".join("%s" % np.float32(x) for x in feats["signals"][i]),
+                    str(int(feats["labels"][i]))]
+            f.write("\t".join(cols) + "\n")
+
+
+class OracleEngine:
+    def __init__(self, weights):
+        self.w = weights
+
+    def run(self, kmer, means, stds, sanums, signals):
+        from oracle import oracle
+        feats = {"kmer": np.asarray(kmer, np.int32), "means": np.asarray(means, np.float32),
+                 "stds": np.asarray(stds, np.float32), "sanums": np.asarray(sanums, np.float32),
+                 "signals": np.asarray(signals, np.float32)}
+        return oracle.forward(self.w, feats, "f32")
+
+
+def test_call_mods_cli_1k_rows_batch32(small_weights, tmp_path):
+    from deepsignal_amd import call_modifications as cm
+    from deepsignal_amd.deepsignal import main
+    n = 1000
+    feats = synth.synthetic_features(n, seed=321)
+    reads = ["read_%04d" % (i // 20) for i in range(n)]
+    tsv, wfile = str(tmp_path / "features.tsv"), str(tmp_path / "model.dsw")
+    out_gpu, out_cpu = str(tmp_path / "gpu.tsv"), str(tmp_path / "cpu.tsv")
+    _write_feature_tsv(tsv, feats, reads)
+    W.save_weights(wfile, small_weights)
+    assert main(["call_mods", "-i", tsv, "-m", wfile, "-o", out_gpu, "-b", "32", "--nproc", "1", "--is_gpu", "yes"]) == 0
+    cm.call_mods(tsv, wfile, out_cpu, 17, 360, 32, 0.001, 2, 1, False, True, True, True, (50,),
+                 engine=OracleEngine(small_weights))
+    g = [l.rstrip("\n").split("\t") for l in open(out_gpu)]
+    c = [l.rstrip("\n").split("\t") for l in open(out_cpu)]
+    assert len(g) == len(c) == n
+    for rg, rc in zip(g, c):
+        assert len(rg) == 10 and rg[:6] == rc[:6] and rg[9] == rc[9]          # sample info + k-mer text, same order
+        p0, p1 = float(rg[6]), float(rg[7])
+        assert abs(p0 - float(rc[6])) <= 1e-5 and abs(p1 - float(rc[7])) <= 1e-5
+        assert abs(p0 + p1 - 1.0) <= 1e-6
+        if abs(float(rc[7]) - float(rc[6])) > 1e-3:
+            assert rg[8] == rc[8]
+    assert [r[4] for r in g] == reads                                          # reads stay contiguous and ordered
