@@ -104,6 +104,7 @@ struct ds_handle {
     int w1 = 0, wa = 0, wb = 0, wc = 0, J = 0, SF = 0;
     int pl_conv1 = 0, pl_pool1 = 0, pl_pool2 = 0, pl_pool3 = 0;
     int B = 512;
+    bool is_cnn = true, is_rnn = true, is_base = true;   // model.py:28-29,59-75,89-95
     bool finalized = false;
     bool debug = false;
     int profiling = 0;    // 0 off | 1 one event pair per run of same-kernel launches on a stream | 2 per launch
@@ -271,9 +272,10 @@ std::string mod_root(int n)
 
 int finalize_weights(ds_handle* h)
 {
+    int rc;
+    if (h->is_cnn) {
     // ---- stem (layers.py:183-203) ----
     FoldedConv c1, c2, c3;
-    int rc;
     if ((rc = fold_conv(h, "modelsignalmconv_layer1", "conv", "bn", 7, 1, 64, &c1))) return rc;
     if ((rc = fold_conv(h, "modelsignalmconv_layer2", "conv", "bn", 1, 64, 128, &c2))) return rc;
     if ((rc = fold_conv(h, "modelsignalmconv_layer3", "conv", "bn", 3, 128, 256, &c3))) return rc;
@@ -305,11 +307,16 @@ int finalize_weights(ds_handle* h)
         if ((rc = upload_concat(h, {&b5b}, &h->m_b5b[m]))) return rc;
         if ((rc = upload_concat(h, {&b5c}, &h->m_b5c[m]))) return rc;
     }
+    }
+    if (h->is_rnn) {
     // ---- BiLSTM (layers.py:45-72; TF LSTMCell kernel rows = [input ; h], columns = [i j f o]) ----
-    const HostTensor* emb = find(h, "modelembedding");
-    if (!emb || (int64_t)emb->data.size() != (int64_t)VOCAB * EMB) return fail(h, DS_ERR_INVALID, "missing modelembedding");
     float* d_emb = nullptr;
-    if ((rc = upload(h, &d_emb, emb->data))) return rc;
+    if (h->is_base) {
+        const HostTensor* emb = find(h, "modelembedding");
+        if (!emb || (int64_t)emb->data.size() != (int64_t)VOCAB * EMB) return fail(h, DS_ERR_INVALID, "missing modelembedding");
+        if ((rc = upload(h, &d_emb, emb->data))) return rc;
+    }
+    const int in0 = h->is_base ? EMB + 3 : 3;      // layer-0 input width (model.py:63-75)
     const char* dirs[2] = {"fw", "bw"};
     for (int d = 0; d < 2; ++d)
         for (int l = 0; l < NLAYER; ++l) {
@@ -318,12 +325,12 @@ int finalize_weights(ds_handle* h)
             const HostTensor* ker = find(h, nm);
             snprintf(nm, sizeof nm, "modelem/%s/multi_rnn_cell/cell_%d/lstm_cell/bias", dirs[d], l);
             const HostTensor* bias = find(h, nm);
-            const int in = l == 0 ? EMB + 3 : HID;
+            const int in = l == 0 ? in0 : HID;
             if (!ker || !bias || (int64_t)ker->data.size() != (int64_t)(in + HID) * 4 * HID || bias->data.size() != 4 * HID)
                 return fail(h, DS_ERR_INVALID, std::string("missing/bad LSTM tensor ") + nm);
             const float* kd = ker->data.data();
             // rows fed through the MFMA GEMM: layer 0 -> only the h rows (x part is table + 3 rank-1 terms)
-            const int row0 = l == 0 ? EMB + 3 : 0;
+            const int row0 = l == 0 ? in0 : 0;
             const int K = l == 0 ? HID : 2 * HID;
             // packed n-tile p = ug*4 + g  <->  TF columns g*256 + ug*32 + [0,32)
             std::vector<float> packed = pack_b(K, 4 * HID, [&](int k, int pc) {
@@ -334,16 +341,19 @@ int finalize_weights(ds_handle* h)
             if ((rc = upload(h, &h->lstm[d][l].Bp, packed))) return rc;
             if ((rc = upload(h, &h->lstm[d][l].bias, bias->data))) return rc;
             if (l == 0) {
-                // embedding folded into W_x: table[v] = emb[v] @ kernel[0:128]   (model.py:61-69)
-                float* d_k0 = nullptr;
-                std::vector<float> k0(kd, kd + (size_t)EMB * 4 * HID);
-                if ((rc = upload(h, &d_k0, k0))) return rc;
-                if ((rc = dalloc(h, &h->lstm_table[d], (size_t)VOCAB * 4 * HID))) return rc;
-                HIPCHK(h, launch_embed_table(d_emb, d_k0, h->lstm_table[d], VOCAB, EMB, 4 * HID, h->s0));
-                std::vector<float> wf(kd + (size_t)EMB * 4 * HID, kd + (size_t)(EMB + 3) * 4 * HID);
+                if (h->is_base) {
+                    // embedding folded into W_x: table[v] = emb[v] @ kernel[0:128]   (model.py:61-69)
+                    float* d_k0 = nullptr;
+                    std::vector<float> k0(kd, kd + (size_t)EMB * 4 * HID);
+                    if ((rc = upload(h, &d_k0, k0))) return rc;
+                    if ((rc = dalloc(h, &h->lstm_table[d], (size_t)VOCAB * 4 * HID))) return rc;
+                    HIPCHK(h, launch_embed_table(d_emb, d_k0, h->lstm_table[d], VOCAB, EMB, 4 * HID, h->s0));
+                }
+                std::vector<float> wf(kd + (size_t)(in0 - 3) * 4 * HID, kd + (size_t)in0 * 4 * HID);
                 if ((rc = upload(h, &h->lstm_wfeat[d], wf))) return rc;
             }
         }
+    }
     // ---- joint FC (layers.py:247-264) ----
     const HostTensor* w1 = find(h, "dense/kernel");
     const HostTensor* w2 = find(h, "dense_1/kernel");
@@ -466,7 +476,9 @@ int build_plan(ds_handle* h, int n, Plan* plan)
     };
 
     // ================= signal model (stream 0) — layers.py:181-239 =================
-    int st = stage_id(h, "stem", 0);
+    int st = 0;
+    if (h->is_cnn) {
+    st = stage_id(h, "stem", 0);
     {
         Op op{};
         op.kind = OP_STEM1; op.stream = 0; op.stage = st; op.in = h->d_signals; op.out = h->stem_pool;
@@ -579,6 +591,7 @@ int build_plan(ds_handle* h, int n, Plan* plan)
         op.in = x; op.out = h->sigfeat; op.a = h->wc; op.d = INC_OUT;
         add_ew_op(cnn, op);
     }
+    }   // is_cnn
 
     // ================= event model (stream 1) — layers.py:20-72,161-173 =================
     // Anti-diagonal wavefront: diagonal d runs cells (layer l, step d-l) of both directions in ONE
@@ -588,7 +601,7 @@ int build_plan(ds_handle* h, int n, Plan* plan)
     // dense variants skip the per-row validity selects; legal when every tile row is a real site
     const GemmCfg lstm_cfg = n % 128 == 0 ? CFG_LSTM_DENSE : CFG_LSTM;
     const GemmCfg fc_cfg = n % 128 == 0 ? CFG_FC_DENSE : CFG_FC;
-    for (int d = 0; d < T + NLAYER - 1; ++d) {
+    for (int d = 0; h->is_rnn && d < T + NLAYER - 1; ++d) {
         GemmLaunch L{};
         for (int dir = 0; dir < 2; ++dir)
             for (int l = 0; l < NLAYER; ++l) {
@@ -604,7 +617,7 @@ int build_plan(ds_handle* h, int n, Plan* plan)
                 P.lstm.codes = h->d_kmer; P.lstm.means = h->d_means; P.lstm.stds = h->d_stds; P.lstm.lens = h->d_sanums;
                 P.lstm.c = h->Cst[dir][l];
                 P.lstm.h_out = h->H[dir][l] + (size_t)t * h->B * HID;
-                P.lstm.t = t; P.lstm.T = T; P.lstm.c_zero = s == 0;
+                P.lstm.t = t; P.lstm.T = T; P.lstm.c_zero = s == 0; P.lstm.use_feat = l == 0;
                 add_tiles(L, P, lstm_cfg);
             }
         add_gemm_op(rnn, 1, st, lstm_cfg, L);
@@ -617,9 +630,11 @@ int build_plan(ds_handle* h, int n, Plan* plan)
         GemmLaunch L{};
         GemmProblem P = base_problem(n, h->J, n, h->fc1);
         // joint = [fw h(T-1) | bw h(0) | signal features]: three A segments, no concat buffer (layers.py:171-172,250-252)
-        add_seg(P, h->H[0][NLAYER - 1] + (size_t)(T - 1) * h->B * HID, HID, 0, HID);
-        add_seg(P, h->H[1][NLAYER - 1] + 0, HID, 0, HID);
-        add_seg(P, h->sigfeat, h->SF, 0, h->SF);
+        if (h->is_rnn) {
+            add_seg(P, h->H[0][NLAYER - 1] + (size_t)(T - 1) * h->B * HID, HID, 0, HID);
+            add_seg(P, h->H[1][NLAYER - 1] + 0, HID, 0, HID);
+        }
+        if (h->is_cnn) add_seg(P, h->sigfeat, h->SF, 0, h->SF);
         add_out(P, h->fc1o, h->J, 0, h->J, 0);
         add_tiles(L, P, fc_cfg);
         add_gemm_op(tail, 0, st, fc_cfg, L);
@@ -828,8 +843,8 @@ int ds_create(const ds_config* cfg, ds_handle** out)
 {
     if (!cfg || !out) return fail(nullptr, DS_ERR_INVALID, "ds_create: null argument");
     *out = nullptr;
-    if (!(cfg->is_cnn && cfg->is_rnn && cfg->is_base))
-        return fail(nullptr, DS_ERR_UNSUPPORTED, "only the full model (is_cnn=is_rnn=is_base=yes) is implemented");
+    if (!(cfg->is_cnn || cfg->is_rnn))
+        return fail(nullptr, DS_ERR_INVALID, "at least one of is_cnn/is_rnn should be True");      // model.py:28-29
     if (cfg->precision != DS_PRECISION_FP32) return fail(nullptr, DS_ERR_UNSUPPORTED, "only fp32 is implemented");
     if (cfg->kmer_len < 1 || cfg->kmer_len > 255 || (cfg->kmer_len & 1) == 0)
         return fail(nullptr, DS_ERR_INVALID, "kmer_len must be odd and in [1,255]");
@@ -848,8 +863,9 @@ int ds_create(const ds_config* cfg, ds_handle** out)
     same_pad(h->w1, 3, 2, &h->wa, &h->pl_pool1);
     same_pad(h->wa, 3, 2, &h->wb, &h->pl_pool2);
     same_pad(h->wb, 3, 2, &h->wc, &h->pl_pool3);
+    h->is_cnn = cfg->is_cnn != 0; h->is_rnn = cfg->is_rnn != 0; h->is_base = cfg->is_base != 0;
     h->SF = h->wc * INC_OUT;
-    h->J = 2 * HID + h->SF;
+    h->J = (h->is_rnn ? 2 * HID : 0) + (h->is_cnn ? h->SF : 0);     // layers.py:248-255
     h->debug = cfg->reserved[0] != 0;
 #define CK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { fail(nullptr, DS_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); ds_destroy(h); return DS_ERR_HIP; } } while (0)
     CK(hipSetDevice(cfg->device));
@@ -1074,10 +1090,13 @@ int64_t ds_get_intermediate(ds_handle* h, const char* name, float* out, int64_t 
         hipMemcpy(fw.data(), h->H[0][NLAYER - 1] + (size_t)(h->T - 1) * h->B * HID, fw.size() * 4, hipMemcpyDeviceToHost);
         hipMemcpy(bw.data(), h->H[1][NLAYER - 1], bw.size() * 4, hipMemcpyDeviceToHost);
         if (hipMemcpy(sf.data(), h->sigfeat, sf.size() * 4, hipMemcpyDeviceToHost) != hipSuccess) return fail(h, DS_ERR_HIP, "hipMemcpy D2H");
+        const int ev = h->is_rnn ? 2 * HID : 0;
         for (int i = 0; i < n; ++i) {
-            memcpy(out + (size_t)i * h->J, fw.data() + (size_t)i * HID, HID * 4);
-            memcpy(out + (size_t)i * h->J + HID, bw.data() + (size_t)i * HID, HID * 4);
-            memcpy(out + (size_t)i * h->J + 2 * HID, sf.data() + (size_t)i * h->SF, (size_t)h->SF * 4);
+            if (h->is_rnn) {
+                memcpy(out + (size_t)i * h->J, fw.data() + (size_t)i * HID, HID * 4);
+                memcpy(out + (size_t)i * h->J + HID, bw.data() + (size_t)i * HID, HID * 4);
+            }
+            if (h->is_cnn) memcpy(out + (size_t)i * h->J + ev, sf.data() + (size_t)i * h->SF, (size_t)h->SF * 4);
         }
         return count;
     }

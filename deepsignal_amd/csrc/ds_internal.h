@@ -47,7 +47,7 @@ struct LstmEp {
     int t;                // original time index this step consumes
     int T;
     int c_zero;           // 1: previous c is zero (first step)
-    int pad_;
+    int use_feat;         // 1: layer 0 — add mean/std/len rank-1 terms (and the table row when table != nullptr)
 };
 
 struct GemmProblem {

@@ -386,9 +386,10 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void gemm_kernel(const GemmLaunc
         if (nvalid[0]) {
             const gptr1 biasg = (gptr1)P.bias;
             const float bi = biasg[u], bj = biasg[256 + u], bf = biasg[512 + u] + 1.0f, bo = biasg[768 + u];   // forget_bias folded
-            const bool has_table = E.table != nullptr;
+            const bool has_table = E.table != nullptr;     // is_base: embedding folded into a [vocab][1024] table
+            const bool has_feat = E.use_feat != 0;         // layer 0: (mean, std, len) rank-1 terms
             float wi[3] = {0, 0, 0}, wj[3] = {0, 0, 0}, wf[3] = {0, 0, 0}, wo[3] = {0, 0, 0};
-            if (has_table) {
+            if (has_feat) {
                 const gptr1 wg = (gptr1)E.wfeat;
 #pragma unroll
                 for (int q = 0; q < 3; ++q) {
@@ -423,14 +424,20 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void gemm_kernel(const GemmLaunc
                         off[k] = rowc * 256u + u;
                         cp[k] = c_zero ? 0.0f : cg[off[k]];
                         xi[k] = xj[k] = xf[k] = xo[k] = 0.0f;
-                        if (has_table) {
+                        if (has_feat) {
                             const unsigned it = rowc * Tt + tt;
-                            const unsigned tb = (unsigned)codeg[it] * 1024u + u;
                             const float f0 = meang[it], f1 = stdg[it], f2 = leng[it];
-                            xi[k] = tabg[tb] + f0 * wi[0] + f1 * wi[1] + f2 * wi[2];
-                            xj[k] = tabg[tb + 256] + f0 * wj[0] + f1 * wj[1] + f2 * wj[2];
-                            xf[k] = tabg[tb + 512] + f0 * wf[0] + f1 * wf[1] + f2 * wf[2];
-                            xo[k] = tabg[tb + 768] + f0 * wo[0] + f1 * wo[1] + f2 * wo[2];
+                            xi[k] = f0 * wi[0] + f1 * wi[1] + f2 * wi[2];
+                            xj[k] = f0 * wj[0] + f1 * wj[1] + f2 * wj[2];
+                            xf[k] = f0 * wf[0] + f1 * wf[1] + f2 * wf[2];
+                            xo[k] = f0 * wo[0] + f1 * wo[1] + f2 * wo[2];
+                            if (has_table) {
+                                const unsigned tb = (unsigned)codeg[it] * 1024u + u;
+                                xi[k] += tabg[tb];
+                                xj[k] += tabg[tb + 256];
+                                xf[k] += tabg[tb + 512];
+                                xo[k] += tabg[tb + 768];
+                            }
                         }
                     }
 #pragma unroll

@@ -123,14 +123,21 @@ class NetDims:
         return 256 if n == 1 else INCEPTION_OUT
 
 
-def net_dims(kmer_len: int = 17, signal_len: int = 360, class_num: int = 2) -> NetDims:
+def net_dims(kmer_len: int = 17, signal_len: int = 360, class_num: int = 2,
+             is_cnn: bool = True, is_rnn: bool = True) -> NetDims:
+    """Shapes of the graph. is_cnn / is_rnn select which sub-model feeds the joint FC
+    (model.py:28-29,89-95); at least one must be on."""
+    if not (is_cnn or is_rnn):
+        raise ValueError("at least one of is_cnn/is_rnn should be True")     # model.py:28-29
     w1, l1, r1 = same_pad(signal_len, 7, 2)
     wa, lp1, rp1 = same_pad(w1, 3, 2)
     wb, lp2, rp2 = same_pad(wa, 3, 2)
     wc, lp3, rp3 = same_pad(wb, 3, 2)
     sf = wc * INCEPTION_OUT
+    ev = 2 * HIDDEN
     return NetDims(kmer_len, signal_len, class_num, w1, wa, wb, wc,
-                   (l1, r1), (lp1, rp1), (lp2, rp2), (lp3, rp3), sf, 2 * HIDDEN, sf + 2 * HIDDEN)
+                   (l1, r1), (lp1, rp1), (lp2, rp2), (lp3, rp3), sf, ev,
+                   (sf if is_cnn else 0) + (ev if is_rnn else 0))
 
 
 def lstm_tensor(direction: str, layer: int, which: str, prefix: str = MODEL_PREFIX) -> str:
@@ -138,35 +145,44 @@ def lstm_tensor(direction: str, layer: int, which: str, prefix: str = MODEL_PREF
     return "%sem/%s/multi_rnn_cell/cell_%d/lstm_cell/%s" % (prefix, direction, layer, which)
 
 
-def lstm_input_size(layer: int) -> int:
-    return EMBEDDING_SIZE + 3 if layer == 0 else HIDDEN     # model.py:63-69
+def lstm_input_size(layer: int, is_base: bool = True) -> int:
+    if layer > 0:
+        return HIDDEN
+    return EMBEDDING_SIZE + 3 if is_base else 3             # model.py:63-75
 
 
 def tensor_table(kmer_len: int = 17, signal_len: int = 360, class_num: int = 2,
-                 prefix: str = MODEL_PREFIX) -> List[Tuple[str, Tuple[int, ...]]]:
+                 prefix: str = MODEL_PREFIX, is_cnn: bool = True, is_rnn: bool = True,
+                 is_base: bool = True) -> List[Tuple[str, Tuple[int, ...]]]:
     """Canonical ordered list of (TF variable name, shape) for the inference parameters.
 
-    The order is the contract between weights.py, the oracle wrapper and the HIP engine."""
-    d = net_dims(kmer_len, signal_len, class_num)
+    The order is the contract between weights.py, the oracle wrapper and the HIP engine.
+    Variants (model.py:28-29,59-75,89-95): without is_rnn there is no embedding / LSTM; without
+    is_base the LSTM reads only (mean, std, len); without is_cnn the signal model does not feed the
+    joint FC (the reference still instantiates it, its tensors are simply not needed here)."""
+    d = net_dims(kmer_len, signal_len, class_num, is_cnn, is_rnn)
     out: List[Tuple[str, Tuple[int, ...]]] = []
-    out.append((prefix + "embedding", (VOCAB_SIZE, EMBEDDING_SIZE)))
-    for direction in ("fw", "bw"):
-        for layer in range(LSTM_LAYERS):
-            out.append((lstm_tensor(direction, layer, "kernel", prefix),
-                        (lstm_input_size(layer) + HIDDEN, 4 * HIDDEN)))
-            out.append((lstm_tensor(direction, layer, "bias", prefix), (4 * HIDDEN,)))
+    if is_rnn:
+        if is_base:
+            out.append((prefix + "embedding", (VOCAB_SIZE, EMBEDDING_SIZE)))
+        for direction in ("fw", "bw"):
+            for layer in range(LSTM_LAYERS):
+                out.append((lstm_tensor(direction, layer, "kernel", prefix),
+                            (lstm_input_size(layer, is_base) + HIDDEN, 4 * HIDDEN)))
+                out.append((lstm_tensor(direction, layer, "bias", prefix), (4 * HIDDEN,)))
 
     def add_conv(c: ConvBN) -> None:
         out.append((c.kernel_name, c.kernel_shape))
         for part in BN_PARTS:
             out.append((c.bn_tensor(part), (c.cout,)))
 
-    for c in stem_convs(prefix):
-        add_conv(c)
-    for n in range(1, N_INCEPTION + 1):
-        convs = inception_convs(n, d.module_cin(n), prefix)
-        for key in INCEPTION_KEYS:
-            add_conv(convs[key])
+    if is_cnn:
+        for c in stem_convs(prefix):
+            add_conv(c)
+        for n in range(1, N_INCEPTION + 1):
+            convs = inception_convs(n, d.module_cin(n), prefix)
+            for key in INCEPTION_KEYS:
+                add_conv(convs[key])
     out.append(("dense/kernel", (d.joint, d.joint)))          # layers.py:257-259
     out.append(("dense_1/kernel", (d.joint, class_num)))      # layers.py:261-262
     return out

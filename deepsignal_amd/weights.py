@@ -49,14 +49,15 @@ def _truncated_normal(rng: np.random.Generator, shape, std: float) -> np.ndarray
 
 def random_weights(seed: int = WEIGHT_SEED, kmer_len: int = 17, signal_len: int = 360,
                    class_num: int = 2, lstm_bias_std: float = 0.0,
-                   randomize_bn: bool = True) -> Dict[str, np.ndarray]:
+                   randomize_bn: bool = True, is_cnn: bool = True, is_rnn: bool = True,
+                   is_base: bool = True) -> Dict[str, np.ndarray]:
     """Random-init parameters in the canonical order of `spec.tensor_table`.
 
     lstm_bias_std=0 reproduces TF's zero LSTM bias; tests pass a non-zero value so the bias path
     is exercised."""
     rng = np.random.default_rng(seed)
     out: Dict[str, np.ndarray] = {}
-    for name, shape in spec.tensor_table(kmer_len, signal_len, class_num):
+    for name, shape in spec.tensor_table(kmer_len, signal_len, class_num, is_cnn=is_cnn, is_rnn=is_rnn, is_base=is_base):
         leaf = name.rsplit("/", 1)[-1]
         if name.endswith("embedding"):
             w = _truncated_normal(rng, shape, float(np.sqrt(2.0 / spec.VOCAB_SIZE)))
@@ -80,8 +81,8 @@ def random_weights(seed: int = WEIGHT_SEED, kmer_len: int = 17, signal_len: int 
 
 
 def check_weights(weights: Dict[str, np.ndarray], kmer_len: int = 17, signal_len: int = 360,
-                  class_num: int = 2) -> None:
-    for name, shape in spec.tensor_table(kmer_len, signal_len, class_num):
+                  class_num: int = 2, **variant) -> None:
+    for name, shape in spec.tensor_table(kmer_len, signal_len, class_num, **variant):
         if name not in weights:
             raise KeyError("missing tensor %s" % name)
         if tuple(weights[name].shape) != tuple(shape):
@@ -138,6 +139,6 @@ def load_weights(path: str) -> Dict[str, np.ndarray]:
 
 
 def ordered(weights: Dict[str, np.ndarray], kmer_len: int = 17, signal_len: int = 360,
-            class_num: int = 2) -> Iterable[np.ndarray]:
-    for name, _ in spec.tensor_table(kmer_len, signal_len, class_num):
+            class_num: int = 2, **variant) -> Iterable[np.ndarray]:
+    for name, _ in spec.tensor_table(kmer_len, signal_len, class_num, **variant):
         yield weights[name]

@@ -37,7 +37,7 @@ typedef struct ds_config {
     int32_t kmer_len;     /* base_num,   default 17  (deepsignal.py:258-259) */
     int32_t signal_len;   /* signal_num, default 360 (deepsignal.py:260-262) */
     int32_t class_num;    /* default 2 */
-    int32_t is_cnn;       /* model.py:28-29 switches; this round: all three must be 1 */
+    int32_t is_cnn;       /* model.py:28-29,59-75,89-95 switches (at least one of is_cnn / is_rnn) */
     int32_t is_rnn;
     int32_t is_base;
     int32_t device;       /* HIP device ordinal */

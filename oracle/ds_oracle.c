@@ -52,6 +52,7 @@ typedef struct {
 
 typedef struct {
     int kmer_len, signal_len, class_num;
+    int is_cnn, is_rnn, is_base;     /* model.py:28-29,59-75,89-95 */
     int w1, wa, wb, wc, joint;
     const float *embedding;
     const float *lstm_kernel[2][NLAYER];
@@ -227,25 +228,29 @@ static void event_model(const net_t *N, const int32_t *kmer, const float *means,
                         ds_oracle_taps *taps)
 {
     const int T = N->kmer_len;
-    real *x0 = scratch;                      /* [T][131] */
+    const int IN0 = N->is_base ? EMB + 3 : 3;    /* model.py:63-75: without is_base only (mean, std, len) */
+    real *x0 = scratch;                      /* [T][IN0] */
     real *h = x0 + (size_t)T * (EMB + 3);    /* [3][256] */
     real *c = h + NLAYER * HID;              /* [3][256] */
     real *z = c + NLAYER * HID;              /* [1024]   */
     real *xin = z + 4 * HID;                 /* [512]    */
-    for (int t = 0; t < T; ++t) {            /* model.py:61-69 embedding_lookup + concat */
-        int code = kmer[t];
-        const float *e = N->embedding + (size_t)code * EMB;
-        for (int i = 0; i < EMB; ++i) x0[(size_t)t * (EMB + 3) + i] = (real)e[i];
-        x0[(size_t)t * (EMB + 3) + EMB + 0] = (real)means[t];
-        x0[(size_t)t * (EMB + 3) + EMB + 1] = (real)stds[t];
-        x0[(size_t)t * (EMB + 3) + EMB + 2] = (real)sanums[t];
+    for (int t = 0; t < T; ++t) {            /* model.py:61-75 embedding_lookup + concat */
+        int o = 0;
+        if (N->is_base) {
+            const float *e = N->embedding + (size_t)kmer[t] * EMB;
+            for (int i = 0; i < EMB; ++i) x0[(size_t)t * IN0 + i] = (real)e[i];
+            o = EMB;
+        }
+        x0[(size_t)t * IN0 + o + 0] = (real)means[t];
+        x0[(size_t)t * IN0 + o + 1] = (real)stds[t];
+        x0[(size_t)t * IN0 + o + 2] = (real)sanums[t];
     }
     for (int d = 0; d < 2; ++d) {
         for (int i = 0; i < NLAYER * HID; ++i) { h[i] = 0; c[i] = 0; }   /* zero initial state */
         for (int s = 0; s < T; ++s) {
             const int t = d == 0 ? s : T - 1 - s;
-            const real *x = x0 + (size_t)t * (EMB + 3);
-            int xin_n = EMB + 3;
+            const real *x = x0 + (size_t)t * IN0;
+            int xin_n = IN0;
             for (int l = 0; l < NLAYER; ++l) {
                 const float *K = N->lstm_kernel[d][l];
                 const float *b = N->lstm_bias[d][l];
@@ -282,27 +287,33 @@ static void event_model(const net_t *N, const int32_t *kmer, const float *means,
     }
 }
 
-static int bind_net(net_t *N, int kmer_len, int signal_len, int class_num, const float *const *t)
+static int bind_net(net_t *N, int kmer_len, int signal_len, int class_num, int is_cnn, int is_rnn, int is_base,
+                    const float *const *t)
 {
     memset(N, 0, sizeof(*N));
     N->kmer_len = kmer_len; N->signal_len = signal_len; N->class_num = class_num;
+    N->is_cnn = is_cnn; N->is_rnn = is_rnn; N->is_base = is_base;
     int pl, w;
     same_pad(signal_len, 7, 2, &N->w1, &pl);
     same_pad(N->w1, 3, 2, &N->wa, &pl);
     same_pad(N->wa, 3, 2, &N->wb, &pl);
     same_pad(N->wb, 3, 2, &N->wc, &pl);
     (void)w;
-    N->joint = 2 * HID + N->wc * INC_OUT;
+    N->joint = (is_rnn ? 2 * HID : 0) + (is_cnn ? N->wc * INC_OUT : 0);     /* layers.py:248-255 */
     int i = 0;
-    N->embedding = t[i++];
-    for (int d = 0; d < 2; ++d)
-        for (int l = 0; l < NLAYER; ++l) { N->lstm_kernel[d][l] = t[i++]; N->lstm_bias[d][l] = t[i++]; }
+    if (is_rnn) {
+        if (is_base) N->embedding = t[i++];
+        for (int d = 0; d < 2; ++d)
+            for (int l = 0; l < NLAYER; ++l) { N->lstm_kernel[d][l] = t[i++]; N->lstm_bias[d][l] = t[i++]; }
+    }
 #define BIND(L, K_, CIN, COUT, S, RELU) do { (L).kernel = t[i++]; (L).beta = t[i++]; (L).gamma = t[i++]; \
         (L).mean = t[i++]; (L).var = t[i++]; (L).k = K_; (L).cin = CIN; (L).cout = COUT; (L).stride = S; (L).relu = RELU; } while (0)
+    if (is_cnn) {
     BIND(N->stem[0], 7, 1, 64, 2, 1);
     BIND(N->stem[1], 1, 64, 128, 1, 1);
     BIND(N->stem[2], 3, 128, 256, 1, 1);
-    for (int m = 0; m < NMOD; ++m) {
+    }
+    for (int m = 0; is_cnn && m < NMOD; ++m) {
         int cin = m == 0 ? 256 : INC_OUT;
         BIND(N->mod[m][0], 1, cin, 48, 1, 1);   /* b1  */
         BIND(N->mod[m][1], 1, cin, 48, 1, 1);   /* b2  */
@@ -321,19 +332,23 @@ static int bind_net(net_t *N, int kmer_len, int signal_len, int class_num, const
     return i;
 }
 
-int ds_oracle_num_tensors(void) { return 1 + 12 + 15 + NMOD * 50 + 2; }
+int ds_oracle_num_tensors(int is_cnn, int is_rnn, int is_base)
+{
+    return (is_rnn ? 12 + (is_base ? 1 : 0) : 0) + (is_cnn ? 15 + NMOD * 50 : 0) + 2;
+}
 
 int ds_oracle_real_bytes(void) { return (int)sizeof(real); }
 
 /* The whole call_mods forward (model.py:25-108): returns 0, fills act [n,class_num] (sigmoid of the
  * logits, model.py:100) and pred [n] (argmax, ties -> first index, model.py:107-108). */
-int ds_oracle_forward(int kmer_len, int signal_len, int class_num, const float *const *tensors,
-                      int n, const int32_t *kmer, const float *means, const float *stds,
+int ds_oracle_forward(int kmer_len, int signal_len, int class_num, int is_cnn, int is_rnn, int is_base,
+                      const float *const *tensors, int n, const int32_t *kmer, const float *means, const float *stds,
                       const float *sanums, const float *signals, float *act, int32_t *pred,
                       ds_oracle_taps *taps, int nthreads)
 {
     net_t N;
-    bind_net(&N, kmer_len, signal_len, class_num, tensors);
+    if (!(is_cnn || is_rnn)) return -2;               /* model.py:28-29 */
+    bind_net(&N, kmer_len, signal_len, class_num, is_cnn, is_rnn, is_base, tensors);
     const int J = N.joint;
     real *joint = (real *)malloc((size_t)n * J * sizeof(real));
     real *fc1 = (real *)calloc((size_t)n * J, sizeof(real));
@@ -352,10 +367,12 @@ int ds_oracle_forward(int kmer_len, int signal_len, int class_num, const float *
         real *scr = (real *)malloc(((size_t)kmer_len * (EMB + 3) + 2 * NLAYER * HID + 4 * HID + 2 * HID) * sizeof(real));
 #pragma omp for schedule(dynamic, 1)
         for (int s = 0; s < n; ++s) {
-            real *jr = joint + (size_t)s * J;
-            event_model(&N, kmer + (size_t)s * kmer_len, means + (size_t)s * kmer_len,
-                        stds + (size_t)s * kmer_len, sanums + (size_t)s * kmer_len, jr, scr, (size_t)s, taps);
-            signal_model(&N, signals + (size_t)s * signal_len, jr + 2 * HID, buf0, buf1, tmp, (size_t)s, taps);
+            real *jr = joint + (size_t)s * J;          /* joint = [event | signal] (layers.py:248-255) */
+            if (is_rnn)
+                event_model(&N, kmer + (size_t)s * kmer_len, means + (size_t)s * kmer_len,
+                            stds + (size_t)s * kmer_len, sanums + (size_t)s * kmer_len, jr, scr, (size_t)s, taps);
+            if (is_cnn)
+                signal_model(&N, signals + (size_t)s * signal_len, jr + (is_rnn ? 2 * HID : 0), buf0, buf1, tmp, (size_t)s, taps);
         }
         free(buf0); free(buf1); free(tmp); free(scr);
     }
@@ -396,10 +413,12 @@ int ds_oracle_forward(int kmer_len, int signal_len, int class_num, const float *
     }
     if (taps && taps->joint) for (size_t i = 0; i < (size_t)n * J; ++i) taps->joint[i] = (float)joint[i];
     if (taps && taps->fc1) for (size_t i = 0; i < (size_t)n * J; ++i) taps->fc1[i] = (float)fc1[i];
-    if (taps && taps->signal_feat)
+    if (taps && taps->signal_feat && is_cnn) {
+        const int ev = is_rnn ? 2 * HID : 0;
         for (int s = 0; s < n; ++s)
-            for (int i = 0; i < J - 2 * HID; ++i)
-                taps->signal_feat[(size_t)s * (J - 2 * HID) + i] = (float)joint[(size_t)s * J + 2 * HID + i];
+            for (int i = 0; i < J - ev; ++i)
+                taps->signal_feat[(size_t)s * (J - ev) + i] = (float)joint[(size_t)s * J + ev + i];
+    }
     free(joint); free(fc1);
     return 0;
 }

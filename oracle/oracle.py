@@ -60,12 +60,12 @@ def _lib(precision: str) -> ctypes.CDLL:
 
 def forward(weights: Dict[str, np.ndarray], feats: Dict[str, np.ndarray], precision: str = "f32",
             taps: bool = False, nthreads: int = 0, kmer_len: int = 17, signal_len: int = 360,
-            class_num: int = 2):
+            class_num: int = 2, is_cnn: bool = True, is_rnn: bool = True, is_base: bool = True):
     """Run the oracle. Returns (act [n,class_num] f32, pred [n] i32[, taps dict])."""
     from deepsignal_amd import spec   # spec only (names/shapes); never the engine
     lib = _lib(precision)
-    table = spec.tensor_table(kmer_len, signal_len, class_num)
-    assert lib.ds_oracle_num_tensors() == len(table)
+    table = spec.tensor_table(kmer_len, signal_len, class_num, is_cnn=is_cnn, is_rnn=is_rnn, is_base=is_base)
+    assert lib.ds_oracle_num_tensors(int(is_cnn), int(is_rnn), int(is_base)) == len(table)
     arrs = [np.ascontiguousarray(weights[name], dtype=np.float32) for name, _ in table]
     for a, (name, shape) in zip(arrs, table):
         assert tuple(a.shape) == tuple(shape), name
@@ -79,7 +79,7 @@ def forward(weights: Dict[str, np.ndarray], feats: Dict[str, np.ndarray], precis
     assert kmer.shape == (n, kmer_len) and signals.shape == (n, signal_len)
     act = np.empty((n, class_num), np.float32)
     pred = np.empty((n,), np.int32)
-    d = spec.net_dims(kmer_len, signal_len, class_num)
+    d = spec.net_dims(kmer_len, signal_len, class_num, is_cnn, is_rnn)
     tap_arrays: Optional[Dict[str, np.ndarray]] = None
     tp = None
     if taps:
@@ -106,6 +106,7 @@ def forward(weights: Dict[str, np.ndarray], feats: Dict[str, np.ndarray], precis
                 st.lstm_h[di][l] = a.ctypes.data
         tp = ctypes.byref(st)
     rc = lib.ds_oracle_forward(ctypes.c_int(kmer_len), ctypes.c_int(signal_len), ctypes.c_int(class_num),
+                               ctypes.c_int(int(is_cnn)), ctypes.c_int(int(is_rnn)), ctypes.c_int(int(is_base)),
                                ptrs, ctypes.c_int(n),
                                ctypes.c_void_p(kmer.ctypes.data), ctypes.c_void_p(means.ctypes.data),
                                ctypes.c_void_p(stds.ctypes.data), ctypes.c_void_p(sanums.ctypes.data),
@@ -114,5 +115,9 @@ def forward(weights: Dict[str, np.ndarray], feats: Dict[str, np.ndarray], precis
     if rc != 0:
         raise RuntimeError("ds_oracle_forward failed: %d" % rc)
     if taps:
+        if not is_cnn:
+            tap_arrays = {k: v for k, v in tap_arrays.items() if not (k.startswith("stem") or k.startswith("module") or k == "signal_feat")}
+        if not is_rnn:
+            tap_arrays = {k: v for k, v in tap_arrays.items() if not k.startswith("lstm")}
         return act, pred, tap_arrays
     return act, pred

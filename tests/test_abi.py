@@ -59,10 +59,11 @@ def test_package_never_imports_the_oracle():
                 assert hit is None, "%s uses the oracle (%s)" % (f, hit.group(0))
 
 
-def test_unsupported_variants_are_rejected_not_substituted(lib):
+def test_invalid_variant_is_rejected(lib):
+    """model.py:28-29: at least one of is_cnn / is_rnn."""
     from deepsignal_amd.engine import DsConfig
-    cfg = DsConfig(17, 360, 2, 0, 1, 1, 0, 0, 8)
+    cfg = DsConfig(17, 360, 2, 0, 0, 1, 0, 0, 8)
     h = ctypes.c_void_p()
     rc = lib.ds_create(ctypes.byref(cfg), ctypes.byref(h))
-    assert rc == -4 and not h.value
-    assert b"full model" in lib.ds_last_error(None)
+    assert rc == -1 and not h.value
+    assert b"at least one" in lib.ds_last_error(None)

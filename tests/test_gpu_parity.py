@@ -133,10 +133,31 @@ def test_errors_are_loud(small_weights):
     feats = synth.synthetic_features(4, seed=1)
     with pytest.raises(RuntimeError):        # weights not loaded
         eng.run(*(feats[k] for k in ("kmer", "means", "stds", "sanums", "signals")))
-    with pytest.raises(RuntimeError):        # variant not implemented must not silently run something else
-        Engine(is_cnn=False)
+    with pytest.raises(RuntimeError):        # model.py:28-29: at least one of is_cnn / is_rnn
+        Engine(is_cnn=False, is_rnn=False)
     bad = dict(small_weights)
     bad.pop("dense/kernel")
     with pytest.raises(RuntimeError):
         eng.load_weights(bad)
+    eng.close()
+
+
+@pytest.mark.parametrize("variant", [dict(is_cnn=False, is_rnn=True, is_base=True),     # RNN-only (what `denoise` uses)
+                                     dict(is_cnn=True, is_rnn=False, is_base=True),     # CNN-only
+                                     dict(is_cnn=True, is_rnn=True, is_base=False),     # no k-mer embedding
+                                     dict(is_cnn=False, is_rnn=True, is_base=False)])
+def test_model_variants(variant):
+    """Model(is_cnn, is_rnn, is_base) switches of model.py:28-29,59-75,89-95."""
+    from deepsignal_amd import weights as W
+    from oracle import oracle
+    w = W.random_weights(seed=21, lstm_bias_std=0.1, **variant)
+    feats = synth.synthetic_features(40, seed=77)
+    eng = _engine(w, max_batch=64, debug=True, **variant)
+    act, pred = eng.run(feats["kmer"], feats["means"], feats["stds"], feats["sanums"], feats["signals"])
+    o_act, o_pred, taps = oracle.forward(w, feats, "f32", taps=True, **variant)
+    for name, ref in taps.items():
+        got = eng.intermediate(name, ref.shape)
+        err = float(np.abs(got - ref).max())
+        assert err <= INTERMEDIATE_RTOL * max(1.0, float(np.abs(ref).max())), (name, err)
+    _check_outputs(act, pred, o_act, o_pred)
     eng.close()

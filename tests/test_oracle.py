@@ -117,3 +117,24 @@ def test_weight_file_roundtrip(tmp_path, gold_weights):
         assert np.array_equal(back[k], sub[k]) and back[k].dtype == np.float32
     with pytest.raises(KeyError):
         weights.check_weights(sub)
+
+
+@pytest.mark.parametrize("variant", [dict(is_cnn=False, is_rnn=True, is_base=True),
+                                     dict(is_cnn=True, is_rnn=False, is_base=True),
+                                     dict(is_cnn=True, is_rnn=True, is_base=False)])
+def test_model_variants_two_statements_agree(variant):
+    """Model(is_cnn, is_rnn, is_base) switches (model.py:28-29,59-75,89-95): joint width, inputs of the
+    first LSTM layer and the tensor table all change; both statements must still agree."""
+    w = weights.random_weights(seed=5, lstm_bias_std=0.1, **variant)
+    weights.check_weights(w, **variant)
+    feats = synth.synthetic_features(5, seed=3)
+    o_act, o_pred, o_taps = oracle.forward(w, feats, "f64", taps=True, **variant)
+    t_act, t_pred, t_taps = torch_statement.forward(w, feats, torch.float64, True, **variant)
+    assert set(o_taps) == set(t_taps)
+    assert np.abs(o_act - t_act).max() < 1e-7 and np.array_equal(o_pred, t_pred)
+    for k, v in o_taps.items():
+        assert np.abs(v - t_taps[k]).max() <= 1e-6 * max(1.0, np.abs(v).max()), k
+    d = spec.net_dims(is_cnn=variant["is_cnn"], is_rnn=variant["is_rnn"])
+    assert o_taps["joint"].shape[1] == d.joint == (5520 if variant["is_cnn"] else 0) + (512 if variant["is_rnn"] else 0)
+    with pytest.raises(ValueError):
+        spec.net_dims(is_cnn=False, is_rnn=False)

@@ -51,12 +51,33 @@ def _inception(x, w, n, cin):
 
 
 def forward(weights: Dict[str, np.ndarray], feats: Dict[str, np.ndarray], dtype=torch.float64,
-            return_taps: bool = False):
+            return_taps: bool = False, is_cnn: bool = True, is_rnn: bool = True, is_base: bool = True):
     w = {k: torch.from_numpy(np.asarray(v)).to(dtype) for k, v in weights.items()}
     kmer = torch.from_numpy(feats["kmer"]).long()
     n, T = kmer.shape
-    d = spec.net_dims(T, feats["signals"].shape[1], w["dense_1/kernel"].shape[1])
+    d = spec.net_dims(T, feats["signals"].shape[1], w["dense_1/kernel"].shape[1], is_cnn, is_rnn)
     taps = {}
+    parts = []
+    if is_rnn:
+        parts += _event_model(w, feats, kmer, n, T, dtype, taps, is_base)
+    if is_cnn:
+        parts.append(_signal_model(w, feats, n, d, dtype, taps))
+    joint = torch.cat(parts, dim=1)
+    fc1 = joint @ w["dense/kernel"]
+    logits = fc1 @ w["dense_1/kernel"]
+    act = torch.sigmoid(logits)
+    pred = torch.argmax(act, dim=1)
+    taps.update(joint=joint, fc1=fc1, logits=logits)
+    if return_taps:
+        out = {}
+        for k, v in taps.items():
+            v = v.permute(0, 2, 1) if (k.startswith("stem") or k.startswith("module")) else v
+            out[k] = v.contiguous().to(torch.float32).numpy()
+        return act.to(torch.float32).numpy(), pred.to(torch.int32).numpy(), out
+    return act.to(torch.float32).numpy(), pred.to(torch.int32).numpy()
+
+
+def _signal_model(w, feats, n, d, dtype, taps):
     # --- signal model (NCW) ---
     x = torch.from_numpy(feats["signals"]).to(dtype)[:, None, :]
     stem = spec.stem_convs()
@@ -71,10 +92,18 @@ def forward(weights: Dict[str, np.ndarray], feats: Dict[str, np.ndarray], dtype=
             x = _maxpool3(x, 2)
     x = F.avg_pool1d(x, 7, stride=1, padding=3, count_include_pad=False)
     signal_feat = x.permute(0, 2, 1).reshape(n, -1)          # flatten order (w, c)
+    taps["signal_feat"] = signal_feat
+    return signal_feat
+
+
+def _event_model(w, feats, kmer, n, T, dtype, taps, is_base):
     # --- event model ---
-    emb = w[spec.MODEL_PREFIX + "embedding"][kmer]            # [n,T,128]
     extra = [torch.from_numpy(feats[k]).to(dtype)[:, :, None] for k in ("means", "stds", "sanums")]
-    x0 = torch.cat([emb] + extra, dim=2)                      # [n,T,131]
+    if is_base:
+        emb = w[spec.MODEL_PREFIX + "embedding"][kmer]        # [n,T,128]
+        x0 = torch.cat([emb] + extra, dim=2)                  # [n,T,131]
+    else:
+        x0 = torch.cat(extra, dim=2)                          # [n,T,3]   (model.py:70-75)
     outs = []
     for direction in ("fw", "bw"):
         seq = x0 if direction == "fw" else torch.flip(x0, dims=[1])
@@ -93,16 +122,4 @@ def forward(weights: Dict[str, np.ndarray], feats: Dict[str, np.ndarray], dtype=
             seq = torch.stack(hs, dim=1)
             taps["lstm_%s_l%d" % (direction, layer)] = seq if direction == "fw" else torch.flip(seq, dims=[1])
         outs.append(seq[:, -1, :])      # fw: t=T-1 ; bw: last processed step == original t=0
-    joint = torch.cat(outs + [signal_feat], dim=1)
-    fc1 = joint @ w["dense/kernel"]
-    logits = fc1 @ w["dense_1/kernel"]
-    act = torch.sigmoid(logits)
-    pred = torch.argmax(act, dim=1)
-    taps.update(signal_feat=signal_feat, joint=joint, fc1=fc1, logits=logits)
-    if return_taps:
-        out = {}
-        for k, v in taps.items():
-            v = v.permute(0, 2, 1) if (k.startswith("stem") or k.startswith("module")) else v
-            out[k] = v.contiguous().to(torch.float32).numpy()
-        return act.to(torch.float32).numpy(), pred.to(torch.int32).numpy(), out
-    return act.to(torch.float32).numpy(), pred.to(torch.int32).numpy()
+    return outs
