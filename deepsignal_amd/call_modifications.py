@@ -142,7 +142,7 @@ def make_engine(model_path: str, kmer_len: int, cent_signals_len: int, class_num
 
 def call_mods(input_path, model_path, result_file, kmer_len, cent_signals_len,
               batch_size, learning_rate, class_num, nproc, is_gpu, is_rnn, is_base, is_cnn,
-              f5_args, engine=None, f5_batch_num=None):
+              f5_args, engine=None, f5_batch_num=None, native_io=True):
     """Feature-file mode of the reference's call_mods (call_modifications.py:417-495).
 
     learning_rate / nproc / is_gpu are accepted for signature compatibility: inference ignores the
@@ -160,13 +160,51 @@ def call_mods(input_path, model_path, result_file, kmer_len, cent_signals_len,
         engine = make_engine(model_path, kmer_len, cent_signals_len, class_num, batch_size,
                              is_cnn=is_cnn, is_rnn=is_rnn, is_base=is_base)
     nsites = 0
-    with open(result_file, "w") as wf:
-        for item in iter_features_batches(input_path, f5_batch_num):
-            pred_str, _, _ = _call_mods(item, engine, batch_size)
-            for row in pred_str:
-                wf.write(row + "\n")
-            wf.flush()
-            nsites += len(pred_str)
+    if native_io:
+        # row f1: native reader (host threads) + native row formatter; same items, same row text
+        from . import fastio
+        reader = fastio.FeatureReader(input_path, kmer_len, cent_signals_len)
+        # parse the next item on a helper thread while the engine works on the current one
+        # (the native calls release the GIL); a bounded queue keeps memory flat
+        import queue
+        import threading
+        q = queue.Queue(maxsize=3)
+
+        def _produce():
+            try:
+                for it in reader.items(f5_batch_num):
+                    q.put(it)
+                q.put(None)
+            except BaseException as exc:          # surfaced on the consumer side
+                q.put(exc)
+
+        th = threading.Thread(target=_produce, daemon=True)
+        th.start()
+        with open(result_file, "wb") as wf:
+            while True:
+                item = q.get()
+                if item is None:
+                    break
+                if isinstance(item, BaseException):
+                    raise item
+                n = len(item.labels)
+                for s in range(0, n, batch_size):
+                    e = min(n, s + batch_size)
+                    act, pred = engine.run(item.kmer[s:e], item.means[s:e], item.stds[s:e], item.lens[s:e],
+                                           item.signals[s:e])
+                    wf.write(fastio.format_rows(item.info, item.info_off[s:e + 1], act, pred, item.kmer[s:e]))
+                wf.flush()
+                nsites += n
+        th.join()
+        reader.close()
+    else:
+        with open(result_file, "w") as wf:
+            for item in iter_features_batches(input_path, f5_batch_num):
+                pred_str, _, _ = _call_mods(item, engine, batch_size)
+                for row in pred_str:
+                    wf.write(row + "\n")
+                wf.flush()
+                nsites += len(pred_str)
     if own:
         engine.close()
     print("call_mods costs %.2f seconds.. (%d sites)" % (time.time() - start, nsites))

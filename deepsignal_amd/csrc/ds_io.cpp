@@ -1,0 +1,318 @@
+// ds_io.cpp — native feature-TSV reader + result-row formatter (scope row f1 of SURVEY.md section 8).
+//
+// At GPU rates the reference's Python reader (~400 float() calls per row,
+// /root/reference/deepsignal/call_modifications.py:35-91) and its per-site formatting loop
+// (:183-190) are >100x too slow; this file restates both natively, behind the same C ABI:
+//   * reader: 12 tab-separated columns (extract_features.py:289-303), rows grouped by read id
+//     (column 5), one batch every `max_reads` reads, exactly as _read_features_file does;
+//     numbers are parsed as double and narrowed to float (= Python float() then the float32 feed);
+//   * formatter: "sampleinfo \t p0/(p0+p1) \t p1/(p0+p1) \t label \t kmer" with the float32
+//     shortest round-trip text numpy's str(np.float32) prints.
+// Host-only code (no HIP); compiled into libdeepsignal_hip.so.
+#include "../../include/deepsignal_hip.h"
+
+#include <algorithm>
+#include <atomic>
+#include <charconv>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+struct ds_tsv {
+    int fd = -1;
+    const char* data = nullptr;
+    size_t size = 0, pos = 0;
+    int kmer_len = 17, signal_len = 360, nthreads = 1;
+    int64_t line_no = 0;
+    std::string err;
+    // current batch
+    std::vector<int32_t> kmer, labels;
+    std::vector<float> means, stds, lens, signals;
+    std::vector<char> info;
+    std::vector<int64_t> info_off;
+    std::vector<std::pair<const char*, const char*>> lines;
+};
+
+namespace {
+
+inline const char* find_tab(const char* p, const char* e)
+{
+    const void* q = memchr(p, '\t', (size_t)(e - p));
+    return q ? (const char*)q : e;
+}
+
+// comma-separated list of exactly `count` numbers in [p, e)
+template <class Out>
+bool parse_list(const char* p, const char* e, int count, Out* out, bool as_int)
+{
+    for (int i = 0; i < count; ++i) {
+        if (p >= e) return false;
+        if (as_int) {
+            long v = 0;
+            auto r = std::from_chars(p, e, v);
+            if (r.ec != std::errc()) return false;
+            out[i] = (Out)v;
+            p = r.ptr;
+        } else {
+            double v = 0;
+            if (*p == '+') ++p;
+            auto r = std::from_chars(p, e, v);
+            if (r.ec != std::errc()) return false;
+            out[i] = (Out)(float)v;                       // float64 -> float32, as the TF feed does
+            p = r.ptr;
+        }
+        if (i + 1 < count) {
+            if (p >= e || *p != ',') return false;
+            ++p;
+        }
+    }
+    return p == e;
+}
+
+int base_code(char c)
+{
+    switch (c) {     // process_utils.py:21
+    case 'A': return 0; case 'C': return 1; case 'G': return 2; case 'T': return 3; case 'N': return 4;
+    default: return -1;
+    }
+}
+
+// one row -> slot i of the batch arrays; returns false on a malformed row
+bool parse_row(ds_tsv* t, size_t i, const char* b, const char* e, int64_t* info_len)
+{
+    const char* col[13];
+    col[0] = b;
+    int nc = 1;
+    for (const char* p = b; p < e && nc < 13;) {
+        const char* q = find_tab(p, e);
+        if (q == e) break;
+        col[nc++] = q + 1;
+        p = q + 1;
+    }
+    if (nc != 12) return false;
+    col[12] = e + 1;
+    auto cb = [&](int c) { return col[c]; };
+    auto ce = [&](int c) { return col[c + 1] - 1; };
+    const int K = t->kmer_len, S = t->signal_len;
+    if (ce(6) - cb(6) != K) return false;
+    for (int k = 0; k < K; ++k) {
+        const int code = base_code(cb(6)[k]);
+        if (code < 0) return false;
+        t->kmer[i * K + k] = code;
+    }
+    if (!parse_list(cb(7), ce(7), K, &t->means[i * K], false)) return false;
+    if (!parse_list(cb(8), ce(8), K, &t->stds[i * K], false)) return false;
+    if (!parse_list(cb(9), ce(9), K, &t->lens[i * K], true)) return false;
+    if (!parse_list(cb(10), ce(10), S, &t->signals[i * S], false)) return false;
+    const char* le = ce(11);
+    while (le > cb(11) && (le[-1] == '\r' || le[-1] == ' ')) --le;
+    int lab = 0;
+    auto r = std::from_chars(cb(11), le, lab);
+    if (r.ec != std::errc() || r.ptr != le) return false;
+    t->labels[i] = lab;
+    *info_len = ce(5) - b;       // columns 0..5 joined by tabs, verbatim
+    return true;
+}
+
+// str(np.float32(x)): shortest digits that round-trip float32; positional for 1e-4 <= |x| < 1e16,
+// scientific otherwise (numpy's default float printing)
+int format_f32(float x, char* out)
+{
+    if (std::isnan(x)) { memcpy(out, "nan", 3); return 3; }
+    if (std::isinf(x)) { if (x < 0) { memcpy(out, "-inf", 4); return 4; } memcpy(out, "inf", 3); return 3; }
+    char buf[48];
+    auto r = std::to_chars(buf, buf + sizeof buf, x, std::chars_format::scientific);   // shortest round-trip
+    *r.ptr = 0;
+    // buf = [-]d[.ddd]e[+-]XX
+    char* p = buf;
+    int n = 0;
+    if (*p == '-') out[n++] = *p++;
+    char digits[24];
+    int nd = 0;
+    digits[nd++] = *p++;
+    if (*p == '.') { ++p; while (*p != 'e') digits[nd++] = *p++; }
+    ++p;   // 'e'
+    const int ex = atoi(p);
+    if (x == 0.0f) { memcpy(out + n, "0.0", 3); return n + 3; }
+    if (ex >= -4 && ex < 16) {
+        if (ex < 0) {
+            out[n++] = '0'; out[n++] = '.';
+            for (int i = 0; i < -ex - 1; ++i) out[n++] = '0';
+            for (int i = 0; i < nd; ++i) out[n++] = digits[i];
+        } else {
+            for (int i = 0; i <= ex; ++i) out[n++] = i < nd ? digits[i] : '0';
+            out[n++] = '.';
+            if (nd > ex + 1) for (int i = ex + 1; i < nd; ++i) out[n++] = digits[i];
+            else out[n++] = '0';
+        }
+        return n;
+    }
+    out[n++] = digits[0];
+    if (nd > 1) {                       // numpy prints '1e-05', not '1.0e-05'
+        out[n++] = '.';
+        for (int i = 1; i < nd; ++i) out[n++] = digits[i];
+    }
+    out[n++] = 'e';
+    out[n++] = ex < 0 ? '-' : '+';
+    const int ax = ex < 0 ? -ex : ex;
+    if (ax < 10) out[n++] = '0';
+    n += snprintf(out + n, 8, "%d", ax);
+    return n;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ds_tsv_open(const char* path, int32_t kmer_len, int32_t signal_len, int32_t nthreads, ds_tsv** out)
+{
+    if (!path || !out || kmer_len < 1 || signal_len < 1) return DS_ERR_INVALID;
+    *out = nullptr;
+    ds_tsv* t = new ds_tsv();
+    t->kmer_len = kmer_len; t->signal_len = signal_len;
+    t->nthreads = nthreads > 0 ? nthreads : std::max(1u, std::thread::hardware_concurrency());
+    t->fd = open(path, O_RDONLY);
+    if (t->fd < 0) { delete t; return DS_ERR_IO; }
+    struct stat st;
+    if (fstat(t->fd, &st) != 0) { close(t->fd); delete t; return DS_ERR_IO; }
+    t->size = (size_t)st.st_size;
+    if (t->size) {
+        void* m = mmap(nullptr, t->size, PROT_READ, MAP_PRIVATE, t->fd, 0);
+        if (m == MAP_FAILED) { close(t->fd); delete t; return DS_ERR_IO; }
+        madvise(m, t->size, MADV_SEQUENTIAL);
+        t->data = (const char*)m;
+    }
+    *out = t;
+    return DS_OK;
+}
+
+void ds_tsv_close(ds_tsv* t)
+{
+    if (!t) return;
+    if (t->data) munmap((void*)t->data, t->size);
+    if (t->fd >= 0) close(t->fd);
+    delete t;
+}
+
+const char* ds_tsv_error(const ds_tsv* t) { return t ? t->err.c_str() : "null reader"; }
+
+// Next queue item: all rows of the next `max_reads` reads (a read = maximal run of consecutive rows with the
+// same column 5). Returns the number of sites, 0 at end of file, negative on a malformed row.
+int64_t ds_tsv_next(ds_tsv* t, int32_t max_reads)
+{
+    if (!t || max_reads < 1) return DS_ERR_INVALID;
+    t->lines.clear();
+    const char* end = t->data + t->size;
+    const char* p = t->data + t->pos;
+    const char* prev_id = nullptr;
+    size_t prev_len = 0;
+    int reads = 0;
+    while (p < end) {
+        const char* nl = (const char*)memchr(p, '\n', (size_t)(end - p));
+        const char* le = nl ? nl : end;
+        const char* ltrim = le;
+        while (ltrim > p && (ltrim[-1] == '\r')) --ltrim;
+        if (ltrim == p) { p = nl ? nl + 1 : end; continue; }       // blank line
+        // read id = column 5 (0-based 4)
+        const char* c = p;
+        int tabs = 0;
+        while (tabs < 4 && c < ltrim) { c = find_tab(c, ltrim); if (c < ltrim) { ++c; ++tabs; } }
+        if (tabs < 4) { t->err = "row " + std::to_string(t->line_no + (int64_t)t->lines.size() + 1) + ": fewer than 5 columns"; return DS_ERR_IO; }
+        const char* ide = find_tab(c, ltrim);
+        const size_t idl = (size_t)(ide - c);
+        if (!prev_id || idl != prev_len || memcmp(c, prev_id, idl) != 0) {
+            if (prev_id) {
+                ++reads;
+                if (reads % max_reads == 0) break;                // this row starts the next item
+            }
+            prev_id = c; prev_len = idl;
+        }
+        t->lines.emplace_back(p, ltrim);
+        p = nl ? nl + 1 : end;
+    }
+    t->pos = (size_t)(p - t->data);
+    const size_t n = t->lines.size();
+    if (n == 0) return 0;
+    const int K = t->kmer_len, S = t->signal_len;
+    t->kmer.resize(n * K); t->means.resize(n * K); t->stds.resize(n * K); t->lens.resize(n * K);
+    t->signals.resize(n * S); t->labels.resize(n);
+    std::vector<int64_t> ilen(n);
+    std::atomic<size_t> next(0);
+    std::atomic<int64_t> bad(-1);
+    auto work = [&]() {
+        for (;;) {
+            const size_t i0 = next.fetch_add(64);
+            if (i0 >= n) break;
+            const size_t i1 = std::min(n, i0 + 64);
+            for (size_t i = i0; i < i1; ++i)
+                if (!parse_row(t, i, t->lines[i].first, t->lines[i].second, &ilen[i])) {
+                    int64_t exp = -1;
+                    bad.compare_exchange_strong(exp, (int64_t)i);
+                }
+        }
+    };
+    const int nt = (int)std::min<size_t>((size_t)t->nthreads, (n + 63) / 64);
+    if (nt <= 1) work();
+    else {
+        std::vector<std::thread> th;
+        for (int i = 0; i < nt; ++i) th.emplace_back(work);
+        for (auto& x : th) x.join();
+    }
+    if (bad.load() >= 0) {
+        t->err = "row " + std::to_string(t->line_no + bad.load() + 1) + ": malformed feature row";
+        return DS_ERR_IO;
+    }
+    t->info_off.resize(n + 1);
+    int64_t tot = 0;
+    for (size_t i = 0; i < n; ++i) { t->info_off[i] = tot; tot += ilen[i]; }
+    t->info_off[n] = tot;
+    t->info.resize((size_t)tot);
+    for (size_t i = 0; i < n; ++i) memcpy(t->info.data() + t->info_off[i], t->lines[i].first, (size_t)ilen[i]);
+    t->line_no += (int64_t)n;
+    return (int64_t)n;
+}
+
+const int32_t* ds_tsv_kmer(const ds_tsv* t) { return t->kmer.data(); }
+const float* ds_tsv_means(const ds_tsv* t) { return t->means.data(); }
+const float* ds_tsv_stds(const ds_tsv* t) { return t->stds.data(); }
+const float* ds_tsv_lens(const ds_tsv* t) { return t->lens.data(); }
+const float* ds_tsv_signals(const ds_tsv* t) { return t->signals.data(); }
+const int32_t* ds_tsv_labels(const ds_tsv* t) { return t->labels.data(); }
+const char* ds_tsv_info(const ds_tsv* t) { return t->info.data(); }
+const int64_t* ds_tsv_info_offsets(const ds_tsv* t) { return t->info_off.data(); }
+
+// Result rows of one batch (call_modifications.py:183-190). Returns bytes written (each row ends with '\n'),
+// or -(needed bytes) when `cap` is too small.
+int64_t ds_format_rows(int64_t n, const char* info, const int64_t* info_off, const float* act, int32_t class_num,
+                       const int32_t* pred, const int32_t* kmer, int32_t kmer_len, char* out, int64_t cap)
+{
+    if (n < 0 || !info || !info_off || !act || !pred || !kmer || !out || class_num < 2) return DS_ERR_INVALID;
+    const int64_t need = info_off[n] + n * (int64_t)(2 * 20 + 16 + kmer_len + 8);
+    if (need > cap) return -need;
+    static const char bases[5] = {'A', 'C', 'G', 'T', 'N'};
+    char* p = out;
+    for (int64_t i = 0; i < n; ++i) {
+        const int64_t il = info_off[i + 1] - info_off[i];
+        memcpy(p, info + info_off[i], (size_t)il);
+        p += il;
+        const float p0 = act[i * class_num], p1 = act[i * class_num + 1];
+        const float s = p0 + p1;                      // float32 arithmetic, as the reference's np.float32 scalars
+        *p++ = '\t'; p += format_f32(p0 / s, p);
+        *p++ = '\t'; p += format_f32(p1 / s, p);
+        *p++ = '\t'; p += snprintf(p, 16, "%d", pred[i]);
+        *p++ = '\t';
+        for (int k = 0; k < kmer_len; ++k) { const int c = kmer[i * kmer_len + k]; *p++ = (c >= 0 && c < 5) ? bases[c] : 'N'; }
+        *p++ = '\n';
+    }
+    return (int64_t)(p - out);
+}
+
+}  // extern "C"

@@ -24,6 +24,9 @@ EXPORTED_SYMBOLS = (
     "ds_finalize_weights", "ds_forward", "ds_forward_device", "ds_sync", "ds_alloc_host", "ds_free_host",
     "ds_get_intermediate", "ds_set_profiling", "ds_num_stages", "ds_get_stage", "ds_reset_stage_times",
     "ds_set_graph", "ds_num_kernels", "ds_get_kernel_stat",
+    # scope row f1 (host I/O)
+    "ds_tsv_open", "ds_tsv_close", "ds_tsv_error", "ds_tsv_next", "ds_tsv_kmer", "ds_tsv_means", "ds_tsv_stds",
+    "ds_tsv_lens", "ds_tsv_signals", "ds_tsv_labels", "ds_tsv_info", "ds_tsv_info_offsets", "ds_format_rows",
 )
 
 

@@ -105,6 +105,34 @@ int ds_num_kernels(ds_handle *h);
 int ds_get_kernel_stat(ds_handle *h, int32_t index, char *name, int32_t name_cap, int64_t *launches,
                        double *total_ms, double *flops);
 
+/* ---- scope row f1: native feature-TSV reader and result-row formatter (host code) -------------------
+ * Replaces _read_features_file (call_modifications.py:35-91): 12 tab-separated columns
+ * (extract_features.py:289-303), rows grouped by read id (column 5). ds_tsv_next() parses the rows of
+ * the next `max_reads` reads (= one queue item, f5_batch_num) with `nthreads` host threads and
+ * returns the number of sites (0 at end of file, negative on a malformed row; ds_tsv_error()). The
+ * accessors return the item's arrays, valid until the next ds_tsv_next(): kmer int32[n,kmer_len]
+ * (A,C,G,T,N -> 0..4), means/stds/lens float[n,kmer_len], signals float[n,signal_len], labels int32[n],
+ * and the verbatim first six columns ("sampleinfo") as one char buffer + int64 offsets[n+1]. */
+typedef struct ds_tsv ds_tsv;
+int ds_tsv_open(const char *path, int32_t kmer_len, int32_t signal_len, int32_t nthreads, ds_tsv **out);
+void ds_tsv_close(ds_tsv *t);
+const char *ds_tsv_error(const ds_tsv *t);
+int64_t ds_tsv_next(ds_tsv *t, int32_t max_reads);
+const int32_t *ds_tsv_kmer(const ds_tsv *t);
+const float *ds_tsv_means(const ds_tsv *t);
+const float *ds_tsv_stds(const ds_tsv *t);
+const float *ds_tsv_lens(const ds_tsv *t);
+const float *ds_tsv_signals(const ds_tsv *t);
+const int32_t *ds_tsv_labels(const ds_tsv *t);
+const char *ds_tsv_info(const ds_tsv *t);
+const int64_t *ds_tsv_info_offsets(const ds_tsv *t);
+/* Replaces the per-site formatting loop of _call_mods (call_modifications.py:183-190): rows
+ * "sampleinfo \t p0/(p0+p1) \t p1/(p0+p1) \t label \t kmer \n" with float32 arithmetic and the
+ * shortest round-trip float32 text str(np.float32) prints. Returns bytes written or -(bytes needed). */
+int64_t ds_format_rows(int64_t n, const char *info, const int64_t *info_off, const float *act,
+                       int32_t class_num, const int32_t *pred, const int32_t *kmer, int32_t kmer_len,
+                       char *out, int64_t cap);
+
 /* Use a captured hipGraph for the forward (default on). */
 int ds_set_graph(ds_handle *h, int32_t enable);
 

@@ -1,0 +1,130 @@
+"""CPU: the native TSV reader / row formatter (scope row f1) against the Python reader and
+formatter, which are themselves pinned byte-for-byte to the reference's harness (test_harness.py)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from deepsignal_amd import call_modifications as cm
+from deepsignal_amd import fastio, synth
+from deepsignal_amd.utils.process_utils import code2base_dna
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "harness_golden.json")
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _built():
+    import __graft_entry__ as g
+    g.build()
+
+
+def _write(path, rows):
+    with open(path, "w") as f:
+        f.write("\n".join(rows) + "\n")
+
+
+def _synthetic_rows(n, sites_per_read, seed):
+    feats = synth.synthetic_features(n, seed=seed)
+    rows = []
+    for i in range(n):
+        kmer = "".join(code2base_dna[int(c)] for c in feats["kmer"][i])
+        rows.append("\t".join([
+            "chr%d" % (i % 7), str(i * 13), "+-"[i % 2], str(10 ** 6 - i), "r%05d" % (i // sites_per_read), "tc"[i % 2], kmer,
+            ",".join(repr(float(np.float64(x))) for x in feats["means"][i]),
+            ",".join("%.6f" % x for x in feats["stds"][i]),
+            ",".join(str(int(x)) for x in feats["sanums"][i]),
+            ",".join("%.6f" % x for x in feats["signals"][i]), str(int(feats["labels"][i]))]))
+    return rows
+
+
+@pytest.mark.parametrize("f5_batch_num,nthreads", [(1, 1), (3, 4), (50, 0)])
+def test_reader_matches_python_reader(tmp_path, f5_batch_num, nthreads):
+    rows = _synthetic_rows(157, 5, seed=4)
+    path = str(tmp_path / "f.tsv")
+    _write(path, rows)
+    py_items = list(cm.iter_features_batches(path, f5_batch_num))
+    rd = fastio.FeatureReader(path, nthreads=nthreads)
+    items = list(rd.items(f5_batch_num))
+    rd.close()
+    assert len(items) == len(py_items)
+    for it, ref in zip(items, py_items):
+        assert it.sampleinfo() == ref[0]
+        assert np.array_equal(it.kmer, np.asarray(ref[1], np.int32))
+        assert np.array_equal(it.means, np.asarray(ref[2], np.float32))      # str -> float64 -> float32, bit-exact
+        assert np.array_equal(it.stds, np.asarray(ref[3], np.float32))
+        assert np.array_equal(it.lens, np.asarray(ref[4], np.float32))
+        assert np.array_equal(it.signals, np.asarray(ref[5], np.float32))
+        assert np.array_equal(it.labels, np.asarray(ref[6], np.int32))
+
+
+def test_reader_on_reference_golden_rows(tmp_path):
+    with open(GOLD) as f:
+        case = json.load(f)["cases"][0]
+    path = str(tmp_path / "g.tsv")
+    _write(path, case["tsv_rows"])
+    items = list(fastio.FeatureReader(path).items(case["f5_batch_num"]))
+    assert [len(i.labels) for i in items] == [q["n"] for q in case["queue_items"]]
+    for it, q in zip(items, case["queue_items"]):
+        assert it.sampleinfo() == q["sampleinfo"] and it.kmer.tolist() == q["kmers"] and it.labels.tolist() == q["labels"]
+
+
+def test_reader_edge_cases(tmp_path):
+    rows = _synthetic_rows(4, 2, seed=1)
+    p = str(tmp_path / "e.tsv")
+    with open(p, "w") as f:                       # blank lines, CRLF, no trailing newline
+        f.write(rows[0] + "\r\n\n" + rows[1] + "\n" + rows[2] + "\n" + rows[3])
+    items = list(fastio.FeatureReader(p).items(50))
+    assert len(items) == 1 and len(items[0].labels) == 4
+    empty = str(tmp_path / "empty.tsv")
+    open(empty, "w").close()
+    assert list(fastio.FeatureReader(empty).items(50)) == []
+    bad = str(tmp_path / "bad.tsv")
+    _write(bad, [rows[0], rows[1].replace(",", ";", 1)])
+    with pytest.raises(ValueError):
+        list(fastio.FeatureReader(bad).items(50))
+    with pytest.raises(IOError):
+        fastio.FeatureReader(str(tmp_path / "missing.tsv"))
+
+
+def test_float32_text_matches_numpy():
+    rng = np.random.default_rng(0)
+    vals = np.concatenate([
+        rng.uniform(0, 1, 4000), 10.0 ** rng.uniform(-12, 0, 4000), 1 - 10.0 ** rng.uniform(-8, -1, 2000),
+        [0.5, 1.0, 0.0, 1e-4, 9.9999e-5, 1e-5, 0.1, 1 / 3, 2 / 3, 1e-45, 3.4e38, 123456.78, 1e16, 9.99e15, 100.0]]).astype(np.float32)
+    n = len(vals)
+    act = np.stack([vals, np.zeros(n, np.float32)], axis=1)        # p0/(p0+0) = 1 or nan for 0 -> use direct ratio below
+    # drive the formatter so that column 7 prints exactly vals[i]: p0 = vals, p1 chosen with p0+p1 == 1 is not exact;
+    # instead check through identity rows: act = (v, 0) gives v/v = 1 -> not useful. Use the public path:
+    info = np.frombuffer(b"x" * n, np.uint8)
+    off = np.arange(n + 1, dtype=np.int64)
+    kmer = np.zeros((n, 1), np.int32)
+    pred = np.zeros(n, np.int32)
+    # p0 = v * 0.5, p1 = 0.5 * (2 - v)... keep it simple and exact: compare against the Python formatter itself
+    p0 = vals
+    p1 = rng.uniform(0, 1, n).astype(np.float32) + np.float32(1e-3)
+    act = np.stack([p0, p1], axis=1)
+    out = fastio.format_rows(info, off, act, pred, kmer).decode().splitlines()
+    for i in range(n):
+        a, b = act[i][0], act[i][1]
+        exp = "\t".join(["x", str(a / (a + b)), str(b / (a + b)), "0", "A"])
+        assert out[i] == exp, (i, out[i], exp)
+
+
+def test_formatter_matches_reference_rows():
+    with open(GOLD) as f:
+        cases = json.load(f)["cases"]
+    for case in cases:
+        rows_iter = iter(r for o in case["outputs"] for r in o["pred_str"])
+        calls = iter(case["session_calls"])
+        for q in case["queue_items"]:
+            n = q["n"]
+            info = "".join(q["sampleinfo"]).encode()
+            off = np.cumsum([0] + [len(s) for s in q["sampleinfo"]]).astype(np.int64)
+            kmer = np.asarray(q["kmers"], np.int32)
+            for s in range(0, n, case["batch_size"]):
+                e = min(n, s + case["batch_size"])
+                act = np.asarray(next(calls)["act"], np.float32)
+                pred = np.argmax(act, axis=1).astype(np.int32)
+                got = fastio.format_rows(np.frombuffer(info, np.uint8), off[s:e + 1], act, pred, kmer[s:e]).decode().splitlines()
+                assert got == [next(rows_iter) for _ in range(e - s)]
