@@ -69,6 +69,26 @@ def _read_features_file(features_file, features_batch_q, f5_batch_num=20):
     print("read_features process {} ending".format(os.getpid()))
 
 
+def _read_features_from_fast5s(fast5s, corrected_group, basecall_subgroup, normalize_method, motif_seqs, methyloc,
+                               chrom2len, kmer_len, raw_signals_len, methy_label, positions=None):
+    """fast5 files -> ONE queue item (reference call_modifications.py:94-122). Means / stds reach the
+    model un-rounded on this route, exactly as in the reference (:115-116)."""
+    from .extract_features import _extract_features
+    features_list, error = _extract_features(fast5s, corrected_group, basecall_subgroup, normalize_method, motif_seqs,
+                                             methyloc, chrom2len, kmer_len, raw_signals_len, methy_label, positions)
+    sampleinfo, kmers, base_means, base_stds, base_signal_lens, cent_signals, labels = [], [], [], [], [], [], []
+    for (chrom, pos, alignstrand, loc_in_ref, readname, strand, k_mer, signal_means, signal_stds, signal_lens,
+         kmer_cent_signals, f_methy_label) in features_list:
+        sampleinfo.append("\t".join([chrom, str(pos), alignstrand, str(loc_in_ref), readname, strand]))
+        kmers.append([base2code_dna[x] for x in k_mer])
+        base_means.append(signal_means)
+        base_stds.append(signal_stds)
+        base_signal_lens.append(signal_lens)
+        cent_signals.append(kmer_cent_signals)
+        labels.append(f_methy_label)
+    return [(sampleinfo, kmers, base_means, base_stds, base_signal_lens, cent_signals, labels)], error
+
+
 def _call_mods(features_batch: FeaturesBatch, engine, batch_size: int):
     """One queue item -> output rows. Reference: call_modifications.py:149-194.
 
@@ -151,8 +171,8 @@ def call_mods(input_path, model_path, result_file, kmer_len, cent_signals_len,
     a "next" row of the scope table."""
     start = time.time()
     if os.path.isdir(input_path):
-        raise NotImplementedError("fast5 directory input needs the feature extractor (scope row f2); "
-                                  "run `deepsignal extract` first and pass the feature file")
+        return _call_mods_from_fast5s(input_path, model_path, result_file, kmer_len, cent_signals_len, batch_size,
+                                      class_num, is_rnn, is_base, is_cnn, f5_args, engine)
     if f5_batch_num is None:
         f5_batch_num = f5_args[0] if f5_args else 50
     own = engine is None
@@ -207,5 +227,54 @@ def call_mods(input_path, model_path, result_file, kmer_len, cent_signals_len,
                 nsites += len(pred_str)
     if own:
         engine.close()
+    print("call_mods costs %.2f seconds.. (%d sites)" % (time.time() - start, nsites))
+    return nsites
+
+
+def _call_mods_from_fast5s(fast5_dir, model_path, result_file, kmer_len, cent_signals_len, batch_size, class_num,
+                           is_rnn, is_base, is_cnn, f5_args, engine=None):
+    """fast5-directory mode (reference call_modifications.py:431-448 + :300-414, single process):
+    batches of f5_batch_num files -> features on the host -> engine -> rows. Needs h5py for the HDF5 files."""
+    from . import extract_features as ef
+    (f5_batch_num, is_recursive, corrected_group, basecall_subgroup, is_dna, normalize_method, motifs, mod_loc,
+     methy_label, position_file, reference_path) = f5_args
+    start = time.time()
+    fast5s = ef.get_fast5s(fast5_dir, is_recursive)
+    print("{} fast5 files in total..".format(len(fast5s)))
+    motif_seqs = ef.get_motif_seqs(motifs, is_dna)
+    chrom2len = None
+    if reference_path is not None:
+        chrom2len, name = {}, None
+        with open(reference_path) as rf:                     # contig lengths (reference utils/ref_reader.py:7-13)
+            for line in rf:
+                if line.startswith(">"):
+                    name = line.strip()[1:].split(" ")[0]
+                    chrom2len[name] = 0
+                elif name is not None:
+                    chrom2len[name] += len(line.strip())
+    positions = None
+    if position_file is not None:
+        with open(position_file) as pf:
+            positions = set(ef.key_sep.join(l.strip().split("\t")[:3]) for l in pf)
+    own = engine is None
+    if own:
+        engine = make_engine(model_path, kmer_len, cent_signals_len, class_num, batch_size,
+                             is_cnn=is_cnn, is_rnn=is_rnn, is_base=is_base)
+    errors = nsites = 0
+    with open(result_file, "w") as wf:
+        for i in range(0, len(fast5s), f5_batch_num):
+            batches, err = _read_features_from_fast5s(fast5s[i:i + f5_batch_num], corrected_group, basecall_subgroup,
+                                                      normalize_method, motif_seqs, mod_loc, chrom2len, kmer_len,
+                                                      cent_signals_len, methy_label, positions)
+            errors += err
+            for fb in batches:
+                pred_str, _, _ = _call_mods(fb, engine, batch_size)
+                for row in pred_str:
+                    wf.write(row + "\n")
+                nsites += len(pred_str)
+            wf.flush()
+    if own:
+        engine.close()
+    print("%d of %d fast5 files failed.." % (errors, len(fast5s)))
     print("call_mods costs %.2f seconds.. (%d sites)" % (time.time() - start, nsites))
     return nsites

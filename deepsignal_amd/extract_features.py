@@ -1,0 +1,190 @@
+"""fast5 -> per-site features (scope row f2; stays host Python as the north star asks).
+
+From-scratch statement of the reference extractor
+(/root/reference/deepsignal/extract_features.py:35-72,121-286,289-303 and
+utils/process_utils.py:95-143): raw pA rescale -> MAD / z-score normalisation rounded to 6 dp ->
+per-base event slices -> motif scan -> per-site k-mer, means, stds, lengths and the 360 central
+signal samples -> the 12-column feature row.
+
+The numeric core works on plain arrays (`extract_read_features`), so it is testable without HDF5;
+reading tombo-resquiggled single-read fast5 files needs `h5py`, imported lazily.
+"""
+from __future__ import annotations
+
+import os
+import random
+from typing import Dict, Iterable, List, Optional, Sequence, Set, Tuple
+
+import numpy as np
+
+key_sep = "||"
+MAD_NORMAL_CONSISTENCY = 0.6744897501960817    # Phi^-1(3/4): statsmodels.robust.mad's default scale
+
+iupac_alphabets = {"A": ["A"], "T": ["T"], "C": ["C"], "G": ["G"], "R": ["A", "G"], "M": ["A", "C"], "S": ["C", "G"],
+                   "Y": ["C", "T"], "K": ["G", "T"], "W": ["A", "T"], "B": ["C", "G", "T"], "D": ["A", "G", "T"],
+                   "H": ["A", "C", "T"], "V": ["A", "C", "G"], "N": ["A", "C", "G", "T"]}
+iupac_alphabets_rna = {k: [("U" if b == "T" else b) for b in v] for k, v in iupac_alphabets.items() if k != "T"}
+iupac_alphabets_rna["U"] = ["U"]
+
+
+def get_motif_seqs(motifs: str, is_dna: bool = True) -> List[str]:
+    """'CG' / 'CHG,CHH' -> every concrete sequence of the IUPAC motifs (process_utils.py:113-143)."""
+    table = iupac_alphabets if is_dna else iupac_alphabets_rna
+    out: List[str] = []
+    for motif in motifs.strip().split(","):
+        seqs = [""]
+        for ch in motif.strip().upper():
+            seqs = [s + b for s in seqs for b in table[ch]]
+        out += seqs
+    return out
+
+
+def get_refloc_of_methysite_in_motif(seqstr: str, motifset: Iterable[str], methyloc_in_motif: int = 0) -> List[int]:
+    """0-based positions of the targeted base of every motif hit (process_utils.py:95-110)."""
+    motifset = set(motifset)
+    motiflen = len(next(iter(motifset)))
+    return [i + methyloc_in_motif for i in range(0, len(seqstr) - motiflen + 1) if seqstr[i:i + motiflen] in motifset]
+
+
+def _rescale_signals(rawsignals, scaling: float, offset: float) -> np.ndarray:
+    return np.array(scaling * (np.asarray(rawsignals) + offset), dtype=np.float64)     # extract_features.py:211-212
+
+
+def _mad(x: np.ndarray) -> float:
+    return float(np.median(np.abs(x - np.median(x))) / MAD_NORMAL_CONSISTENCY)
+
+
+def _normalize_signals(signals: np.ndarray, normalize_method: str = "mad") -> np.ndarray:
+    if normalize_method == "zscore":
+        sshift, sscale = np.mean(signals), float(np.std(signals))
+    elif normalize_method == "mad":
+        sshift, sscale = np.median(signals), _mad(signals)
+    else:
+        raise ValueError("normalize_method must be 'mad' or 'zscore'")
+    return np.around((signals - sshift) / sscale, decimals=6)          # extract_features.py:143-151
+
+
+def _get_central_signals(signals_list: Sequence[np.ndarray], rawsignal_num: int = 360):
+    """The rawsignal_num samples centred on the middle base (extract_features.py:154-190)."""
+    total = sum(len(x) for x in signals_list)
+    if total < rawsignal_num:
+        real = np.concatenate(signals_list)
+        return np.append(real, np.array([0] * (rawsignal_num - len(real))))
+    mid_loc = int((len(signals_list) - 1) / 2)
+    mid = signals_list[mid_loc]
+    if len(mid) >= rawsignal_num:       # ordered random subsample of the (very long) middle base
+        return [mid[x] for x in sorted(random.sample(range(len(mid)), rawsignal_num))]
+    left_len = (rawsignal_num - len(mid)) // 2
+    right_len = rawsignal_num - left_len
+    left = np.concatenate(signals_list[:mid_loc])
+    right = np.concatenate(signals_list[mid_loc:])
+    if left_len > len(left):
+        right_len += left_len - len(left)
+        left_len = len(left)
+    elif right_len > len(right):
+        left_len += right_len - len(right)
+        right_len = len(right)
+    assert right_len + left_len == rawsignal_num
+    if left_len == 0:
+        return right[:right_len]
+    return np.append(left[-left_len:], right[:right_len])
+
+
+def extract_read_features(raw_signal, starts, lengths, bases: str, scaling: float, offset: float, readname: str,
+                          strand: str, alignstrand: str, chrom: str, chrom_start: int, chromlen: Optional[int],
+                          motif_seqs: Iterable[str], methyloc: int, kmer_len: int, raw_signals_len: int,
+                          methy_label: int, normalize_method: str = "mad", positions: Optional[Set[str]] = None):
+    """All feature tuples of one read (the body of the reference's per-file loop, :225-280)."""
+    if kmer_len % 2 == 0:
+        raise ValueError("kmer_len must be odd")
+    num_bases = (kmer_len - 1) // 2
+    norm = _normalize_signals(_rescale_signals(raw_signal, scaling, offset), normalize_method)
+    signal_list = [norm[int(s):int(s) + int(l)] for s, l in zip(starts, lengths)]
+    genomeseq = bases
+    out = []
+    for loc in get_refloc_of_methysite_in_motif(genomeseq, set(motif_seqs), methyloc):
+        if not (num_bases <= loc < len(genomeseq) - num_bases):
+            continue
+        if alignstrand == "-":
+            pos = chrom_start + len(genomeseq) - 1 - loc
+            pos_in_strand = chromlen - 1 - pos if chromlen is not None else -1
+        else:
+            pos = chrom_start + loc
+            pos_in_strand = pos if chromlen is not None else -1
+        if positions is not None and key_sep.join([chrom, str(pos), alignstrand]) not in positions:
+            continue
+        k_mer = genomeseq[loc - num_bases:loc + num_bases + 1]
+        k_signals = signal_list[loc - num_bases:loc + num_bases + 1]
+        signal_lens = [len(x) for x in k_signals]
+        signal_means = [np.mean(x) for x in k_signals]
+        signal_stds = [np.std(x) for x in k_signals]
+        cent = _get_central_signals(k_signals, raw_signals_len)
+        out.append((chrom, pos, alignstrand, pos_in_strand, readname, strand, k_mer, signal_means, signal_stds,
+                    signal_lens, cent, methy_label))
+    return out
+
+
+def _features_to_str(features) -> str:
+    """One 12-column feature row (extract_features.py:289-303)."""
+    chrom, pos, alignstrand, pos_in_strand, readname, strand, k_mer, means, stds, lens, cent, label = features
+    return "\t".join([chrom, str(pos), alignstrand, str(pos_in_strand), readname, strand, k_mer,
+                      ",".join(str(x) for x in np.around(means, decimals=6)),
+                      ",".join(str(x) for x in np.around(stds, decimals=6)),
+                      ",".join(str(x) for x in lens), ",".join(str(x) for x in cent), str(label)])
+
+
+# ------------------------------------------------------------------ fast5 (HDF5) access, needs h5py
+def _read_fast5(path: str, corrected_group: str, basecall_subgroup: str):
+    """Schema of SURVEY.md Appendix C.4 (extract_features.py:35-72,75-140,193-208)."""
+    import h5py      # only needed for real fast5 input
+    with h5py.File(path, "r") as f:
+        read = list(f["Raw/Reads"].values())[0]
+        raw = read["Signal"][()]
+        rid = read.attrs["read_id"]
+        rid = rid.decode() if isinstance(rid, bytes) else str(rid)
+        ch = f["UniqueGlobalKey/channel_id"].attrs
+        scaling, offset = ch["range"] / ch["digitisation"], ch["offset"]
+        base = "/".join(["Analyses", corrected_group, basecall_subgroup])
+        ev = f[base + "/Events"]
+        rel = ev.attrs["read_start_rel_to_raw"]
+        starts = ev["start"].astype(np.int64) + int(rel)
+        lengths = ev["length"].astype(np.int64)
+        bases = "".join(b.decode("UTF-8") for b in ev["base"])
+        if base + "/Alignment" in f:
+            al = f[base + "/Alignment"].attrs
+            dec = lambda v: v.decode() if isinstance(v, bytes) else str(v)
+            info = (rid, "t" if basecall_subgroup.endswith("template") else "c", dec(al["mapped_strand"]),
+                    dec(al["mapped_chrom"]), int(al["mapped_start"]))
+        else:
+            info = ("", "", "", "", "")
+    return raw, starts, lengths, bases, scaling, offset, info
+
+
+def _extract_features(fast5s, corrected_group, basecall_subgroup, normalize_method, motif_seqs, methyloc, chrom2len,
+                      kmer_len, raw_signals_len, methy_label, positions):
+    """Reference signature (extract_features.py:215-286): -> (features_list, number of failed files)."""
+    if kmer_len % 2 == 0:
+        raise ValueError("kmer_len must be odd")
+    features_list, error = [], 0
+    for fp in fast5s:
+        try:
+            raw, starts, lengths, bases, scaling, offset, info = _read_fast5(fp, corrected_group, basecall_subgroup)
+            readname, strand, alignstrand, chrom, chrom_start = info
+            chromlen = None
+            if chrom2len is not None:
+                chromlen = chrom2len.get(chrom)
+                if chromlen is None:
+                    print("warning - chrom_name in fast5 not in provided reference genome!")
+            features_list += extract_read_features(raw, starts, lengths, bases, scaling, offset, readname, strand,
+                                                   alignstrand, chrom, chrom_start, chromlen, motif_seqs, methyloc,
+                                                   kmer_len, raw_signals_len, methy_label, normalize_method, positions)
+        except Exception:
+            error += 1
+    return features_list, error
+
+
+def get_fast5s(fast5_dir: str, is_recursive: bool = True) -> List[str]:
+    fast5_dir = os.path.abspath(fast5_dir)
+    if is_recursive:
+        return [os.path.join(r, f) for r, _, fs in os.walk(fast5_dir) for f in fs if f.endswith(".fast5")]
+    return ["/".join([fast5_dir, f]) for f in os.listdir(fast5_dir) if f.endswith(".fast5")]

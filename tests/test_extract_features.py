@@ -1,0 +1,67 @@
+"""CPU: scope row f2 — the from-scratch feature extractor against outputs of the REFERENCE extractor
+(tests/golden/make_extract_golden.py ran deepsignal/extract_features.py on synthetic fast5 files; the
+raw arrays of every read are committed, so no HDF5 library is needed here)."""
+import json
+import os
+import random
+
+import numpy as np
+import pytest
+
+from deepsignal_amd import extract_features as ef
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "extract_golden.json")
+
+
+@pytest.fixture(scope="module")
+def gold():
+    with open(GOLD) as f:
+        return json.load(f)
+
+
+@pytest.mark.parametrize("idx", [0, 1, 2, 3])
+def test_feature_rows_match_reference(gold, idx):
+    case = gold["cases"][idx]
+    assert ef.get_motif_seqs(case["motifs"]) == case["motif_seqs"]
+    random.seed(case["seed"])          # the >= 360-sample middle-base branch draws from `random`
+    feats = []
+    for name in gold["read_order"]:
+        r = gold["reads"][name]
+        chromlen = None if case["chrom2len"] is None else case["chrom2len"].get(r["chrom"])
+        feats += ef.extract_read_features(
+            np.asarray(r["signal"], np.int16), r["starts"], r["lengths"], r["bases"], r["range"] / r["digitisation"],
+            r["offset"], r["read_id"], r["strand"], r["alignstrand"], r["chrom"], r["chrom_start"], chromlen,
+            case["motif_seqs"], 0, case["kmer_len"], case["signal_len"], 1, case["normalize_method"])
+    rows = [ef._features_to_str(f) for f in feats]
+    assert rows == case["features_str"]               # byte-identical 12-column rows, in the same order
+    for f, ref in zip(feats, case["features_head"]):
+        assert [f[0], int(f[1]), f[2], int(f[3]), f[4], f[5], f[6]] == ref[:7]
+        assert [float(x) for x in f[7]] == ref[7] and [float(x) for x in f[8]] == ref[8]      # un-rounded means / stds
+        assert [int(x) for x in f[9]] == ref[9] and int(f[11]) == ref[11]
+
+
+def test_rows_feed_the_call_mods_reader(gold, tmp_path):
+    """extract -> TSV -> reader: the produced rows parse back to the same numbers (6-dp contract)."""
+    from deepsignal_amd import call_modifications as cm
+    case = gold["cases"][0]
+    p = str(tmp_path / "features.tsv")
+    with open(p, "w") as f:
+        f.write("\n".join(case["features_str"]) + "\n")
+    items = list(cm.iter_features_batches(p, 2))
+    n = sum(len(it[0]) for it in items)
+    assert n == len(case["features_str"])
+    assert all(len(k) == 17 for it in items for k in it[1]) and all(len(s) == 360 for it in items for s in it[5])
+
+
+def test_helpers():
+    assert ef.get_motif_seqs("CG") == ["CG"] and sorted(ef.get_motif_seqs("CHG")) == ["CAG", "CCG", "CTG"]
+    assert ef.get_refloc_of_methysite_in_motif("ACGTCGA", {"CG"}, 0) == [1, 4]
+    x = np.array([1.0, 2.0, 4.0, 7.0, 100.0])
+    assert abs(ef._mad(x) - np.median(np.abs(x - 4.0)) / 0.6744897501960817) < 1e-15
+    with pytest.raises(ValueError):
+        ef._normalize_signals(x, "nope")
+    short = [np.arange(3.0), np.arange(4.0)]
+    c = ef._get_central_signals(short, 10)
+    assert list(c) == [0, 1, 2, 0, 1, 2, 3, 0, 0, 0]
+    with pytest.raises(ValueError):
+        ef.extract_read_features([0], [0], [1], "A", 1.0, 0.0, "r", "t", "+", "c", 0, None, ["CG"], 0, 16, 360, 1)

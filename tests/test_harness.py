@@ -81,8 +81,6 @@ def test_call_mods_end_to_end_file(cases, tmp_path):
     expect = [r for o in case["outputs"] for r in o["pred_str"]]
     assert n == len(expect)
     assert open(out).read().splitlines() == expect
-    with pytest.raises(NotImplementedError):
-        cm.call_mods(str(tmp_path), "unused", out, 17, 360, 4, 0.001, 2, 1, False, True, True, True, (2,), engine=eng)
 
 
 def test_writer_and_sentinel(tmp_path):
@@ -111,3 +109,40 @@ def test_cli_flag_surface():
     assert (a.corrected_group, a.basecall_subgroup, a.normalize_method, a.motifs, a.mod_loc) == \
         ("RawGenomeCorrected_000", "BaseCalled_template", "mad", "CG", 0)
     assert a.learning_rate == 0.001 and a.positions is None and a.reference_path is None
+
+
+def test_fast5_directory_mode(tmp_path, monkeypatch):
+    """call_mods on a fast5 directory (config 5 plumbing): files -> host extraction -> engine -> rows.
+    The HDF5 access is replaced by the committed raw arrays of the reference-run golden (h5py is not a
+    dependency of the test environment); the engine is a deterministic stand-in."""
+    from deepsignal_amd import extract_features as ef
+    with open(os.path.join(os.path.dirname(GOLD), "extract_golden.json")) as f:
+        g = json.load(f)
+    d = tmp_path / "f5"
+    d.mkdir()
+    for name in g["read_order"]:
+        (d / (name + ".fast5")).write_bytes(b"")
+    (d / "broken.fast5").write_bytes(b"")
+
+    def fake_read(path, corrected_group, basecall_subgroup):
+        r = g["reads"][os.path.basename(path)[:-6]]           # KeyError for broken.fast5 -> counted as failed
+        return (np.asarray(r["signal"], np.int16), r["starts"], r["lengths"], r["bases"], r["range"] / r["digitisation"],
+                r["offset"], (r["read_id"], r["strand"], r["alignstrand"], r["chrom"], r["chrom_start"]))
+
+    monkeypatch.setattr(ef, "_read_fast5", fake_read)
+
+    class Eng:
+        def run(self, kmer, means, stds, sanums, signals):
+            x = np.asarray(signals, np.float32)
+            assert x.shape[1] == 360 and np.asarray(means).shape == np.asarray(kmer).shape
+            act = np.stack([1 / (1 + np.exp(-x[:, 0])), 1 / (1 + np.exp(x[:, 1]))], axis=1).astype(np.float32)
+            return act, np.argmax(act, axis=1)
+
+    out = str(tmp_path / "r.tsv")
+    f5_args = (2, True, "RawGenomeCorrected_000", "BaseCalled_template", True, "mad", "CG", 0, 1, None, None)
+    n = cm.call_mods(str(d), "unused", out, 17, 360, 16, 0.001, 2, 1, False, True, True, True, f5_args, engine=Eng())
+    rows = [l.split("\t") for l in open(out).read().splitlines()]
+    case = g["cases"][1]                                      # same settings, no reference genome -> pos_in_strand = -1
+    assert n == len(rows) == len(case["features_str"])
+    expect = sorted("\t".join(r.split("\t")[:7]) for r in case["features_str"])
+    assert sorted("\t".join(r[:6] + [r[9]]) for r in rows) == expect
