@@ -138,6 +138,7 @@ struct ds_handle {
     float *fc1o = nullptr, *logits = nullptr, *act = nullptr;
     int* pred = nullptr;
 
+    bool debug_keep_pool = false;   // keep the stand-alone maxpool kernels (diagnostic)
     const float* zero_seg = nullptr;
     unsigned long long* dbg_stamps = nullptr;   // [NMOD][1024 wgs][2 waves][8] when DS_DEBUG_STAMPS is set
     std::vector<Stage> stages;
@@ -501,6 +502,7 @@ int build_plan(ds_handle* h, int n, Plan* plan)
     }
     const float* x = h->conv3o;
     int cin = 256;
+    int pend_pool_win = 0, pend_pool_pad = 0;      // a stride-2 maxpool waiting to be folded into the next fused module
     for (int m = 0; m < NMOD; ++m) {
         char nm[32];
         snprintf(nm, sizeof nm, "module%d", m + 1);
@@ -523,6 +525,8 @@ int build_plan(ds_handle* h, int n, Plan* plan)
             op.kind = OP_FUSED; op.stream = 0; op.stage = st;
             op.tm = (best_spt * W + 31) / 32;
             op.fa.X = x; op.fa.Y = y; op.fa.n_sites = n; op.fa.W = W; op.fa.cin = cin; op.fa.spt = best_spt;
+            op.fa.pool_win = pend_pool_win; op.fa.pool_pad = pend_pool_pad;
+            pend_pool_win = 0;
             op.fa.Bp1 = h->m_f1[m].Bp; op.fa.bias1 = h->m_f1[m].bias;
             op.fa.Bp3b = h->m_b3b[m].Bp; op.fa.bias3b = h->m_b3b[m].bias;
             op.fa.Bp4b = h->m_b4b[m].Bp; op.fa.bias4b = h->m_b4b[m].bias;
@@ -577,12 +581,18 @@ int build_plan(ds_handle* h, int n, Plan* plan)
         }
         x = y; cin = INC_OUT;
         if (m == 2 || m == 7) {   // maxpool_layer2/3                            layers.py:211-213,224-226
-            Op op{};
-            op.kind = OP_MAXPOOL; op.stream = 0; op.stage = stage_id(h, "pools", 0);
-            op.in = y; op.out = m == 2 ? h->pool2 : h->pool3;
-            op.a = W; op.b = m == 2 ? h->wb : h->wc; op.c = m == 2 ? h->pl_pool2 : h->pl_pool3; op.d = INC_OUT;
-            add_ew_op(cnn, op);
-            x = op.out;
+            const int wout = m == 2 ? h->wb : h->wc, pad = m == 2 ? h->pl_pool2 : h->pl_pool3;
+            static const bool no_fused2 = getenv("DS_NO_FUSED") != nullptr;
+            if (!no_fused2 && wout <= 96 && !h->debug_keep_pool) {
+                pend_pool_win = W; pend_pool_pad = pad;      // folded into module m+2's staging: no launch, no buffer
+            } else {
+                Op op{};
+                op.kind = OP_MAXPOOL; op.stream = 0; op.stage = stage_id(h, "pools", 0);
+                op.in = y; op.out = m == 2 ? h->pool2 : h->pool3;
+                op.a = W; op.b = wout; op.c = pad; op.d = INC_OUT;
+                add_ew_op(cnn, op);
+                x = op.out;
+            }
         }
     }
     {   // avgpool_layer1 + flatten                                              layers.py:233-238

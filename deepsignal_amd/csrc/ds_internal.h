@@ -85,6 +85,8 @@ struct FusedArgs {
     const float* X;      // [n_sites*W, cin] NWC input
     float* Y;            // [n_sites*W, 240] output (concat order b1|b2|b3|b4|b5)
     int n_sites, W, cin, spt;   // spt = sites per workgroup tile (whole sites only: taps never cross tiles)
+    int pool_win, pool_pad;     // pool_win > 0: X is [n_sites*pool_win, cin] and the module input is its
+                                // maxpool(3, stride 2, SAME) (pad_left = pool_pad), taken while staging (layers.py:211-213,224-226)
     const float* Bp1;    // packed [cin x 256]: columns b5s(48)|b2(48)|b3a(32)|b4a(32)|b5a(32)|b1(48, pooled input)|pad
     const float* bias1;  // [256]
     const float *Bp3b, *bias3b, *Bp4b, *bias4b, *Bp5b, *bias5b, *Bp5c, *bias5c;

@@ -572,7 +572,23 @@ __global__ __launch_bounds__(512, DS_FUSED_WPS) void inception_fused_kernel(cons
     const bool stager = tid < TR32 * 4;
     const int sr = tid >> 2, sq = tid & 3;
     const int rr = sr < TRv ? sr : TRv - 1;
-    const float* pc = a.X + (grow0 + rr) * cin + sq * 4;
+    // plain input: one row per staged row. Pooled input (modules right after maxpool_layer2/3): the staged
+    // row (site s, w) is the max of input rows 2w - pad + {0,1,2} of site s that exist (padded taps ignored).
+    const bool pooled_in = a.pool_win > 0;
+    const float *pc, *pq = nullptr, *pr = nullptr;
+    if (!pooled_in) {
+        pc = a.X + (grow0 + rr) * cin + sq * 4;
+    } else {
+        const int s_ = rr / W, w_ = rr % W;
+        const int i0 = 2 * w_ - a.pool_pad;
+        const int ia = i0 < 0 ? i0 + 1 : i0;                               // first existing tap
+        const int ib = i0 + 1 < a.pool_win ? (i0 + 1 < 0 ? ia : i0 + 1) : ia;
+        const int ic = i0 + 2 < a.pool_win ? i0 + 2 : ib;
+        const float* sb = a.X + ((size_t)(site0 + s_) * a.pool_win) * cin + sq * 4;
+        pc = sb + (size_t)ia * cin;
+        pq = sb + (size_t)ib * cin;
+        pr = sb + (size_t)ic * cin;
+    }
     const float* bp = a.Bp1 + ((size_t)wave * ((cin + 31) / 32 * 4) * 64 + lane) * 4;   // K padded to 32 in the pack
 
     floatx16 acc[TM];
@@ -605,7 +621,13 @@ __global__ __launch_bounds__(512, DS_FUSED_WPS) void inception_fused_kernel(cons
         float4 bq[2][2];
         float4 af[2][2][TM];
         auto load_a = [&](int X) {
-            if (stager) { vc[X] = gload4(pc); pc += KC; }
+            if (stager) {
+                vc[X] = gload4(pc); pc += KC;
+                if (pooled_in) {       // wave-uniform per launch
+                    vc[X] = f4max(f4max(vc[X], gload4(pq)), gload4(pr));
+                    pq += KC; pr += KC;
+                }
+            }
         };
         auto store_a = [&](int X) {
             if (stager) *reinterpret_cast<float4*>(Ad + X * TR32 * F_LDA + sr * F_LDA + sq * 4) = vc[X];
