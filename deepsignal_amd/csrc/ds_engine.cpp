@@ -97,6 +97,26 @@ struct Plan {
 
 }  // namespace
 
+// One in-flight forward: private workspace, stream pair, fork/join events and captured graphs.
+struct Slot {
+    hipStream_t s0 = nullptr, s1 = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    int* d_kmer = nullptr;
+    float *d_means = nullptr, *d_stds = nullptr, *d_sanums = nullptr, *d_signals = nullptr;
+    float *stem_pool = nullptr, *conv2o = nullptr, *conv3o = nullptr;
+    float* modout[NMOD] = {nullptr};
+    float *pool2 = nullptr, *pool3 = nullptr;
+    float *tmpA = nullptr, *tmpS = nullptr, *tmpB = nullptr;
+    float* sigfeat = nullptr;
+    float* H[2][NLAYER] = {{nullptr}};   // [T][B][256]
+    float* Cst[2][NLAYER] = {{nullptr}}; // [B][256]
+    float *fc1o = nullptr, *logits = nullptr, *act = nullptr;
+    int* pred = nullptr;
+
+    std::map<int, Plan> plans;
+    int last_n = 0;
+};
+
 struct ds_handle {
     ds_config cfg{};
     std::string err;
@@ -109,8 +129,6 @@ struct ds_handle {
     bool debug = false;
     int profiling = 0;    // 0 off | 1 one event pair per run of same-kernel launches on a stream | 2 per launch
     bool use_graph = true;
-    hipStream_t s0 = nullptr, s1 = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     std::map<std::string, HostTensor> host;
     std::vector<void*> allocs;
 
@@ -125,26 +143,17 @@ struct ds_handle {
     PackedGemm fc1;
     float* fc2 = nullptr;
 
-    // workspace
-    int* d_kmer = nullptr;
-    float *d_means = nullptr, *d_stds = nullptr, *d_sanums = nullptr, *d_signals = nullptr;
-    float *stem_pool = nullptr, *conv2o = nullptr, *conv3o = nullptr;
-    float* modout[NMOD] = {nullptr};
-    float *pool2 = nullptr, *pool3 = nullptr;
-    float *tmpA = nullptr, *tmpS = nullptr, *tmpB = nullptr;
-    float* sigfeat = nullptr;
-    float* H[2][NLAYER] = {{nullptr}};   // [T][B][256]
-    float* Cst[2][NLAYER] = {{nullptr}}; // [B][256]
-    float *fc1o = nullptr, *logits = nullptr, *act = nullptr;
-    int* pred = nullptr;
-
     bool debug_keep_pool = false;   // keep the stand-alone maxpool kernels (diagnostic)
     const float* zero_seg = nullptr;
     unsigned long long* dbg_stamps = nullptr;   // [NMOD][1024 wgs][2 waves][8] when DS_DEBUG_STAMPS is set
     std::vector<Stage> stages;
     KernelStat kstat[K_COUNT];
-    std::map<int, Plan> plans;
-    int last_n = 0;
+    // pipelining: consecutive forwards rotate over independent slots (own workspace, streams, graphs), so the
+    // dependency chain of one 512-site forward overlaps the next ones'; weights are shared
+    std::vector<Slot> slots;
+    Slot* cur = nullptr;
+    unsigned next_slot = 0;
+    bool stages_done = false;
 };
 
 namespace {
@@ -348,7 +357,7 @@ int finalize_weights(ds_handle* h)
                     std::vector<float> k0(kd, kd + (size_t)EMB * 4 * HID);
                     if ((rc = upload(h, &d_k0, k0))) return rc;
                     if ((rc = dalloc(h, &h->lstm_table[d], (size_t)VOCAB * 4 * HID))) return rc;
-                    HIPCHK(h, launch_embed_table(d_emb, d_k0, h->lstm_table[d], VOCAB, EMB, 4 * HID, h->s0));
+                    HIPCHK(h, launch_embed_table(d_emb, d_k0, h->lstm_table[d], VOCAB, EMB, 4 * HID, h->cur->s0));
                 }
                 std::vector<float> wf(kd + (size_t)(in0 - 3) * 4 * HID, kd + (size_t)in0 * 4 * HID);
                 if ((rc = upload(h, &h->lstm_wfeat[d], wf))) return rc;
@@ -369,7 +378,7 @@ int finalize_weights(ds_handle* h)
         h->fc1.bias = nullptr;
         if ((rc = upload(h, &h->fc2, w2->data))) return rc;
     }
-    HIPCHK(h, hipStreamSynchronize(h->s0));
+    HIPCHK(h, hipStreamSynchronize(h->cur->s0));
     h->host.clear();
     h->finalized = true;
     return DS_OK;
@@ -380,20 +389,20 @@ int alloc_workspace(ds_handle* h)
     const size_t B = h->B;
     int rc = 0;
     auto A = [&](auto** p, size_t count) { if (!rc) rc = dalloc(h, p, count); };
-    A(&h->d_kmer, B * h->T); A(&h->d_means, B * h->T); A(&h->d_stds, B * h->T); A(&h->d_sanums, B * h->T);
-    A(&h->d_signals, B * h->S);
-    A(&h->stem_pool, B * h->wa * 64); A(&h->conv2o, B * h->wa * 128); A(&h->conv3o, B * h->wa * 256);
-    A(&h->pool2, B * h->wb * INC_OUT); A(&h->pool3, B * h->wc * INC_OUT);
-    A(&h->tmpA, B * h->wa * 96); A(&h->tmpS, B * h->wa * 48); A(&h->tmpB, B * h->wa * 64);
-    A(&h->sigfeat, B * h->SF);
+    A(&h->cur->d_kmer, B * h->T); A(&h->cur->d_means, B * h->T); A(&h->cur->d_stds, B * h->T); A(&h->cur->d_sanums, B * h->T);
+    A(&h->cur->d_signals, B * h->S);
+    A(&h->cur->stem_pool, B * h->wa * 64); A(&h->cur->conv2o, B * h->wa * 128); A(&h->cur->conv3o, B * h->wa * 256);
+    A(&h->cur->pool2, B * h->wb * INC_OUT); A(&h->cur->pool3, B * h->wc * INC_OUT);
+    A(&h->cur->tmpA, B * h->wa * 96); A(&h->cur->tmpS, B * h->wa * 48); A(&h->cur->tmpB, B * h->wa * 64);
+    A(&h->cur->sigfeat, B * h->SF);
     for (int d = 0; d < 2; ++d)
-        for (int l = 0; l < NLAYER; ++l) { A(&h->H[d][l], (size_t)h->T * B * HID); A(&h->Cst[d][l], B * HID); }
-    A(&h->fc1o, B * h->J); A(&h->logits, B * h->C); A(&h->act, B * h->C); A(&h->pred, B);
+        for (int l = 0; l < NLAYER; ++l) { A(&h->cur->H[d][l], (size_t)h->T * B * HID); A(&h->cur->Cst[d][l], B * HID); }
+    A(&h->cur->fc1o, B * h->J); A(&h->cur->logits, B * h->C); A(&h->cur->act, B * h->C); A(&h->cur->pred, B);
     // module outputs: ping-pong pair normally; one buffer per module in debug mode (for taps)
     const int nbuf = h->debug ? NMOD : 2;
     float* bufs[NMOD] = {nullptr};
     for (int i = 0; i < nbuf; ++i) A(&bufs[i], B * h->wa * INC_OUT);
-    for (int m = 0; m < NMOD; ++m) h->modout[m] = bufs[h->debug ? m : (m & 1)];
+    for (int m = 0; m < NMOD; ++m) h->cur->modout[m] = bufs[h->debug ? m : (m & 1)];
     return rc;
 }
 
@@ -458,7 +467,7 @@ int build_plan(ds_handle* h, int n, Plan* plan)
     g_zero_seg = h->zero_seg;
     std::vector<Op> cnn, rnn;
     auto& LS = plan->launches;
-    const bool first_plan = h->plans.empty();
+    const bool first_plan = !h->stages_done;
     auto add_gemm_op = [&](std::vector<Op>& list, int stream, int stage, GemmCfg cfg, const GemmLaunch& L) {
         Op op{};
         op.kind = OP_GEMM; op.stream = stream; op.stage = stage; op.cfg = cfg;
@@ -482,25 +491,25 @@ int build_plan(ds_handle* h, int n, Plan* plan)
     st = stage_id(h, "stem", 0);
     {
         Op op{};
-        op.kind = OP_STEM1; op.stream = 0; op.stage = st; op.in = h->d_signals; op.out = h->stem_pool;
+        op.kind = OP_STEM1; op.stream = 0; op.stage = st; op.in = h->cur->d_signals; op.out = h->cur->stem_pool;
         op.flops = 2.0 * h->w1 * 7 * 64 * n;
         add_ew_op(cnn, op);
         if (first_plan) h->stages[st].flops_per_site += 2.0 * h->w1 * 7 * 64;
         const int M = n * h->wa;
         GemmLaunch L{};
         GemmProblem P = base_problem(M, 128, h->wa, h->conv2);                 // conv_layer2 1x1 (layers.py:192-197)
-        add_seg(P, h->stem_pool, 64, 0, 64);
-        add_out(P, h->conv2o, 128, 0, 128, 1);
+        add_seg(P, h->cur->stem_pool, 64, 0, 64);
+        add_out(P, h->cur->conv2o, 128, 0, 128, 1);
         add_tiles(L, P, CFG_CONV);
         add_gemm_op(cnn, 0, st, CFG_CONV, L);
         GemmLaunch L3{};
         GemmProblem P3 = base_problem(M, 256, h->wa, h->conv3);                // conv_layer3 1x3 (layers.py:198-203)
-        for (int t = 0; t < 3; ++t) add_seg(P3, h->conv2o, 128, t - 1, 128);
-        add_out(P3, h->conv3o, 256, 0, 256, 1);
+        for (int t = 0; t < 3; ++t) add_seg(P3, h->cur->conv2o, 128, t - 1, 128);
+        add_out(P3, h->cur->conv3o, 256, 0, 256, 1);
         add_tiles(L3, P3, CFG_CONV);
         add_gemm_op(cnn, 0, st, CFG_CONV, L3);
     }
-    const float* x = h->conv3o;
+    const float* x = h->cur->conv3o;
     int cin = 256;
     int pend_pool_win = 0, pend_pool_pad = 0;      // a stride-2 maxpool waiting to be folded into the next fused module
     for (int m = 0; m < NMOD; ++m) {
@@ -508,7 +517,7 @@ int build_plan(ds_handle* h, int n, Plan* plan)
         snprintf(nm, sizeof nm, "module%d", m + 1);
         st = stage_id(h, nm, 0);
         const int W = module_width(h, m), M = n * W;
-        float* y = h->modout[m];
+        float* y = h->cur->modout[m];
         static const bool no_fused = getenv("DS_NO_FUSED") != nullptr;
         if (!no_fused && W <= 96) {
             // one fused launch per module; tile = spt whole sites (<= 96 rows). Pick the spt that
@@ -542,8 +551,8 @@ int build_plan(ds_handle* h, int n, Plan* plan)
             GemmProblem P = base_problem(M, 192, W, h->m_s1[m]);
             add_seg(P, x, cin, 0, cin);
             add_out(P, y + 48, INC_OUT, 0, 48, 1);          // branch2
-            add_out(P, h->tmpS, 48, 48, 48, 0);             // branch5 stem (BN, no ReLU)
-            add_out(P, h->tmpA, 96, 96, 96, 1);             // b3a | b4a | b5a
+            add_out(P, h->cur->tmpS, 48, 48, 48, 0);             // branch5 stem (BN, no ReLU)
+            add_out(P, h->cur->tmpA, 96, 96, 96, 1);             // b3a | b4a | b5a
             add_tiles(L, P, CFG_CONV);
             add_gemm_op(cnn, 0, st, CFG_CONV, L);
             GemmLaunch L1{};
@@ -557,24 +566,24 @@ int build_plan(ds_handle* h, int n, Plan* plan)
         {   // second-stage convs from the 32-channel intermediates             layers.py:106-110,115-119,127-131
             GemmLaunch L{};
             GemmProblem P = base_problem(M, 48, W, h->m_b3b[m]);
-            for (int t = 0; t < 3; ++t) add_seg(P, h->tmpA + 0, 96, t - 1, 32);
+            for (int t = 0; t < 3; ++t) add_seg(P, h->cur->tmpA + 0, 96, t - 1, 32);
             add_out(P, y + 96, INC_OUT, 0, 48, 1);
             add_tiles(L, P, CFG_CONV);
             GemmProblem Q = base_problem(M, 48, W, h->m_b4b[m]);
-            for (int t = 0; t < 5; ++t) add_seg(Q, h->tmpA + 32, 96, t - 2, 32);
+            for (int t = 0; t < 5; ++t) add_seg(Q, h->cur->tmpA + 32, 96, t - 2, 32);
             add_out(Q, y + 144, INC_OUT, 0, 48, 1);
             add_tiles(L, Q, CFG_CONV);
             GemmProblem R = base_problem(M, 64, W, h->m_b5b[m]);
-            for (int t = 0; t < 3; ++t) add_seg(R, h->tmpA + 64, 96, t - 1, 32);
-            add_out(R, h->tmpB, 64, 0, 64, 1);
+            for (int t = 0; t < 3; ++t) add_seg(R, h->cur->tmpA + 64, 96, t - 1, 32);
+            add_out(R, h->cur->tmpB, 64, 0, 64, 1);
             add_tiles(L, R, CFG_CONV);
             add_gemm_op(cnn, 0, st, CFG_CONV, L);
         }
         {   // residual tail: relu(stem + BN(1x1 48 of tmpB))                    layers.py:132-138
             GemmLaunch L{};
             GemmProblem P = base_problem(M, 48, W, h->m_b5c[m]);
-            add_seg(P, h->tmpB, 64, 0, 64);
-            add_out(P, y + 192, INC_OUT, 0, 48, 1, h->tmpS, 48);
+            add_seg(P, h->cur->tmpB, 64, 0, 64);
+            add_out(P, y + 192, INC_OUT, 0, 48, 1, h->cur->tmpS, 48);
             add_tiles(L, P, CFG_CONV);
             add_gemm_op(cnn, 0, st, CFG_CONV, L);
         }
@@ -588,7 +597,7 @@ int build_plan(ds_handle* h, int n, Plan* plan)
             } else {
                 Op op{};
                 op.kind = OP_MAXPOOL; op.stream = 0; op.stage = stage_id(h, "pools", 0);
-                op.in = y; op.out = m == 2 ? h->pool2 : h->pool3;
+                op.in = y; op.out = m == 2 ? h->cur->pool2 : h->cur->pool3;
                 op.a = W; op.b = wout; op.c = pad; op.d = INC_OUT;
                 add_ew_op(cnn, op);
                 x = op.out;
@@ -598,7 +607,7 @@ int build_plan(ds_handle* h, int n, Plan* plan)
     {   // avgpool_layer1 + flatten                                              layers.py:233-238
         Op op{};
         op.kind = OP_AVGPOOL; op.stream = 0; op.stage = stage_id(h, "pools", 0);
-        op.in = x; op.out = h->sigfeat; op.a = h->wc; op.d = INC_OUT;
+        op.in = x; op.out = h->cur->sigfeat; op.a = h->wc; op.d = INC_OUT;
         add_ew_op(cnn, op);
     }
     }   // is_cnn
@@ -620,13 +629,13 @@ int build_plan(ds_handle* h, int n, Plan* plan)
                 const int t = dir == 0 ? s : T - 1 - s;
                 const int tprev = dir == 0 ? t - 1 : t + 1;
                 GemmProblem P = base_problem(n, 4 * HID, n, h->lstm[dir][l]);
-                if (l > 0) add_seg(P, h->H[dir][l - 1] + (size_t)t * h->B * HID, HID, 0, HID);
-                if (s > 0) add_seg(P, h->H[dir][l] + (size_t)tprev * h->B * HID, HID, 0, HID);
+                if (l > 0) add_seg(P, h->cur->H[dir][l - 1] + (size_t)t * h->B * HID, HID, 0, HID);
+                if (s > 0) add_seg(P, h->cur->H[dir][l] + (size_t)tprev * h->B * HID, HID, 0, HID);
                 P.lstm.table = l == 0 ? h->lstm_table[dir] : nullptr;
                 P.lstm.wfeat = h->lstm_wfeat[dir];
-                P.lstm.codes = h->d_kmer; P.lstm.means = h->d_means; P.lstm.stds = h->d_stds; P.lstm.lens = h->d_sanums;
-                P.lstm.c = h->Cst[dir][l];
-                P.lstm.h_out = h->H[dir][l] + (size_t)t * h->B * HID;
+                P.lstm.codes = h->cur->d_kmer; P.lstm.means = h->cur->d_means; P.lstm.stds = h->cur->d_stds; P.lstm.lens = h->cur->d_sanums;
+                P.lstm.c = h->cur->Cst[dir][l];
+                P.lstm.h_out = h->cur->H[dir][l] + (size_t)t * h->B * HID;
                 P.lstm.t = t; P.lstm.T = T; P.lstm.c_zero = s == 0; P.lstm.use_feat = l == 0;
                 add_tiles(L, P, lstm_cfg);
             }
@@ -641,11 +650,11 @@ int build_plan(ds_handle* h, int n, Plan* plan)
         GemmProblem P = base_problem(n, h->J, n, h->fc1);
         // joint = [fw h(T-1) | bw h(0) | signal features]: three A segments, no concat buffer (layers.py:171-172,250-252)
         if (h->is_rnn) {
-            add_seg(P, h->H[0][NLAYER - 1] + (size_t)(T - 1) * h->B * HID, HID, 0, HID);
-            add_seg(P, h->H[1][NLAYER - 1] + 0, HID, 0, HID);
+            add_seg(P, h->cur->H[0][NLAYER - 1] + (size_t)(T - 1) * h->B * HID, HID, 0, HID);
+            add_seg(P, h->cur->H[1][NLAYER - 1] + 0, HID, 0, HID);
         }
-        if (h->is_cnn) add_seg(P, h->sigfeat, h->SF, 0, h->SF);
-        add_out(P, h->fc1o, h->J, 0, h->J, 0);
+        if (h->is_cnn) add_seg(P, h->cur->sigfeat, h->SF, 0, h->SF);
+        add_out(P, h->cur->fc1o, h->J, 0, h->J, 0);
         add_tiles(L, P, fc_cfg);
         add_gemm_op(tail, 0, st, fc_cfg, L);
     }
@@ -694,7 +703,7 @@ int issue_op(ds_handle* h, Plan& plan, const Op& op, hipStream_t s)
         HIPCHK(h, launch_inception_fused(op.tm, op.fa, s));
         break;
     case OP_HEAD:
-        HIPCHK(h, launch_head(h->fc1o, h->fc2, h->logits, h->act, h->pred, n, h->J, h->C, s));
+        HIPCHK(h, launch_head(h->cur->fc1o, h->fc2, h->cur->logits, h->cur->act, h->cur->pred, n, h->J, h->C, s));
         break;
     }
     return DS_OK;
@@ -706,14 +715,14 @@ int kernel_class(const Op& op);
 
 int enqueue_forward(ds_handle* h, Plan& plan, int timed)
 {
-    HIPCHK(h, hipEventRecord(h->ev_fork, h->s0));
-    HIPCHK(h, hipStreamWaitEvent(h->s1, h->ev_fork, 0));
+    HIPCHK(h, hipEventRecord(h->cur->ev_fork, h->cur->s0));
+    HIPCHK(h, hipStreamWaitEvent(h->cur->s1, h->cur->ev_fork, 0));
     bool joined = false;
     static const bool serial = getenv("DS_SERIAL") != nullptr;   // diagnostic: one stream, no overlap
     Op* head[2] = {nullptr, nullptr};       // open run per stream (timed == 1)
     auto close_run = [&](int si) -> int {
         if (head[si]) {
-            HIPCHK(h, hipEventRecord(head[si]->ev1, si == 0 ? h->s0 : h->s1));
+            HIPCHK(h, hipEventRecord(head[si]->ev1, si == 0 ? h->cur->s0 : h->cur->s1));
             head[si]->pending = true;
             head[si] = nullptr;
         }
@@ -721,13 +730,13 @@ int enqueue_forward(ds_handle* h, Plan& plan, int timed)
     };
     for (Op& op : plan.ops) {
         const int si = (op.stream == 0 || serial) ? 0 : 1;
-        hipStream_t s = si == 0 ? h->s0 : h->s1;
+        hipStream_t s = si == 0 ? h->cur->s0 : h->cur->s1;
         const bool is_tail = h->stages[op.stage].name == "fc1" || h->stages[op.stage].name == "head";
         if (is_tail && !joined) {
             int rc = close_run(0); if (rc) return rc;
             rc = close_run(1); if (rc) return rc;
-            HIPCHK(h, hipEventRecord(h->ev_join, h->s1));
-            HIPCHK(h, hipStreamWaitEvent(h->s0, h->ev_join, 0));
+            HIPCHK(h, hipEventRecord(h->cur->ev_join, h->cur->s1));
+            HIPCHK(h, hipStreamWaitEvent(h->cur->s0, h->cur->ev_join, 0));
             joined = true;
         }
         if (timed && !op.ev0) {
@@ -756,8 +765,8 @@ int enqueue_forward(ds_handle* h, Plan& plan, int timed)
     }
     { int rc = close_run(0); if (rc) return rc; rc = close_run(1); if (rc) return rc; }
     if (!joined) {
-        HIPCHK(h, hipEventRecord(h->ev_join, h->s1));
-        HIPCHK(h, hipStreamWaitEvent(h->s0, h->ev_join, 0));
+        HIPCHK(h, hipEventRecord(h->cur->ev_join, h->cur->s1));
+        HIPCHK(h, hipStreamWaitEvent(h->cur->s0, h->cur->ev_join, 0));
     }
     return DS_OK;
 }
@@ -780,7 +789,8 @@ int kernel_class(const Op& op)
 
 int collect_stage_times(ds_handle* h)
 {
-    for (auto& kv : h->plans)
+    for (Slot& sl : h->slots)
+      for (auto& kv : sl.plans)
         for (Op& op : kv.second.ops) {
             if (!op.pending) continue;
             HIPCHK(h, hipEventSynchronize(op.ev1));
@@ -796,12 +806,13 @@ int collect_stage_times(ds_handle* h)
 
 int get_plan(ds_handle* h, int n, Plan** out)
 {
-    auto it = h->plans.find(n);
-    if (it == h->plans.end()) {
+    auto it = h->cur->plans.find(n);
+    if (it == h->cur->plans.end()) {
         Plan p;
         int rc = build_plan(h, n, &p);
         if (rc) return rc;
-        it = h->plans.emplace(n, std::move(p)).first;
+        it = h->cur->plans.emplace(n, std::move(p)).first;
+        h->stages_done = true;
     }
     *out = &it->second;
     return DS_OK;
@@ -813,7 +824,7 @@ int run_resident(ds_handle* h, int n)
     Plan* plan = nullptr;
     int rc = get_plan(h, n, &plan);
     if (rc) return rc;
-    h->last_n = n;
+    h->cur->last_n = n;
     if (h->profiling) {
         rc = collect_stage_times(h);      // events of a previous profiled forward are reused below
         if (rc) return rc;
@@ -825,16 +836,16 @@ int run_resident(ds_handle* h, int n)
     if (h->use_graph) {
         if (!plan->graph) {
             hipGraph_t g = nullptr;
-            HIPCHK(h, hipStreamBeginCapture(h->s0, hipStreamCaptureModeThreadLocal));
+            HIPCHK(h, hipStreamBeginCapture(h->cur->s0, hipStreamCaptureModeThreadLocal));
             rc = enqueue_forward(h, *plan, 0);
-            hipError_t e = hipStreamEndCapture(h->s0, &g);
+            hipError_t e = hipStreamEndCapture(h->cur->s0, &g);
             if (rc) { if (g) hipGraphDestroy(g); return rc; }
             if (e != hipSuccess) return fail(h, DS_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
             e = hipGraphInstantiate(&plan->graph, g, nullptr, nullptr, 0);
             hipGraphDestroy(g);
             if (e != hipSuccess) return fail(h, DS_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e));
         }
-        HIPCHK(h, hipGraphLaunch(plan->graph, h->s0));
+        HIPCHK(h, hipGraphLaunch(plan->graph, h->cur->s0));
         return DS_OK;
     }
     return enqueue_forward(h, *plan, 0);
@@ -867,6 +878,8 @@ int ds_create(const ds_config* cfg, ds_handle** out)
     if (cfg->device < 0 || cfg->device >= ndev) return fail(nullptr, DS_ERR_INVALID, "device ordinal out of range");
     ds_handle* h = new ds_handle();
     h->cfg = *cfg;
+    h->slots.resize(1);
+    h->cur = &h->slots[0];
     h->T = cfg->kmer_len; h->S = cfg->signal_len; h->C = cfg->class_num;
     h->B = cfg->max_batch > 0 ? cfg->max_batch : 512;
     same_pad(h->S, 7, 2, &h->w1, &h->pl_conv1);
@@ -879,12 +892,21 @@ int ds_create(const ds_config* cfg, ds_handle** out)
     h->debug = cfg->reserved[0] != 0;
 #define CK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { fail(nullptr, DS_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); ds_destroy(h); return DS_ERR_HIP; } } while (0)
     CK(hipSetDevice(cfg->device));
-    CK(hipStreamCreateWithFlags(&h->s0, hipStreamNonBlocking));
-    CK(hipStreamCreateWithFlags(&h->s1, hipStreamNonBlocking));
-    CK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
-    CK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
+    // reserved[1] = forwards in flight (pipeline slots); 0 -> default
+    int nslots = cfg->reserved[1] > 0 ? cfg->reserved[1] : (getenv("DS_SLOTS") ? atoi(getenv("DS_SLOTS")) : (h->B <= 1024 ? 8 : 4));
+    nslots = std::max(1, std::min(nslots, 8));
+    h->slots.resize(nslots);
+    int rc = DS_OK;
+    for (Slot& sl : h->slots) {
+        h->cur = &sl;
+        CK(hipStreamCreateWithFlags(&sl.s0, hipStreamNonBlocking));
+        CK(hipStreamCreateWithFlags(&sl.s1, hipStreamNonBlocking));
+        CK(hipEventCreateWithFlags(&sl.ev_fork, hipEventDisableTiming));
+        CK(hipEventCreateWithFlags(&sl.ev_join, hipEventDisableTiming));
+        if (!rc) rc = alloc_workspace(h);
+    }
+    h->cur = &h->slots[0];
 #undef CK
-    int rc = alloc_workspace(h);
     if (!rc) {
         float* z = nullptr;
         rc = dalloc(h, &z, 64);
@@ -904,17 +926,19 @@ void ds_destroy(ds_handle* h)
 {
     if (!h) return;
     hipSetDevice(h->cfg.device);
-    if (h->s0) hipStreamSynchronize(h->s0);
-    if (h->s1) hipStreamSynchronize(h->s1);
-    for (auto& kv : h->plans)
-        if (kv.second.graph) hipGraphExecDestroy(kv.second.graph);
-    for (auto& kv : h->plans)
-        for (Op& op : kv.second.ops) { if (op.ev0) hipEventDestroy(op.ev0); if (op.ev1) hipEventDestroy(op.ev1); }
+    for (Slot& sl : h->slots) {
+        if (sl.s0) hipStreamSynchronize(sl.s0);
+        if (sl.s1) hipStreamSynchronize(sl.s1);
+        for (auto& kv : sl.plans) {
+            if (kv.second.graph) hipGraphExecDestroy(kv.second.graph);
+            for (Op& op : kv.second.ops) { if (op.ev0) hipEventDestroy(op.ev0); if (op.ev1) hipEventDestroy(op.ev1); }
+        }
+        if (sl.ev_fork) hipEventDestroy(sl.ev_fork);
+        if (sl.ev_join) hipEventDestroy(sl.ev_join);
+        if (sl.s0) hipStreamDestroy(sl.s0);
+        if (sl.s1) hipStreamDestroy(sl.s1);
+    }
     for (void* p : h->allocs) hipFree(p);
-    if (h->ev_fork) hipEventDestroy(h->ev_fork);
-    if (h->ev_join) hipEventDestroy(h->ev_join);
-    if (h->s0) hipStreamDestroy(h->s0);
-    if (h->s1) hipStreamDestroy(h->s1);
     delete h;
 }
 
@@ -981,24 +1005,28 @@ int ds_forward_device(ds_handle* h, int32_t n, const int32_t* d_kmer, const floa
     if (!d_kmer || !d_means || !d_stds || !d_sanums || !d_signals || !d_act || !d_pred)
         return fail(h, DS_ERR_INVALID, "null buffer");
     HIPCHK(h, hipSetDevice(h->cfg.device));
+    // next pipeline slot (profiling runs stay on slot 0 so the event statistics are coherent)
+    h->cur = &h->slots[h->profiling ? 0 : (h->next_slot++ % h->slots.size())];
     const size_t nt = (size_t)n * h->T;
-    HIPCHK(h, hipMemcpyAsync(h->d_kmer, d_kmer, nt * 4, hipMemcpyDeviceToDevice, h->s0));
-    HIPCHK(h, hipMemcpyAsync(h->d_means, d_means, nt * 4, hipMemcpyDeviceToDevice, h->s0));
-    HIPCHK(h, hipMemcpyAsync(h->d_stds, d_stds, nt * 4, hipMemcpyDeviceToDevice, h->s0));
-    HIPCHK(h, hipMemcpyAsync(h->d_sanums, d_sanums, nt * 4, hipMemcpyDeviceToDevice, h->s0));
-    HIPCHK(h, hipMemcpyAsync(h->d_signals, d_signals, (size_t)n * h->S * 4, hipMemcpyDeviceToDevice, h->s0));
+    HIPCHK(h, hipMemcpyAsync(h->cur->d_kmer, d_kmer, nt * 4, hipMemcpyDeviceToDevice, h->cur->s0));
+    HIPCHK(h, hipMemcpyAsync(h->cur->d_means, d_means, nt * 4, hipMemcpyDeviceToDevice, h->cur->s0));
+    HIPCHK(h, hipMemcpyAsync(h->cur->d_stds, d_stds, nt * 4, hipMemcpyDeviceToDevice, h->cur->s0));
+    HIPCHK(h, hipMemcpyAsync(h->cur->d_sanums, d_sanums, nt * 4, hipMemcpyDeviceToDevice, h->cur->s0));
+    HIPCHK(h, hipMemcpyAsync(h->cur->d_signals, d_signals, (size_t)n * h->S * 4, hipMemcpyDeviceToDevice, h->cur->s0));
     int rc = run_resident(h, n);
     if (rc) return rc;
-    HIPCHK(h, hipMemcpyAsync(d_act, h->act, (size_t)n * h->C * 4, hipMemcpyDeviceToDevice, h->s0));
-    HIPCHK(h, hipMemcpyAsync(d_pred, h->pred, (size_t)n * 4, hipMemcpyDeviceToDevice, h->s0));
+    HIPCHK(h, hipMemcpyAsync(d_act, h->cur->act, (size_t)n * h->C * 4, hipMemcpyDeviceToDevice, h->cur->s0));
+    HIPCHK(h, hipMemcpyAsync(d_pred, h->cur->pred, (size_t)n * 4, hipMemcpyDeviceToDevice, h->cur->s0));
     return DS_OK;
 }
 
 int ds_sync(ds_handle* h)
 {
     if (!h) return DS_ERR_INVALID;
-    HIPCHK(h, hipStreamSynchronize(h->s0));
-    HIPCHK(h, hipStreamSynchronize(h->s1));
+    for (Slot& sl : h->slots) {
+        HIPCHK(h, hipStreamSynchronize(sl.s0));
+        HIPCHK(h, hipStreamSynchronize(sl.s1));
+    }
     if (h->profiling) return collect_stage_times(h);
     return DS_OK;
 }
@@ -1014,16 +1042,17 @@ int ds_forward(ds_handle* h, int32_t n, const int32_t* kmer, const float* means,
     HIPCHK(h, hipSetDevice(h->cfg.device));
     for (int off = 0; off < n; off += h->B) {
         const int m = std::min(h->B, n - off);
+        h->cur = &h->slots[0];
         const size_t mt = (size_t)m * h->T, ot = (size_t)off * h->T;
-        HIPCHK(h, hipMemcpyAsync(h->d_kmer, kmer + ot, mt * 4, hipMemcpyHostToDevice, h->s0));
-        HIPCHK(h, hipMemcpyAsync(h->d_means, means + ot, mt * 4, hipMemcpyHostToDevice, h->s0));
-        HIPCHK(h, hipMemcpyAsync(h->d_stds, stds + ot, mt * 4, hipMemcpyHostToDevice, h->s0));
-        HIPCHK(h, hipMemcpyAsync(h->d_sanums, sanums + ot, mt * 4, hipMemcpyHostToDevice, h->s0));
-        HIPCHK(h, hipMemcpyAsync(h->d_signals, signals + (size_t)off * h->S, (size_t)m * h->S * 4, hipMemcpyHostToDevice, h->s0));
+        HIPCHK(h, hipMemcpyAsync(h->cur->d_kmer, kmer + ot, mt * 4, hipMemcpyHostToDevice, h->cur->s0));
+        HIPCHK(h, hipMemcpyAsync(h->cur->d_means, means + ot, mt * 4, hipMemcpyHostToDevice, h->cur->s0));
+        HIPCHK(h, hipMemcpyAsync(h->cur->d_stds, stds + ot, mt * 4, hipMemcpyHostToDevice, h->cur->s0));
+        HIPCHK(h, hipMemcpyAsync(h->cur->d_sanums, sanums + ot, mt * 4, hipMemcpyHostToDevice, h->cur->s0));
+        HIPCHK(h, hipMemcpyAsync(h->cur->d_signals, signals + (size_t)off * h->S, (size_t)m * h->S * 4, hipMemcpyHostToDevice, h->cur->s0));
         int rc = run_resident(h, m);
         if (rc) return rc;
-        HIPCHK(h, hipMemcpyAsync(act + (size_t)off * h->C, h->act, (size_t)m * h->C * 4, hipMemcpyDeviceToHost, h->s0));
-        HIPCHK(h, hipMemcpyAsync(pred + off, h->pred, (size_t)m * 4, hipMemcpyDeviceToHost, h->s0));
+        HIPCHK(h, hipMemcpyAsync(act + (size_t)off * h->C, h->cur->act, (size_t)m * h->C * 4, hipMemcpyDeviceToHost, h->cur->s0));
+        HIPCHK(h, hipMemcpyAsync(pred + off, h->cur->pred, (size_t)m * 4, hipMemcpyDeviceToHost, h->cur->s0));
         rc = ds_sync(h);
         if (rc) return rc;
     }
@@ -1041,7 +1070,7 @@ int ds_free_host(void* p) { return hipHostFree(p) == hipSuccess ? DS_OK : DS_ERR
 int64_t ds_get_intermediate(ds_handle* h, const char* name, float* out, int64_t capacity)
 {
     if (!h || !name || !out) return DS_ERR_INVALID;
-    const int n = h->last_n;
+    const int n = h->cur->last_n;
     if (n <= 0) return fail(h, DS_ERR_INVALID, "no forward has run");
     int rc = ds_sync(h);
     if (rc) return rc;
@@ -1051,17 +1080,17 @@ int64_t ds_get_intermediate(ds_handle* h, const char* name, float* out, int64_t 
         if (hipMemcpy(out, src, (size_t)count * 4, hipMemcpyDeviceToHost) != hipSuccess) return fail(h, DS_ERR_HIP, "hipMemcpy D2H");
         return count;
     };
-    if (s == "stem_pool") return copy(h->stem_pool, (int64_t)n * h->wa * 64);
-    if (s == "stem_conv2") return copy(h->conv2o, (int64_t)n * h->wa * 128);
-    if (s == "stem_conv3") return copy(h->conv3o, (int64_t)n * h->wa * 256);
-    if (s == "signal_feat") return copy(h->sigfeat, (int64_t)n * h->SF);
-    if (s == "fc1") return copy(h->fc1o, (int64_t)n * h->J);
-    if (s == "logits") return copy(h->logits, (int64_t)n * h->C);
+    if (s == "stem_pool") return copy(h->cur->stem_pool, (int64_t)n * h->wa * 64);
+    if (s == "stem_conv2") return copy(h->cur->conv2o, (int64_t)n * h->wa * 128);
+    if (s == "stem_conv3") return copy(h->cur->conv3o, (int64_t)n * h->wa * 256);
+    if (s == "signal_feat") return copy(h->cur->sigfeat, (int64_t)n * h->SF);
+    if (s == "fc1") return copy(h->cur->fc1o, (int64_t)n * h->J);
+    if (s == "logits") return copy(h->cur->logits, (int64_t)n * h->C);
     if (s.rfind("module", 0) == 0) {
         const int m = atoi(s.c_str() + 6) - 1;
         if (m < 0 || m >= NMOD) return fail(h, DS_ERR_INVALID, "bad module index");
         if (!h->debug && m < NMOD - 2) return fail(h, DS_ERR_INVALID, "module taps need debug mode (cfg.reserved[0]=1)");
-        return copy(h->modout[m], (int64_t)n * module_width(h, m) * INC_OUT);
+        return copy(h->cur->modout[m], (int64_t)n * module_width(h, m) * INC_OUT);
     }
     if (s.rfind("lstm_", 0) == 0 && s.size() == 10) {   // lstm_fw_l0: device layout [T][B][256] -> [n][T][256]
         const int d = s[5] == 'f' ? 0 : 1, l = s[9] - '0';
@@ -1069,7 +1098,7 @@ int64_t ds_get_intermediate(ds_handle* h, const char* name, float* out, int64_t 
         const int64_t count = (int64_t)n * h->T * HID;
         if (count > capacity) return fail(h, DS_ERR_INVALID, "capacity too small");
         std::vector<float> tmp((size_t)h->T * h->B * HID);
-        if (hipMemcpy(tmp.data(), h->H[d][l], tmp.size() * 4, hipMemcpyDeviceToHost) != hipSuccess) return fail(h, DS_ERR_HIP, "hipMemcpy D2H");
+        if (hipMemcpy(tmp.data(), h->cur->H[d][l], tmp.size() * 4, hipMemcpyDeviceToHost) != hipSuccess) return fail(h, DS_ERR_HIP, "hipMemcpy D2H");
         for (int i = 0; i < n; ++i)
             for (int t = 0; t < h->T; ++t)
                 memcpy(out + ((size_t)i * h->T + t) * HID, tmp.data() + ((size_t)t * h->B + i) * HID, HID * 4);
@@ -1097,9 +1126,9 @@ int64_t ds_get_intermediate(ds_handle* h, const char* name, float* out, int64_t 
         const int64_t count = (int64_t)n * h->J;
         if (count > capacity) return fail(h, DS_ERR_INVALID, "capacity too small");
         std::vector<float> fw((size_t)n * HID), bw((size_t)n * HID), sf((size_t)n * h->SF);
-        hipMemcpy(fw.data(), h->H[0][NLAYER - 1] + (size_t)(h->T - 1) * h->B * HID, fw.size() * 4, hipMemcpyDeviceToHost);
-        hipMemcpy(bw.data(), h->H[1][NLAYER - 1], bw.size() * 4, hipMemcpyDeviceToHost);
-        if (hipMemcpy(sf.data(), h->sigfeat, sf.size() * 4, hipMemcpyDeviceToHost) != hipSuccess) return fail(h, DS_ERR_HIP, "hipMemcpy D2H");
+        hipMemcpy(fw.data(), h->cur->H[0][NLAYER - 1] + (size_t)(h->T - 1) * h->B * HID, fw.size() * 4, hipMemcpyDeviceToHost);
+        hipMemcpy(bw.data(), h->cur->H[1][NLAYER - 1], bw.size() * 4, hipMemcpyDeviceToHost);
+        if (hipMemcpy(sf.data(), h->cur->sigfeat, sf.size() * 4, hipMemcpyDeviceToHost) != hipSuccess) return fail(h, DS_ERR_HIP, "hipMemcpy D2H");
         const int ev = h->is_rnn ? 2 * HID : 0;
         for (int i = 0; i < n; ++i) {
             if (h->is_rnn) {

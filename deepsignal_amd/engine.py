@@ -88,11 +88,12 @@ class Engine:
 
     def __init__(self, kmer_len: int = 17, signal_len: int = 360, class_num: int = 2, device: int = 0,
                  max_batch: int = 512, is_cnn: bool = True, is_rnn: bool = True, is_base: bool = True,
-                 debug: bool = False):
+                 debug: bool = False, slots: int = 0):
         self._lib = load_library()
         self._h = ctypes.c_void_p()
         cfg = DsConfig(kmer_len, signal_len, class_num, int(is_cnn), int(is_rnn), int(is_base), device, 0, max_batch)
         cfg.reserved[0] = 1 if debug else 0
+        cfg.reserved[1] = slots          # forwards in flight for run_device (0 = engine default)
         rc = self._lib.ds_create(ctypes.byref(cfg), ctypes.byref(self._h))
         if rc != 0:
             msg = self._lib.ds_last_error(None).decode()

@@ -43,7 +43,9 @@ typedef struct ds_config {
     int32_t device;       /* HIP device ordinal */
     int32_t precision;    /* DS_PRECISION_FP32 */
     int32_t max_batch;    /* largest n per device pass (workspaces are sized for it); larger n is looped */
-    int32_t reserved[7];  /* reserved[0] != 0: debug mode — keep every module output for ds_get_intermediate */
+    int32_t reserved[7];  /* reserved[0] != 0: debug mode — keep every module output for ds_get_intermediate;
+                             reserved[1]: forwards in flight for ds_forward_device (pipeline slots; default 8 for
+                             max_batch <= 1024, else 4; max 8) */
 } ds_config;
 
 /* Replaces Model(...) + tf.Session(): call_modifications.py:203-209. */
@@ -68,8 +70,11 @@ int ds_finalize_weights(ds_handle *h);
 int ds_forward(ds_handle *h, int32_t n, const int32_t *kmer, const float *means, const float *stds,
                const float *sanums, const float *signals, float *act, int32_t *pred);
 
-/* Same contract with every pointer in DEVICE memory of h's GPU (n <= max_batch). Asynchronous on
- * the handle's streams; ds_sync() waits. Used when features are already resident in HBM. */
+/* Same contract with every pointer in DEVICE memory of h's GPU (n <= max_batch). Asynchronous and
+ * PIPELINED: consecutive calls rotate over independent slots (own workspace, HIP streams and captured
+ * graph), so several forwards are in flight at once; inputs are staged and outputs written on the slot's
+ * stream, so keep both buffers untouched until ds_sync() returns. Used when features are already
+ * resident in HBM. */
 int ds_forward_device(ds_handle *h, int32_t n, const int32_t *d_kmer, const float *d_means,
                       const float *d_stds, const float *d_sanums, const float *d_signals,
                       float *d_act, int32_t *d_pred);
