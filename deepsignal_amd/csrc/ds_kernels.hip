@@ -50,7 +50,7 @@ __device__ __forceinline__ void gstore(float* p, float v) { *(gptr1w)(p) = v; }
 // accumulators are exchanged through LDS at the end. It doubles the waves per SIMD for grids that
 // only have ~one workgroup per CU and halves the serial chunk chain of short-K problems.
 template <int MT, int NT, int WM, int WN, int EPI, int AMODE, int BD, int KS>
-__global__ __launch_bounds__(64 * WM * WN * KS) void gemm_kernel(const GemmLaunch* __restrict__ L)
+__global__ __launch_bounds__(64 * WM * WN * KS, (EPI == 1 && KS == 1) ? 2 : 1) void gemm_kernel(const GemmLaunch* __restrict__ L)
 {
     constexpr int BM = WM * MT * 32;
     constexpr int LDA = KC + 4;
