@@ -161,3 +161,31 @@ def test_model_variants(variant):
         assert err <= INTERMEDIATE_RTOL * max(1.0, float(np.abs(ref).max())), (name, err)
     _check_outputs(act, pred, o_act, o_pred)
     eng.close()
+
+
+def test_pipelined_device_forwards_match_blocking(small_weights):
+    """ds_forward_device rotates over independent slots (several forwards in flight): every slot must give
+    bit-identical results to the blocking host path, in any interleaving."""
+    import torch
+    feats = synth.synthetic_features(4 * 512, seed=31)
+    eng = _engine(small_weights, max_batch=512, slots=5)
+    dev = torch.device("cuda", 0)
+    d = {k: torch.from_numpy(feats[k]).to(dev) for k in ("kmer", "means", "stds", "sanums", "signals")}
+    nstep = 13
+    out_act = torch.zeros((nstep, 512, 2), dtype=torch.float32, device=dev)
+    out_pred = torch.zeros((nstep, 512), dtype=torch.int32, device=dev)
+    for i in range(nstep):
+        b = (i % 4) * 512
+        eng.run_device(512, *(d[k][b:b + 512].data_ptr() for k in ("kmer", "means", "stds", "sanums", "signals")),
+                       out_act[i].data_ptr(), out_pred[i].data_ptr())
+    eng.sync()
+    ref = [eng.run(*(feats[k][j * 512:(j + 1) * 512] for k in ("kmer", "means", "stds", "sanums", "signals"))) for j in range(4)]
+    got_act, got_pred = out_act.cpu().numpy(), out_pred.cpu().numpy()
+    for i in range(nstep):
+        assert np.array_equal(got_act[i], ref[i % 4][0]) and np.array_equal(got_pred[i], ref[i % 4][1])
+    # spot-check the batch against the oracle too
+    from oracle import oracle
+    sub = {k: v[512:512 + 64] for k, v in feats.items()}
+    o_act, o_pred = oracle.forward(small_weights, sub, "f32")
+    _check_outputs(got_act[1][:64], got_pred[1][:64], o_act, o_pred)
+    eng.close()
