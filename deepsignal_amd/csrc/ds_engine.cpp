@@ -43,7 +43,7 @@ struct PackedGemm {      // device-resident packed weights of one GEMM
     int K = 0, N = 0;
 };
 
-enum OpKind { OP_GEMM, OP_STEM1, OP_MAXPOOL, OP_AVGPOOL, OP_HEAD, OP_FUSED };
+enum OpKind { OP_GEMM, OP_STEM1, OP_MAXPOOL, OP_AVGPOOL, OP_HEAD, OP_FUSED, OP_PACKEV };
 
 struct Op {
     OpKind kind;
@@ -66,12 +66,16 @@ struct Op {
 };
 
 // per-kernel accumulators (one entry per __global__ function / template instantiation)
-enum KernelClass { K_GEMM_CONV = 0, K_GEMM_FC, K_GEMM_LSTM, K_GEMM_CONV_WIDE, K_GEMM_CONV_POOL, K_GEMM_FC_DENSE, K_GEMM_LSTM_DENSE, K_FUSED1, K_FUSED2, K_FUSED3, K_STEM1, K_MAXPOOL, K_AVGPOOL, K_HEAD, K_COUNT };
+enum KernelClass { K_GEMM_CONV = 0, K_GEMM_FC, K_GEMM_LSTM, K_GEMM_CONV_WIDE, K_GEMM_CONV_POOL, K_GEMM_FC_DENSE, K_GEMM_LSTM_DENSE, K_FUSED1, K_FUSED2, K_FUSED3, K_STEM1, K_MAXPOOL, K_AVGPOOL, K_HEAD,
+                   K_GEMM_BCONV, K_GEMM_BCONV_POOL, K_GEMM_BFC, K_GEMM_BFC_DENSE, K_PACKEV, K_COUNT };
 const char* const kKernelNames[K_COUNT] = {"gemm_kernel<1,2,4,1,0,0,1,1>", "gemm_kernel<1,3,4,1,0,0,2,1>", "gemm_kernel<1,4,4,1,1,0,1,1>",
                                            "gemm_kernel<2,2,2,2,0,0,1,1>", "gemm_kernel<1,2,4,1,0,1,1,1>", "gemm_kernel<1,3,4,1,0,2,2,1>",
                                            "gemm_kernel<1,4,4,1,1,2,1,1>", "inception_fused_kernel<1>",
                                            "inception_fused_kernel<2>", "inception_fused_kernel<3>", "stem1_kernel",
-                                           "maxpool_s2_kernel", "avgpool7_kernel", "head_kernel"};
+                                           "maxpool_s2_kernel", "avgpool7_kernel", "head_kernel",
+                                           "gemm_kernel<1,2,4,1,0,0,1,1,bf16>", "gemm_kernel<1,2,4,1,0,1,1,1,bf16>",
+                                           "gemm_kernel<4,2,1,4,0,0,2,1,bf16>", "gemm_kernel<4,2,1,4,0,2,2,1,bf16>",
+                                           "pack_event_feat_bf16_kernel"};
 struct KernelStat {
     int64_t launches = 0;
     double total_ms = 0;
@@ -112,6 +116,7 @@ struct Slot {
     float* Cst[2][NLAYER] = {{nullptr}}; // [B][256]
     float *fc1o = nullptr, *logits = nullptr, *act = nullptr;
     int* pred = nullptr;
+    float* joint = nullptr;              // bf16 mode: [B][JP] bf16 FC operand (event features | signal features | zero pad)
 
     std::map<int, Plan> plans;
     int last_n = 0;
@@ -125,6 +130,8 @@ struct ds_handle {
     int pl_conv1 = 0, pl_pool1 = 0, pl_pool2 = 0, pl_pool3 = 0;
     int B = 512;
     bool is_cnn = true, is_rnn = true, is_base = true;   // model.py:28-29,59-75,89-95
+    bool bf16 = false;    // DS_PRECISION_BF16: bf16 conv + FC operands (fp32 accumulate), fp32 BiLSTM
+    int JP = 0;           // J rounded up to a whole K chunk (32 bf16)
     bool finalized = false;
     bool debug = false;
     int profiling = 0;    // 0 off | 1 one event pair per run of same-kernel launches on a stream | 2 per launch
@@ -212,6 +219,37 @@ std::vector<float> pack_b(int K, int N, const std::function<float(int, int)>& w_
     return out;
 }
 
+uint16_t f32_to_bf16(float f)      // round to nearest even, like v_cvt_pk_bf16_f32
+{
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);   // quiet NaN
+    u += 0x7fffu + ((u >> 16) & 1);
+    return (uint16_t)(u >> 16);
+}
+
+// bf16 operand packing, same byte geometry as pack_b: [ntile][kstep of 16][lane][8 bf16], lane (j, half) holds
+// W[kstep*16 + 8*half + s][ntile*32 + j], s = 0..7 (the v_mfma_f32_32x32x16_bf16 B fragment). K is padded with
+// zero rows to a multiple of 64 elements (= 32 four-byte units, like the fp32 packer).
+std::vector<float> pack_b_bf16(int K, int N, const std::function<float(int, int)>& w_in)
+{
+    const int Kp = (K + 63) / 64 * 64;
+    const int ntiles = (N + 31) / 32, ks = Kp / 16;
+    std::vector<uint16_t> out((size_t)ntiles * ks * 64 * 8, 0);
+    for (int nt = 0; nt < ntiles; ++nt)
+        for (int g = 0; g < ks; ++g)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int col = nt * 32 + (lane & 31);
+                if (col >= N) continue;
+                const int k0 = g * 16 + 8 * (lane >> 5);
+                uint16_t* o = &out[(((size_t)nt * ks + g) * 64 + lane) * 8];
+                for (int q = 0; q < 8; ++q) o[q] = k0 + q < K ? f32_to_bf16(w_in(k0 + q, col)) : 0;
+            }
+    std::vector<float> raw(out.size() / 2);
+    memcpy(raw.data(), out.data(), out.size() * 2);
+    return raw;
+}
+
 struct FoldedConv {     // BN folded into the kernel: y = conv(x, w') + b'   (layers.py:80-84)
     int k, cin, cout;
     std::vector<float> w;   // [k*cin][cout]
@@ -261,13 +299,16 @@ int upload_concat(ds_handle* h, const std::vector<const FoldedConv*>& parts, Pac
         for (int c = 0; c < parts[i]->cout; ++c) { owner[c0 + c] = (int)i; local[c0 + c] = c; }
         c0 += parts[i]->cout;
     }
-    std::vector<float> packed = pack_b(K, N, [&](int k, int col) {
+    auto wfun = [&](int k, int col) {
         const FoldedConv* p = parts[owner[col]];
         return p->w[(size_t)k * p->cout + local[col]];
-    });
+    };
+    // bf16 mode: the module input rows are stored with 256-channel pitch, so a cin = 240 operand is padded to 256
+    // zero rows by the packer; K is then counted in 4-byte units (two bf16), see ds_kernels.hip
+    std::vector<float> packed = h->bf16 ? pack_b_bf16(K, N, wfun) : pack_b(K, N, wfun);
     std::vector<float> bias((N + 31) / 32 * 32, 0.0f);
     for (int col = 0; col < N; ++col) bias[col] = parts[owner[col]]->b[local[col]];
-    pg->K = K; pg->N = N;
+    pg->K = h->bf16 ? (K + 1) / 2 : K; pg->N = N;
     int rc = upload(h, &pg->Bp, packed);
     if (rc) return rc;
     return upload(h, &pg->bias, bias);
@@ -372,8 +413,9 @@ int finalize_weights(ds_handle* h)
         return fail(h, DS_ERR_INVALID, "missing/bad dense kernels");
     {
         const float* wd = w1->data.data();
-        std::vector<float> packed = pack_b(J, J, [&](int k, int col) { return wd[(size_t)k * J + col]; });
-        h->fc1.K = J; h->fc1.N = J;
+        auto wfun = [&](int k, int col) { return wd[(size_t)k * J + col]; };
+        std::vector<float> packed = h->bf16 ? pack_b_bf16(J, J, wfun) : pack_b(J, J, wfun);
+        h->fc1.K = h->bf16 ? h->JP / 2 : J; h->fc1.N = J;
         if ((rc = upload(h, &h->fc1.Bp, packed))) return rc;
         h->fc1.bias = nullptr;
         if ((rc = upload(h, &h->fc2, w2->data))) return rc;
@@ -398,11 +440,21 @@ int alloc_workspace(ds_handle* h)
     for (int d = 0; d < 2; ++d)
         for (int l = 0; l < NLAYER; ++l) { A(&h->cur->H[d][l], (size_t)h->T * B * HID); A(&h->cur->Cst[d][l], B * HID); }
     A(&h->cur->fc1o, B * h->J); A(&h->cur->logits, B * h->C); A(&h->cur->act, B * h->C); A(&h->cur->pred, B);
+    if (h->bf16) A(&h->cur->joint, B * (size_t)h->JP / 2);
     // module outputs: ping-pong pair normally; one buffer per module in debug mode (for taps)
     const int nbuf = h->debug ? NMOD : 2;
     float* bufs[NMOD] = {nullptr};
     for (int i = 0; i < nbuf; ++i) A(&bufs[i], B * h->wa * INC_OUT);
     for (int m = 0; m < NMOD; ++m) h->cur->modout[m] = bufs[h->debug ? m : (m & 1)];
+    if (!rc && h->bf16) {
+        // bf16 rows are [.., 256] with channels 240..255 (and the joint's tail) never written: they must read as zero
+        hipError_t e = hipSuccess;
+        for (int i = 0; i < nbuf && e == hipSuccess; ++i) e = hipMemset(bufs[i], 0, B * h->wa * INC_OUT * 4);
+        if (e == hipSuccess) e = hipMemset(h->cur->pool2, 0, B * h->wb * INC_OUT * 4);
+        if (e == hipSuccess) e = hipMemset(h->cur->pool3, 0, B * h->wc * INC_OUT * 4);
+        if (e == hipSuccess) e = hipMemset(h->cur->joint, 0, B * (size_t)h->JP * 2);
+        if (e != hipSuccess) rc = fail(h, DS_ERR_HIP, std::string("hipMemset: ") + hipGetErrorString(e));
+    }
     return rc;
 }
 
@@ -423,6 +475,7 @@ void add_tiles(GemmLaunch& L, GemmProblem& P, GemmCfg cfg)
     P.tiles_m = (P.M + g.bm - 1) / g.bm;
     P.tiles_n = (P.N + g.bn - 1) / g.bn;
     P.ntiles32 = (P.N + 31) / 32;
+    P.n_fast = (double)P.M > (double)P.N ? 1 : 0;      // A bytes (M*K) vs B bytes (K*N)
     P.tile_start = L.total_tiles;
     L.total_tiles += P.tiles_m * P.tiles_n;
     L.prob[L.nprob++] = P;
@@ -445,10 +498,11 @@ void add_seg(GemmProblem& P, const float* base, int ld, int shift, int klen)
     P.K += klen;
 }
 
-void add_out(GemmProblem& P, float* base, int ld, int col0, int ncols, int relu, const float* add = nullptr, int add_ld = 0)
+void add_out(GemmProblem& P, float* base, int ld, int col0, int ncols, int relu, const float* add = nullptr, int add_ld = 0,
+             int bf16 = 0)
 {
     OSeg& o = P.out[P.nout++];
-    o.base = base; o.ld = ld; o.col0 = col0; o.ncols = ncols; o.relu = relu; o.add = add; o.add_ld = add_ld;
+    o.base = base; o.ld = ld; o.col0 = col0; o.ncols = ncols; o.relu = relu; o.add = add; o.add_ld = add_ld; o.bf16 = bf16;
 }
 
 int stage_id(ds_handle* h, const std::string& name, int stream)
@@ -468,11 +522,16 @@ int build_plan(ds_handle* h, int n, Plan* plan)
     std::vector<Op> cnn, rnn;
     auto& LS = plan->launches;
     const bool first_plan = !h->stages_done;
-    auto add_gemm_op = [&](std::vector<Op>& list, int stream, int stage, GemmCfg cfg, const GemmLaunch& L) {
+    const bool bf = h->bf16;
+    auto U = [&](int elems) { return bf ? elems / 2 : elems; };                // elements -> 4-byte units of the A operand
+    auto eoff = [&](float* p, size_t elems) { return bf ? reinterpret_cast<float*>(reinterpret_cast<uint16_t*>(p) + elems) : p + elems; };
+    const int CL = bf ? 256 : INC_OUT;                                         // channel pitch of module outputs
+    auto add_gemm_op = [&](std::vector<Op>& list, int stream, int stage, GemmCfg cfg, const GemmLaunch& L, double kscale = 1.0) {
         Op op{};
         op.kind = OP_GEMM; op.stream = stream; op.stage = stage; op.cfg = cfg;
         op.launch_index = (int)LS.size(); op.total_tiles = L.total_tiles;
-        for (int i = 0; i < L.nprob; ++i) op.flops += 2.0 * L.prob[i].M * (double)L.prob[i].N * L.prob[i].K;
+        const double kelems = (cfg >= CFG_BCONV ? 2.0 : 1.0) * kscale;        // bf16 problems count K in units; kscale removes zero pad
+        for (int i = 0; i < L.nprob; ++i) op.flops += 2.0 * L.prob[i].M * (double)L.prob[i].N * L.prob[i].K * kelems;
         LS.push_back(L);
         list.push_back(op);
         if (first_plan) {
@@ -491,23 +550,24 @@ int build_plan(ds_handle* h, int n, Plan* plan)
     st = stage_id(h, "stem", 0);
     {
         Op op{};
-        op.kind = OP_STEM1; op.stream = 0; op.stage = st; op.in = h->cur->d_signals; op.out = h->cur->stem_pool;
+        op.kind = OP_STEM1; op.stream = 0; op.stage = st; op.in = h->cur->d_signals; op.out = h->cur->stem_pool; op.a = bf;
         op.flops = 2.0 * h->w1 * 7 * 64 * n;
         add_ew_op(cnn, op);
         if (first_plan) h->stages[st].flops_per_site += 2.0 * h->w1 * 7 * 64;
         const int M = n * h->wa;
         GemmLaunch L{};
+        const GemmCfg ccfg = bf ? CFG_BCONV : CFG_CONV;
         GemmProblem P = base_problem(M, 128, h->wa, h->conv2);                 // conv_layer2 1x1 (layers.py:192-197)
-        add_seg(P, h->cur->stem_pool, 64, 0, 64);
-        add_out(P, h->cur->conv2o, 128, 0, 128, 1);
-        add_tiles(L, P, CFG_CONV);
-        add_gemm_op(cnn, 0, st, CFG_CONV, L);
+        add_seg(P, h->cur->stem_pool, U(64), 0, U(64));
+        add_out(P, h->cur->conv2o, 128, 0, 128, 1, nullptr, 0, bf);
+        add_tiles(L, P, ccfg);
+        add_gemm_op(cnn, 0, st, ccfg, L);
         GemmLaunch L3{};
         GemmProblem P3 = base_problem(M, 256, h->wa, h->conv3);                // conv_layer3 1x3 (layers.py:198-203)
-        for (int t = 0; t < 3; ++t) add_seg(P3, h->cur->conv2o, 128, t - 1, 128);
-        add_out(P3, h->cur->conv3o, 256, 0, 256, 1);
-        add_tiles(L3, P3, CFG_CONV);
-        add_gemm_op(cnn, 0, st, CFG_CONV, L3);
+        for (int t = 0; t < 3; ++t) add_seg(P3, h->cur->conv2o, U(128), t - 1, U(128));
+        add_out(P3, h->cur->conv3o, 256, 0, 256, 1, nullptr, 0, bf);
+        add_tiles(L3, P3, ccfg);
+        add_gemm_op(cnn, 0, st, ccfg, L3);
     }
     const float* x = h->cur->conv3o;
     int cin = 256;
@@ -519,7 +579,7 @@ int build_plan(ds_handle* h, int n, Plan* plan)
         const int W = module_width(h, m), M = n * W;
         float* y = h->cur->modout[m];
         static const bool no_fused = getenv("DS_NO_FUSED") != nullptr;
-        if (!no_fused && W <= 96) {
+        if (!no_fused && !bf && W <= 96) {
             // one fused launch per module; tile = spt whole sites (<= 96 rows). Pick the spt that
             // minimises padded rows while keeping >= 256 workgroups when the batch allows it.
             int best_spt = 1; long best_rows = -1;
@@ -547,58 +607,64 @@ int build_plan(ds_handle* h, int n, Plan* plan)
             add_ew_op(cnn, op);
         } else {
         {   // five 1x1 convs on the module input + branch1 (maxpool on load)   layers.py:90-101,103,112,121-126
+            // bf16 mode: rows have a 256-channel pitch (cin = 240 inputs carry 16 zero channels, matched by zero weight rows)
+            const int xld = bf ? 256 : cin;
+            const double ks = (double)cin / xld;
+            const GemmCfg ccfg = bf ? CFG_BCONV : CFG_CONV, pcfg = bf ? CFG_BCONV_POOL : CFG_CONV_POOL;
             GemmLaunch L{};
             GemmProblem P = base_problem(M, 192, W, h->m_s1[m]);
-            add_seg(P, x, cin, 0, cin);
-            add_out(P, y + 48, INC_OUT, 0, 48, 1);          // branch2
-            add_out(P, h->cur->tmpS, 48, 48, 48, 0);             // branch5 stem (BN, no ReLU)
-            add_out(P, h->cur->tmpA, 96, 96, 96, 1);             // b3a | b4a | b5a
-            add_tiles(L, P, CFG_CONV);
-            add_gemm_op(cnn, 0, st, CFG_CONV, L);
+            add_seg(P, x, U(xld), 0, U(xld));
+            add_out(P, eoff(y, 48), CL, 0, 48, 1, nullptr, 0, bf);          // branch2
+            add_out(P, h->cur->tmpS, 48, 48, 48, 0);                        // branch5 stem (BN, no ReLU), kept fp32
+            add_out(P, h->cur->tmpA, 96, 96, 96, 1, nullptr, 0, bf);        // b3a | b4a | b5a
+            add_tiles(L, P, ccfg);
+            add_gemm_op(cnn, 0, st, ccfg, L, ks);
             GemmLaunch L1{};
             GemmProblem Q = base_problem(M, 48, W, h->m_b1[m]);
             Q.a_mode = 1;                                   // maxpool(3, s1) fused into the A load (layers.py:90-91)
-            add_seg(Q, x, cin, 0, cin);
-            add_out(Q, y, INC_OUT, 0, 48, 1);               // branch1
-            add_tiles(L1, Q, CFG_CONV_POOL);
-            add_gemm_op(cnn, 0, st, CFG_CONV_POOL, L1);
+            add_seg(Q, x, U(xld), 0, U(xld));
+            add_out(Q, y, CL, 0, 48, 1, nullptr, 0, bf);    // branch1
+            add_tiles(L1, Q, pcfg);
+            add_gemm_op(cnn, 0, st, pcfg, L1, ks);
         }
         {   // second-stage convs from the 32-channel intermediates             layers.py:106-110,115-119,127-131
+            const GemmCfg ccfg = bf ? CFG_BCONV : CFG_CONV;
             GemmLaunch L{};
             GemmProblem P = base_problem(M, 48, W, h->m_b3b[m]);
-            for (int t = 0; t < 3; ++t) add_seg(P, h->cur->tmpA + 0, 96, t - 1, 32);
-            add_out(P, y + 96, INC_OUT, 0, 48, 1);
-            add_tiles(L, P, CFG_CONV);
+            for (int t = 0; t < 3; ++t) add_seg(P, eoff(h->cur->tmpA, 0), U(96), t - 1, U(32));
+            add_out(P, eoff(y, 96), CL, 0, 48, 1, nullptr, 0, bf);
+            add_tiles(L, P, ccfg);
             GemmProblem Q = base_problem(M, 48, W, h->m_b4b[m]);
-            for (int t = 0; t < 5; ++t) add_seg(Q, h->cur->tmpA + 32, 96, t - 2, 32);
-            add_out(Q, y + 144, INC_OUT, 0, 48, 1);
-            add_tiles(L, Q, CFG_CONV);
+            for (int t = 0; t < 5; ++t) add_seg(Q, eoff(h->cur->tmpA, 32), U(96), t - 2, U(32));
+            add_out(Q, eoff(y, 144), CL, 0, 48, 1, nullptr, 0, bf);
+            add_tiles(L, Q, ccfg);
             GemmProblem R = base_problem(M, 64, W, h->m_b5b[m]);
-            for (int t = 0; t < 3; ++t) add_seg(R, h->cur->tmpA + 64, 96, t - 1, 32);
-            add_out(R, h->cur->tmpB, 64, 0, 64, 1);
-            add_tiles(L, R, CFG_CONV);
-            add_gemm_op(cnn, 0, st, CFG_CONV, L);
+            for (int t = 0; t < 3; ++t) add_seg(R, eoff(h->cur->tmpA, 64), U(96), t - 1, U(32));
+            add_out(R, h->cur->tmpB, 64, 0, 64, 1, nullptr, 0, bf);
+            add_tiles(L, R, ccfg);
+            add_gemm_op(cnn, 0, st, ccfg, L);
         }
         {   // residual tail: relu(stem + BN(1x1 48 of tmpB))                    layers.py:132-138
+            const GemmCfg ccfg = bf ? CFG_BCONV : CFG_CONV;
             GemmLaunch L{};
             GemmProblem P = base_problem(M, 48, W, h->m_b5c[m]);
-            add_seg(P, h->cur->tmpB, 64, 0, 64);
-            add_out(P, y + 192, INC_OUT, 0, 48, 1, h->cur->tmpS, 48);
-            add_tiles(L, P, CFG_CONV);
-            add_gemm_op(cnn, 0, st, CFG_CONV, L);
+            add_seg(P, h->cur->tmpB, U(64), 0, U(64));
+            add_out(P, eoff(y, 192), CL, 0, 48, 1, h->cur->tmpS, 48, bf);
+            add_tiles(L, P, ccfg);
+            add_gemm_op(cnn, 0, st, ccfg, L);
         }
         }
         x = y; cin = INC_OUT;
         if (m == 2 || m == 7) {   // maxpool_layer2/3                            layers.py:211-213,224-226
             const int wout = m == 2 ? h->wb : h->wc, pad = m == 2 ? h->pl_pool2 : h->pl_pool3;
             static const bool no_fused2 = getenv("DS_NO_FUSED") != nullptr;
-            if (!no_fused2 && wout <= 96 && !h->debug_keep_pool) {
+            if (!no_fused2 && !bf && wout <= 96 && !h->debug_keep_pool) {
                 pend_pool_win = W; pend_pool_pad = pad;      // folded into module m+2's staging: no launch, no buffer
             } else {
                 Op op{};
                 op.kind = OP_MAXPOOL; op.stream = 0; op.stage = stage_id(h, "pools", 0);
                 op.in = y; op.out = m == 2 ? h->cur->pool2 : h->cur->pool3;
-                op.a = W; op.b = wout; op.c = pad; op.d = INC_OUT;
+                op.a = W; op.b = wout; op.c = pad; op.d = CL;
                 add_ew_op(cnn, op);
                 x = op.out;
             }
@@ -607,7 +673,7 @@ int build_plan(ds_handle* h, int n, Plan* plan)
     {   // avgpool_layer1 + flatten                                              layers.py:233-238
         Op op{};
         op.kind = OP_AVGPOOL; op.stream = 0; op.stage = stage_id(h, "pools", 0);
-        op.in = x; op.out = h->cur->sigfeat; op.a = h->wc; op.d = INC_OUT;
+        op.in = x; op.out = bf ? h->cur->joint : h->cur->sigfeat; op.a = h->wc; op.d = INC_OUT;
         add_ew_op(cnn, op);
     }
     }   // is_cnn
@@ -619,7 +685,7 @@ int build_plan(ds_handle* h, int n, Plan* plan)
     const int T = h->T;
     // dense variants skip the per-row validity selects; legal when every tile row is a real site
     const GemmCfg lstm_cfg = n % 128 == 0 ? CFG_LSTM_DENSE : CFG_LSTM;
-    const GemmCfg fc_cfg = n % 128 == 0 ? CFG_FC_DENSE : CFG_FC;
+    const GemmCfg fc_cfg = bf ? (n % 128 == 0 ? CFG_BFC_DENSE : CFG_BFC) : (n % 128 == 0 ? CFG_FC_DENSE : CFG_FC);
     for (int d = 0; h->is_rnn && d < T + NLAYER - 1; ++d) {
         GemmLaunch L{};
         for (int dir = 0; dir < 2; ++dir)
@@ -641,6 +707,11 @@ int build_plan(ds_handle* h, int n, Plan* plan)
             }
         add_gemm_op(rnn, 1, st, lstm_cfg, L);
     }
+    if (bf && h->is_rnn) {     // the bf16 FC reads [bf16(h_fw(T-1)) | bf16(h_bw(0)) | signal features] from one buffer
+        Op op{};
+        op.kind = OP_PACKEV; op.stream = 1; op.stage = st;
+        add_ew_op(rnn, op);
+    }
 
     // ================= joint model (stream 0 after join) — layers.py:247-264 =================
     std::vector<Op> tail;
@@ -649,14 +720,18 @@ int build_plan(ds_handle* h, int n, Plan* plan)
         GemmLaunch L{};
         GemmProblem P = base_problem(n, h->J, n, h->fc1);
         // joint = [fw h(T-1) | bw h(0) | signal features]: three A segments, no concat buffer (layers.py:171-172,250-252)
+        if (bf) {
+            add_seg(P, h->cur->joint, h->JP / 2, 0, h->JP / 2);
+        } else {
         if (h->is_rnn) {
             add_seg(P, h->cur->H[0][NLAYER - 1] + (size_t)(T - 1) * h->B * HID, HID, 0, HID);
             add_seg(P, h->cur->H[1][NLAYER - 1] + 0, HID, 0, HID);
         }
         if (h->is_cnn) add_seg(P, h->cur->sigfeat, h->SF, 0, h->SF);
+        }
         add_out(P, h->cur->fc1o, h->J, 0, h->J, 0);
         add_tiles(L, P, fc_cfg);
-        add_gemm_op(tail, 0, st, fc_cfg, L);
+        add_gemm_op(tail, 0, st, fc_cfg, L, bf ? (double)h->J / h->JP : 1.0);
     }
     st = stage_id(h, "head", 0);
     {
@@ -691,13 +766,19 @@ int issue_op(ds_handle* h, Plan& plan, const Op& op, hipStream_t s)
         HIPCHK(h, launch_gemm(op.cfg, plan.d_launches + op.launch_index, op.total_tiles, s));
         break;
     case OP_STEM1:
-        HIPCHK(h, launch_stem1(op.in, h->stem1_w, h->stem1_b, op.out, n, h->S, h->w1, h->pl_conv1, h->wa, h->pl_pool1, s));
+        HIPCHK(h, launch_stem1(op.in, h->stem1_w, h->stem1_b, op.out, n, h->S, h->w1, h->pl_conv1, h->wa, h->pl_pool1, op.a, s));
         break;
     case OP_MAXPOOL:
-        HIPCHK(h, launch_maxpool_s2(op.in, op.out, n, op.a, op.b, op.c, op.d, s));
+        if (h->bf16) HIPCHK(h, launch_maxpool_s2_bf16(op.in, op.out, n, op.a, op.b, op.c, op.d, s));
+        else HIPCHK(h, launch_maxpool_s2(op.in, op.out, n, op.a, op.b, op.c, op.d, s));
         break;
     case OP_AVGPOOL:
-        HIPCHK(h, launch_avgpool7(op.in, op.out, n, op.a, op.d, s));
+        if (h->bf16) HIPCHK(h, launch_avgpool7_bf16(op.in, op.out, n, op.a, op.d, 256, h->JP, h->is_rnn ? 2 * HID : 0, s));
+        else HIPCHK(h, launch_avgpool7(op.in, op.out, n, op.a, op.d, s));
+        break;
+    case OP_PACKEV:
+        HIPCHK(h, launch_pack_event_feat_bf16(h->cur->H[0][NLAYER - 1] + (size_t)(h->T - 1) * h->B * HID, h->cur->H[1][NLAYER - 1],
+                                              h->cur->joint, n, h->JP, s));
         break;
     case OP_FUSED:
         HIPCHK(h, launch_inception_fused(op.tm, op.fa, s));
@@ -777,12 +858,15 @@ int kernel_class(const Op& op)
     case OP_GEMM:
         return op.cfg == CFG_CONV ? K_GEMM_CONV : op.cfg == CFG_FC ? K_GEMM_FC : op.cfg == CFG_LSTM ? K_GEMM_LSTM
                : op.cfg == CFG_CONV_POOL ? K_GEMM_CONV_POOL : op.cfg == CFG_FC_DENSE ? K_GEMM_FC_DENSE
-               : op.cfg == CFG_LSTM_DENSE ? K_GEMM_LSTM_DENSE : K_GEMM_CONV_WIDE;
+               : op.cfg == CFG_LSTM_DENSE ? K_GEMM_LSTM_DENSE : op.cfg == CFG_BCONV ? K_GEMM_BCONV
+               : op.cfg == CFG_BCONV_POOL ? K_GEMM_BCONV_POOL : op.cfg == CFG_BFC ? K_GEMM_BFC
+               : op.cfg == CFG_BFC_DENSE ? K_GEMM_BFC_DENSE : K_GEMM_CONV_WIDE;
     case OP_FUSED: return op.tm == 1 ? K_FUSED1 : op.tm == 2 ? K_FUSED2 : K_FUSED3;
     case OP_STEM1: return K_STEM1;
     case OP_MAXPOOL: return K_MAXPOOL;
     case OP_AVGPOOL: return K_AVGPOOL;
     case OP_HEAD: return K_HEAD;
+    case OP_PACKEV: return K_PACKEV;
     }
     return K_HEAD;
 }
@@ -856,7 +940,7 @@ int run_resident(ds_handle* h, int n)
 // ======================================= C ABI =======================================
 extern "C" {
 
-const char* ds_version(void) { return "deepsignal_amd 0.1 (gfx950, fp32 MFMA)"; }
+const char* ds_version(void) { return "deepsignal_amd 0.2 (gfx950, fp32 MFMA; optional bf16 conv+FC)"; }
 
 const char* ds_last_error(const ds_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
 
@@ -866,7 +950,8 @@ int ds_create(const ds_config* cfg, ds_handle** out)
     *out = nullptr;
     if (!(cfg->is_cnn || cfg->is_rnn))
         return fail(nullptr, DS_ERR_INVALID, "at least one of is_cnn/is_rnn should be True");      // model.py:28-29
-    if (cfg->precision != DS_PRECISION_FP32) return fail(nullptr, DS_ERR_UNSUPPORTED, "only fp32 is implemented");
+    if (cfg->precision != DS_PRECISION_FP32 && cfg->precision != DS_PRECISION_BF16)
+        return fail(nullptr, DS_ERR_UNSUPPORTED, "precision must be DS_PRECISION_FP32 or DS_PRECISION_BF16");
     if (cfg->kmer_len < 1 || cfg->kmer_len > 255 || (cfg->kmer_len & 1) == 0)
         return fail(nullptr, DS_ERR_INVALID, "kmer_len must be odd and in [1,255]");
     if (cfg->signal_len < 16 || cfg->class_num < 1 || cfg->class_num > 16)
@@ -889,6 +974,8 @@ int ds_create(const ds_config* cfg, ds_handle** out)
     h->is_cnn = cfg->is_cnn != 0; h->is_rnn = cfg->is_rnn != 0; h->is_base = cfg->is_base != 0;
     h->SF = h->wc * INC_OUT;
     h->J = (h->is_rnn ? 2 * HID : 0) + (h->is_cnn ? h->SF : 0);     // layers.py:248-255
+    h->bf16 = cfg->precision == DS_PRECISION_BF16;
+    h->JP = (h->J + 31) / 32 * 32;
     h->debug = cfg->reserved[0] != 0;
 #define CK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { fail(nullptr, DS_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); ds_destroy(h); return DS_ERR_HIP; } } while (0)
     CK(hipSetDevice(cfg->device));
@@ -1080,6 +1167,31 @@ int64_t ds_get_intermediate(ds_handle* h, const char* name, float* out, int64_t 
         if (hipMemcpy(out, src, (size_t)count * 4, hipMemcpyDeviceToHost) != hipSuccess) return fail(h, DS_ERR_HIP, "hipMemcpy D2H");
         return count;
     };
+    // bf16 mode: activation taps are stored as bf16 rows of pitch ld; widen the valid channels to fp32
+    auto copy_bf = [&](const float* src, int64_t rows, int ch, int ld, int col0 = 0) -> int64_t {
+        if (rows * ch > capacity) return fail(h, DS_ERR_INVALID, "capacity too small for " + s);
+        std::vector<uint16_t> tmp((size_t)rows * ld);
+        if (hipMemcpy(tmp.data(), src, tmp.size() * 2, hipMemcpyDeviceToHost) != hipSuccess) return fail(h, DS_ERR_HIP, "hipMemcpy D2H");
+        for (int64_t r = 0; r < rows; ++r)
+            for (int c = 0; c < ch; ++c) {
+                const uint32_t u = (uint32_t)tmp[(size_t)r * ld + col0 + c] << 16;
+                memcpy(out + r * ch + c, &u, 4);
+            }
+        return rows * ch;
+    };
+    if (h->bf16) {
+        if (s == "stem_pool") return copy_bf(h->cur->stem_pool, (int64_t)n * h->wa, 64, 64);
+        if (s == "stem_conv2") return copy_bf(h->cur->conv2o, (int64_t)n * h->wa, 128, 128);
+        if (s == "stem_conv3") return copy_bf(h->cur->conv3o, (int64_t)n * h->wa, 256, 256);
+        if (s == "signal_feat") return copy_bf(h->cur->joint, n, h->SF, h->JP, h->is_rnn ? 2 * HID : 0);
+        if (s == "joint") return copy_bf(h->cur->joint, n, h->J, h->JP);
+        if (s.rfind("module", 0) == 0) {
+            const int m = atoi(s.c_str() + 6) - 1;
+            if (m < 0 || m >= NMOD) return fail(h, DS_ERR_INVALID, "bad module index");
+            if (!h->debug && m < NMOD - 2) return fail(h, DS_ERR_INVALID, "module taps need debug mode (cfg.reserved[0]=1)");
+            return copy_bf(h->cur->modout[m], (int64_t)n * module_width(h, m), INC_OUT, 256);
+        }
+    }
     if (s == "stem_pool") return copy(h->cur->stem_pool, (int64_t)n * h->wa * 64);
     if (s == "stem_conv2") return copy(h->cur->conv2o, (int64_t)n * h->wa * 128);
     if (s == "stem_conv3") return copy(h->cur->conv3o, (int64_t)n * h->wa * 256);

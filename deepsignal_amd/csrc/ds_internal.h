@@ -31,7 +31,7 @@ struct OSeg {
     int col0;
     int ncols;
     int relu;
-    int pad_;
+    int bf16;           // 1: base is a bf16 buffer (ld / col offsets in bf16 elements), values rounded to nearest even
 };
 
 // Fused LSTM-cell epilogue (TF-1.x LSTMCell, gate order i,j,f,o, forget_bias 1.0).
@@ -53,6 +53,7 @@ struct LstmEp {
 struct GemmProblem {
     int M, N, K, W;             // K = sum of the used segments' klen
     int a_mode;                 // informational: 1 = maxpool(3, stride 1, SAME) on load (kernel variant CFG_CONV_POOL)
+    int n_fast;                 // tile order inside the problem: 1 = n-tiles of one m-tile are neighbours (A-heavy shapes)
     int nseg;
     int kgroups_stride;         // K-groups (of 8) per packed n-tile panel in Bp
     int nout;
@@ -71,7 +72,9 @@ struct GemmLaunch {
     int pad_[2];
 };
 
-enum GemmCfg { CFG_CONV = 0, CFG_FC = 1, CFG_LSTM = 2, CFG_CONV_WIDE = 3, CFG_CONV_POOL = 4, CFG_FC_DENSE = 5, CFG_LSTM_DENSE = 6 };
+enum GemmCfg { CFG_CONV = 0, CFG_FC = 1, CFG_LSTM = 2, CFG_CONV_WIDE = 3, CFG_CONV_POOL = 4, CFG_FC_DENSE = 5, CFG_LSTM_DENSE = 6,
+               // bf16-operand variants (mixed-precision mode)
+               CFG_BCONV = 7, CFG_BCONV_POOL = 8, CFG_BFC = 9, CFG_BFC_DENSE = 10 };
 
 // tile geometry per config (host needs it for grid sizing)
 struct TileGeom { int bm, bn, threads, ksplit; };
@@ -98,7 +101,12 @@ size_t inception_fused_lds_bytes(int tm, int W, int spt);
 
 // stem conv1 (K=7, stride 2, Cin=1) + folded BN + ReLU + maxpool(3, stride 2)   layers.py:183-191
 hipError_t launch_stem1(const float* signals, const float* w7x64, const float* bias64, float* out,
-                        int n, int signal_len, int w1, int pad_l_conv, int wa, int pad_l_pool, hipStream_t s);
+                        int n, int signal_len, int w1, int pad_l_conv, int wa, int pad_l_pool, int out_bf16, hipStream_t s);
+// bf16-mode pools: activations are [rows][ch_ld] bf16 (ch_ld = channels padded to a multiple of 32, pad = 0)
+hipError_t launch_maxpool_s2_bf16(const float* in, float* out, int n, int win, int wout, int pad_l, int ch_ld, hipStream_t s);
+hipError_t launch_avgpool7_bf16(const float* in, float* joint, int n, int w, int ch, int ld_in, int joint_ld, int joint_off,
+                                hipStream_t s);
+hipError_t launch_pack_event_feat_bf16(const float* hfw, const float* hbw, float* joint, int n, int joint_ld, hipStream_t s);
 // maxpool(3, stride 2, SAME) over [n, win, ch] -> [n, wout, ch]                 layers.py:211-213,224-226
 hipError_t launch_maxpool_s2(const float* in, float* out, int n, int win, int wout, int pad_l, int ch, hipStream_t s);
 // avgpool(7, stride 1, SAME, divisor = valid taps) + flatten                    layers.py:233-238

@@ -28,7 +28,7 @@ __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf
 // LSTM gate non-linearities on the hardware exp (v_exp_f32, ~1 ulp): abs error < 2e-7, far inside the
 // 2e-5 parity budget, at a fraction of the ocml expf/tanhf instruction count.
 __device__ __forceinline__ float fast_sigmoid(float x) { return __fdividef(1.0f, 1.0f + __expf(-x)); }
-__device__ __forceinline__ float fast_tanh(float x) { return 2.0f * fast_sigmoid(2.0f * x) - 1.0f; }
+__device__ __forceinline__ float fast_tanh(float x) { return fmaf(2.0f, fast_sigmoid(2.0f * x), -1.0f); }
 
 // Pointers reach the kernels through descriptor structs, so the compiler only knows them as
 // generic; these casts make every access a global_* instruction (flat_* would tie vmcnt and
@@ -45,11 +45,36 @@ __device__ __forceinline__ float4 gload4(const float* p)
 __device__ __forceinline__ float gload(const float* p) { return *(gptr1)(p); }
 __device__ __forceinline__ void gstore(float* p, float v) { *(gptr1w)(p) = v; }
 
+// ---- bf16 helpers (mixed-precision mode: bf16 operands, fp32 accumulate) ----
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+// max of two packed bf16 pairs; widening a bf16 to fp32 is a shift, and max returns one of its inputs, so
+// narrowing back by truncation is exact
+__device__ __forceinline__ float bf2max(float a, float b)
+{
+    const unsigned ua = __float_as_uint(a), ub = __float_as_uint(b);
+    const float lo = fmaxf(__uint_as_float(ua << 16), __uint_as_float(ub << 16));
+    const float hi = fmaxf(__uint_as_float(ua & 0xffff0000u), __uint_as_float(ub & 0xffff0000u));
+    return __uint_as_float((__float_as_uint(hi) & 0xffff0000u) | (__float_as_uint(lo) >> 16));
+}
+__device__ __forceinline__ float4 bf8max(float4 a, float4 b)
+{
+    return make_float4(bf2max(a.x, b.x), bf2max(a.y, b.y), bf2max(a.z, b.z), bf2max(a.w, b.w));
+}
+__device__ __forceinline__ unsigned short f2bf(float v)     // round to nearest even (v_cvt_pk_bf16_f32)
+{
+    return __builtin_bit_cast(unsigned short, (__bf16)v);
+}
+__device__ __forceinline__ float bf2f(unsigned short b) { return __uint_as_float((unsigned)b << 16); }
+
+// BF = bf16 operands. The byte geometry is the same as fp32: a "unit" is 4 bytes (one float or two bf16), a
+// K chunk is 16 units = 64 B per row (16 floats / 32 bf16), one 16-B fragment per lane feeds four
+// v_mfma_f32_32x32x2_f32 (fp32) or ONE v_mfma_f32_32x32x16_bf16 (lane half h owns k = 8h..8h+7 of the 16).
+// The host passes ld / klen / K of bf16 operands in units, so the staging code is shared.
 // KS = in-workgroup K split: KS wave groups ("K-lanes") own the same output tile and take alternate
 // 16-wide K chunks (lane g: chunks g, g+KS, ...), each with its own LDS staging area, and the partial
 // accumulators are exchanged through LDS at the end. It doubles the waves per SIMD for grids that
 // only have ~one workgroup per CU and halves the serial chunk chain of short-K problems.
-template <int MT, int NT, int WM, int WN, int EPI, int AMODE, int BD, int KS>
+template <int MT, int NT, int WM, int WN, int EPI, int AMODE, int BD, int KS, bool BF = false>
 __global__ __launch_bounds__(64 * WM * WN * KS, (EPI == 1 && KS == 1) ? 2 : 1) void gemm_kernel(const GemmLaunch* __restrict__ L)
 {
     constexpr int BM = WM * MT * 32;
@@ -69,13 +94,24 @@ __global__ __launch_bounds__(64 * WM * WN * KS, (EPI == 1 && KS == 1) ? 2 : 1) v
     float* const As0 = smem_ + (0 * KS + kl) * BM * LDA;
     float* const As1 = smem_ + (1 * KS + kl) * BM * LDA;
     const int wm = wave % WM, wn = wave / WM;
-    const int bid = blockIdx.x;
+    // XCD-aware tile order: hardware deals workgroup b to XCD b % 8, each with a private L2. Give every XCD a
+    // contiguous run of logical tiles (m-tiles of one weight panel are neighbours), so a weight panel is pulled
+    // into ONE L2 instead of up to eight (PMC: FC1 fetched its 146 MB of weights 4x before this remap).
+    int bid;
+    {
+        const int total = L->total_tiles, q = total >> 3, r = total & 7;
+        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        bid = xcd * q + (xcd < r ? xcd : r) + idx;
+    }
     int pi = 0;
     for (int i = 1; i < L->nprob; ++i)
         if (bid >= L->prob[i].tile_start) pi = i;
     const GemmProblem& P = L->prob[pi];
     const int local = bid - P.tile_start;
-    const int tm = local % P.tiles_m, tn = local / P.tiles_m;
+    // neighbours in the logical order share the bigger operand: the weight panel (m fastest) for FC / LSTM
+    // shapes, the activation rows (n fastest) for the convolutions
+    const int tm = P.n_fast ? local / P.tiles_n : local % P.tiles_m;
+    const int tn = P.n_fast ? local % P.tiles_n : local / P.tiles_m;
     const int m0 = tm * BM;
     const int M = P.M, W = P.W;
     const int nchunks = P.K / KC / KS;          // chunks per K-lane (planner pads K to a multiple of KC*KS)
@@ -183,7 +219,8 @@ __global__ __launch_bounds__(64 * WM * WN * KS, (EPI == 1 && KS == 1) ? 2 : 1) v
         for (int i = 0; i < SLOTS; ++i) {
             const int idx = tid + i * NTHR;
             float4 v = R[X][i];
-            if (AMODE == 1) v = f4max(f4max(v, Rm[X][i]), Rp[X][i]);   // maxpool(3, s1, SAME): padded taps ignored
+            if (AMODE == 1) v = BF ? bf8max(bf8max(v, Rm[X][i]), Rp[X][i])
+                                   : f4max(f4max(v, Rm[X][i]), Rp[X][i]);   // maxpool(3, s1, SAME): padded taps ignored
             if (AMODE != 2) {     // AMODE 2 = dense: every row of every tile is valid, no taps -> no select
                 v.x = lok[X][i] ? v.x : 0.0f;
                 v.y = lok[X][i] ? v.y : 0.0f;
@@ -216,6 +253,11 @@ __global__ __launch_bounds__(64 * WM * WN * KS, (EPI == 1 && KS == 1) ? 2 : 1) v
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
+                if (BF) {
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[X][rs][mt]),
+                                                                          __builtin_bit_cast(bf16x8, bq[J][nt][rs]), acc[mt][nt], 0, 0, 0);
+                    continue;
+                }
                 acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[X][rs][mt].x, bq[J][nt][rs].x, acc[mt][nt], 0, 0, 0);
                 acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[X][rs][mt].y, bq[J][nt][rs].y, acc[mt][nt], 0, 0, 0);
                 acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[X][rs][mt].z, bq[J][nt][rs].z, acc[mt][nt], 0, 0, 0);
@@ -226,7 +268,7 @@ __global__ __launch_bounds__(64 * WM * WN * KS, (EPI == 1 && KS == 1) ? 2 : 1) v
     // wave per SIMD a burst of loads / LDS ops in front of the MFMA block leaves the matrix pipe idle
     // while they issue, so each non-MFMA instruction is slotted behind one MFMA instead.
     //   masks: VALU 0x2, MFMA 0x8, VMEM read 0x20, DS read 0x100, DS write 0x200
-    constexpr int N_MFMA_HALF = MT * NT * 4;
+    constexpr int N_MFMA_HALF = MT * NT * (BF ? 1 : 4);
     constexpr int N_ALOADS = SLOTS * (AMODE == 1 ? 3 : 1);
     constexpr int N_BLOADS = 2 * NT;
     constexpr int N_VALU_PER_STORE = (AMODE == 1 ? 12 : AMODE == 2 ? 0 : 4);
@@ -372,7 +414,10 @@ __global__ __launch_bounds__(64 * WM * WN * KS, (EPI == 1 && KS == 1) ? 2 : 1) v
                         float v = acc[mt][nt][r] + bias;
                         if (os.add) v += gload(os.add + (size_t)row * os.add_ld + cc);
                         if (os.relu) v = fmaxf(v, 0.0f);
-                        gstore(os.base + (size_t)row * os.ld + cc, v);
+                        if (BF && os.bf16)
+                            *(__attribute__((address_space(1))) unsigned short*)((unsigned short*)os.base + (size_t)row * os.ld + cc) = f2bf(v);
+                        else
+                            gstore(os.base + (size_t)row * os.ld + cc, v);
                     }
                 }
         }
@@ -427,10 +472,12 @@ __global__ __launch_bounds__(64 * WM * WN * KS, (EPI == 1 && KS == 1) ? 2 : 1) v
                         if (has_feat) {
                             const unsigned it = rowc * Tt + tt;
                             const float f0 = meang[it], f1 = stdg[it], f2 = leng[it];
-                            xi[k] = f0 * wi[0] + f1 * wi[1] + f2 * wi[2];
-                            xj[k] = f0 * wj[0] + f1 * wj[1] + f2 * wj[2];
-                            xf[k] = f0 * wf[0] + f1 * wf[1] + f2 * wf[2];
-                            xo[k] = f0 * wo[0] + f1 * wo[1] + f2 * wo[2];
+                            // explicit fma chains: every instantiation of this template (dense / masked rows) must
+                            // round identically, so a site's result does not depend on the batch it travels in
+                            xi[k] = fmaf(f2, wi[2], fmaf(f1, wi[1], f0 * wi[0]));
+                            xj[k] = fmaf(f2, wj[2], fmaf(f1, wj[1], f0 * wj[0]));
+                            xf[k] = fmaf(f2, wf[2], fmaf(f1, wf[1], f0 * wf[0]));
+                            xo[k] = fmaf(f2, wo[2], fmaf(f1, wo[1], f0 * wo[0]));
                             if (has_table) {
                                 const unsigned tb = (unsigned)codeg[it] * 1024u + u;
                                 xi[k] += tabg[tb];
@@ -443,9 +490,9 @@ __global__ __launch_bounds__(64 * WM * WN * KS, (EPI == 1 && KS == 1) ? 2 : 1) v
 #pragma unroll
                     for (int k = 0; k < 8; ++k) {
                         const int r = hb * 8 + k;
-                        const float zi = acc[mt][0 % NT][r] + bi + xi[k], zj = acc[mt][1 % NT][r] + bj + xj[k];
-                        const float zf = acc[mt][2 % NT][r] + bf + xf[k], zo = acc[mt][3 % NT][r] + bo + xo[k];
-                        const float cn = fast_sigmoid(zf) * cp[k] + fast_sigmoid(zi) * fast_tanh(zj);
+                        const float zi = (acc[mt][0 % NT][r] + bi) + xi[k], zj = (acc[mt][1 % NT][r] + bj) + xj[k];
+                        const float zf = (acc[mt][2 % NT][r] + bf) + xf[k], zo = (acc[mt][3 % NT][r] + bo) + xo[k];
+                        const float cn = fmaf(fast_sigmoid(zf), cp[k], fast_sigmoid(zi) * fast_tanh(zj));
                         const float hn = fast_sigmoid(zo) * fast_tanh(cn);
                         if (ok[k]) {
                             cgw[off[k]] = cn;
@@ -467,6 +514,10 @@ TileGeom gemm_geom(GemmCfg cfg)
     case CFG_CONV_POOL: return {128, 64, 256, 1};   // CFG_CONV with maxpool(3,s1) fused into the A load
     case CFG_FC_DENSE: return {128, 96, 256, 1};    // CFG_FC / CFG_LSTM for M % 128 == 0 (no row masks)
     case CFG_LSTM_DENSE: return {128, 128, 256, 1};
+    case CFG_BCONV: return {128, 64, 256, 1};       // bf16 operands, same staging as CFG_CONV
+    case CFG_BCONV_POOL: return {128, 64, 256, 1};
+    case CFG_BFC: return {128, 256, 256, 1};        // MT4 NT2 WM1 WN4: every wave owns all 128 rows x 64 columns, so a
+    case CFG_BFC_DENSE: return {128, 256, 256, 1};  // weight fragment is loaded by exactly one wave of the workgroup
     }
     return {0, 0, 0, 1};
 }
@@ -482,6 +533,10 @@ hipError_t launch_gemm(GemmCfg cfg, const GemmLaunch* d_launch, int total_tiles,
     case CFG_CONV_POOL: hipLaunchKernelGGL((gemm_kernel<1, 2, 4, 1, 0, 1, 1, 1>), dim3(total_tiles), dim3(256), 0, s, d_launch); break;
     case CFG_FC_DENSE: hipLaunchKernelGGL((gemm_kernel<1, 3, 4, 1, 0, 2, 2, 1>), dim3(total_tiles), dim3(256), 0, s, d_launch); break;
     case CFG_LSTM_DENSE: hipLaunchKernelGGL((gemm_kernel<1, 4, 4, 1, 1, 2, 1, 1>), dim3(total_tiles), dim3(256), 0, s, d_launch); break;
+    case CFG_BCONV: hipLaunchKernelGGL((gemm_kernel<1, 2, 4, 1, 0, 0, 1, 1, true>), dim3(total_tiles), dim3(256), 0, s, d_launch); break;
+    case CFG_BCONV_POOL: hipLaunchKernelGGL((gemm_kernel<1, 2, 4, 1, 0, 1, 1, 1, true>), dim3(total_tiles), dim3(256), 0, s, d_launch); break;
+    case CFG_BFC: hipLaunchKernelGGL((gemm_kernel<4, 2, 1, 4, 0, 0, 2, 1, true>), dim3(total_tiles), dim3(256), 0, s, d_launch); break;
+    case CFG_BFC_DENSE: hipLaunchKernelGGL((gemm_kernel<4, 2, 1, 4, 0, 2, 2, 1, true>), dim3(total_tiles), dim3(256), 0, s, d_launch); break;
     }
     return hipGetLastError();
 }
@@ -889,6 +944,7 @@ hipError_t launch_inception_fused(int tm, const FusedArgs& a, hipStream_t s)
 // One block per site; the window sits in LDS with a zero halo (SAME padding, no bounds checks in the
 // tap loop); lane = output channel, so the 64-float output rows are written as whole 256-B lines.
 constexpr int STEM_HALO = 8;
+template <bool OUT_BF>
 __global__ __launch_bounds__(256) void stem1_kernel(const float* __restrict__ signals, const float* __restrict__ w,
                                                      const float* __restrict__ bias, float* __restrict__ out,
                                                      int signal_len, int w1, int pad_l_conv, int wa, int pad_l_pool)
@@ -922,17 +978,23 @@ __global__ __launch_bounds__(256) void stem1_kernel(const float* __restrict__ si
             const int wc = wc0 + pt;
             best = (wc >= 0 && wc < w1) ? fmaxf(best, a) : best;     // padded pool taps are ignored
         }
-        out[((size_t)site * wa + p) * 64 + c] = fmaxf(best + b, 0.0f);
+        const float y = fmaxf(best + b, 0.0f);
+        if (OUT_BF) reinterpret_cast<unsigned short*>(out)[((size_t)site * wa + p) * 64 + c] = f2bf(y);
+        else out[((size_t)site * wa + p) * 64 + c] = y;
     }
 }
 
 hipError_t launch_stem1(const float* signals, const float* w7x64, const float* bias64, float* out, int n,
-                        int signal_len, int w1, int pad_l_conv, int wa, int pad_l_pool, hipStream_t s)
+                        int signal_len, int w1, int pad_l_conv, int wa, int pad_l_pool, int out_bf16, hipStream_t s)
 {
     if (n <= 0) return hipSuccess;
     const size_t lds = (signal_len + 2 * STEM_HALO + 8) * sizeof(float);
-    hipLaunchKernelGGL(stem1_kernel, dim3(n), dim3(256), lds, s, signals, w7x64, bias64, out,
-                       signal_len, w1, pad_l_conv, wa, pad_l_pool);
+    if (out_bf16)
+        hipLaunchKernelGGL(stem1_kernel<true>, dim3(n), dim3(256), lds, s, signals, w7x64, bias64, out,
+                           signal_len, w1, pad_l_conv, wa, pad_l_pool);
+    else
+        hipLaunchKernelGGL(stem1_kernel<false>, dim3(n), dim3(256), lds, s, signals, w7x64, bias64, out,
+                           signal_len, w1, pad_l_conv, wa, pad_l_pool);
     return hipGetLastError();
 }
 
@@ -1052,6 +1114,99 @@ hipError_t launch_head(const float* fc1, const float* w2, float* logits, float* 
 {
     if (n <= 0) return hipSuccess;
     hipLaunchKernelGGL(head_kernel, dim3(n), dim3(256), 0, s, fc1, w2, logits, act, pred, n, J, class_num);
+    return hipGetLastError();
+}
+
+// ---- bf16-mode elementwise kernels: 8 channels (16 B) per thread ----
+__global__ __launch_bounds__(256) void maxpool_s2_bf16_kernel(const float4* __restrict__ in, float4* __restrict__ out,
+                                                               long total, int win, int wout, int pad_l, int ch8)
+{
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % ch8);
+        const long r = i / ch8;
+        const int wo = (int)(r % wout);
+        const long site = r / wout;
+        const float ninf2 = __uint_as_float(0xff80ff80u);   // two bf16 -inf
+        float4 m = make_float4(ninf2, ninf2, ninf2, ninf2);
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            const int wi = 2 * wo + t - pad_l;
+            if (wi >= 0 && wi < win) m = bf8max(m, in[(site * win + wi) * ch8 + c]);
+        }
+        out[i] = m;
+    }
+}
+
+hipError_t launch_maxpool_s2_bf16(const float* in, float* out, int n, int win, int wout, int pad_l, int ch_ld, hipStream_t s)
+{
+    const long total = (long)n * wout * (ch_ld / 8);
+    if (total <= 0) return hipSuccess;
+    const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(maxpool_s2_bf16_kernel, dim3(blocks), dim3(256), 0, s, (const float4*)in, (float4*)out, total, win,
+                       wout, pad_l, ch_ld / 8);
+    return hipGetLastError();
+}
+
+// avgpool(7, s1, SAME, divisor = valid taps) of the bf16 module output [n][w][ld_in] -> joint[n][out_off + w*ch + c] (bf16)
+__global__ __launch_bounds__(256) void avgpool7_bf16_kernel(const float4* __restrict__ in, unsigned short* __restrict__ out,
+                                                             long total, int w, int ch8, int ld_in8, long out_ld, int out_off)
+{
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % ch8);
+        const long r = i / ch8;
+        const int wo = (int)(r % w);
+        const long site = r / w;
+        float a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        int cnt = 0;
+        for (int t = -3; t <= 3; ++t) {
+            const int wi = wo + t;
+            if (wi < 0 || wi >= w) continue;
+            const float4 v = in[(site * w + wi) * ld_in8 + c];
+            const unsigned u[4] = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                a[2 * q] += __uint_as_float(u[q] << 16);
+                a[2 * q + 1] += __uint_as_float(u[q] & 0xffff0000u);
+            }
+            ++cnt;
+        }
+        const float d = (float)cnt;
+        unsigned o[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) o[q] = (unsigned)f2bf(a[2 * q] / d) | ((unsigned)f2bf(a[2 * q + 1] / d) << 16);
+        *reinterpret_cast<uint4*>(out + site * out_ld + out_off + ((long)wo * ch8 + c) * 8) = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+hipError_t launch_avgpool7_bf16(const float* in, float* joint, int n, int w, int ch, int ld_in, int joint_ld, int joint_off,
+                                hipStream_t s)
+{
+    const long total = (long)n * w * (ch / 8);
+    if (total <= 0) return hipSuccess;
+    const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(avgpool7_bf16_kernel, dim3(blocks), dim3(256), 0, s, (const float4*)in, (unsigned short*)joint, total, w,
+                       ch / 8, ld_in / 8, (long)joint_ld, joint_off);
+    return hipGetLastError();
+}
+
+// joint[:, 0:256] = bf16(h_fw), joint[:, 256:512] = bf16(h_bw)     (layers.py:171-172, bf16 FC operand)
+__global__ __launch_bounds__(256) void pack_event_feat_bf16_kernel(const float* __restrict__ hfw, const float* __restrict__ hbw,
+                                                                    unsigned short* __restrict__ joint, int n, long joint_ld)
+{
+    const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;      // one thread per 4 values
+    if (i >= (long)n * 128) return;
+    const int site = (int)(i / 128), q = (int)(i % 128);
+    const float* src = q < 64 ? hfw + (size_t)site * 256 + q * 4 : hbw + (size_t)site * 256 + (q - 64) * 4;
+    const float4 v = *reinterpret_cast<const float4*>(src);
+    const unsigned lo = (unsigned)f2bf(v.x) | ((unsigned)f2bf(v.y) << 16), hi = (unsigned)f2bf(v.z) | ((unsigned)f2bf(v.w) << 16);
+    *reinterpret_cast<uint2*>(joint + site * joint_ld + q * 4) = make_uint2(lo, hi);
+}
+
+hipError_t launch_pack_event_feat_bf16(const float* hfw, const float* hbw, float* joint, int n, int joint_ld, hipStream_t s)
+{
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(pack_event_feat_bf16_kernel, dim3((unsigned)(((long)n * 128 + 255) / 256)), dim3(256), 0, s, hfw, hbw,
+                       (unsigned short*)joint, n, (long)joint_ld);
     return hipGetLastError();
 }
 

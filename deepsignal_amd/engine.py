@@ -39,7 +39,34 @@ class DsConfig(ctypes.Structure):
     ]
 
 
+# ds_config.precision (include/deepsignal_hip.h): "bf16" = bf16 conv + FC operands with fp32 accumulation, fp32 BiLSTM
+PRECISIONS = {"fp32": 0, "bf16": 1}
+
 _lib: Optional[ctypes.CDLL] = None
+
+
+def _share_hip_runtime_with_torch() -> None:
+    """One HIP runtime per process. PyTorch-ROCm wheels bundle their own libamdhip64.so (SONAME
+    libamdhip64.so.7) and ask for it by file name, so if this library pulls in /opt/rocm's copy first, a later
+    `import torch` loads a SECOND runtime that cannot see the GPU ("No HIP GPUs are available"). Mapping
+    torch's copy first (no torch import needed) lets both resolve to the same runtime in either import order.
+    Processes without torch installed simply use the system ROCm runtime."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
+        except OSError:
+            pass
 
 
 def load_library() -> ctypes.CDLL:
@@ -51,6 +78,7 @@ def load_library() -> ctypes.CDLL:
         raise RuntimeError(
             "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(or `make -C deepsignal_amd/csrc`). There is no CPU fallback." % LIB_PATH)
+    _share_hip_runtime_with_torch()
     lib = ctypes.CDLL(LIB_PATH)
     vp, i32, i64 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64
     lib.ds_create.argtypes = [ctypes.POINTER(DsConfig), ctypes.POINTER(vp)]
@@ -88,10 +116,14 @@ class Engine:
 
     def __init__(self, kmer_len: int = 17, signal_len: int = 360, class_num: int = 2, device: int = 0,
                  max_batch: int = 512, is_cnn: bool = True, is_rnn: bool = True, is_base: bool = True,
-                 debug: bool = False, slots: int = 0):
+                 debug: bool = False, slots: int = 0, precision: str = "fp32"):
         self._lib = load_library()
         self._h = ctypes.c_void_p()
-        cfg = DsConfig(kmer_len, signal_len, class_num, int(is_cnn), int(is_rnn), int(is_base), device, 0, max_batch)
+        if precision not in PRECISIONS:
+            raise ValueError("precision must be one of %s" % (sorted(PRECISIONS),))
+        self.precision = precision
+        cfg = DsConfig(kmer_len, signal_len, class_num, int(is_cnn), int(is_rnn), int(is_base), device,
+                       PRECISIONS[precision], max_batch)
         cfg.reserved[0] = 1 if debug else 0
         cfg.reserved[1] = slots          # forwards in flight for run_device (0 = engine default)
         rc = self._lib.ds_create(ctypes.byref(cfg), ctypes.byref(self._h))

@@ -29,6 +29,10 @@ extern "C" {
 #define DS_ERR_NOMEM (-5)
 
 #define DS_PRECISION_FP32 0
+/* BASELINE.json configs[2]: bf16 operands with fp32 accumulation for the signal model's convolutions and the joint
+ * FC (activations between those layers are stored as bf16); the BiLSTM, the Cin=1 stem conv, FC2, sigmoid and
+ * argmax stay fp32. Same ABI, same outputs to the tolerance stated in DESIGN.md. */
+#define DS_PRECISION_BF16 1
 
 typedef struct ds_handle ds_handle;
 
@@ -41,7 +45,7 @@ typedef struct ds_config {
     int32_t is_rnn;
     int32_t is_base;
     int32_t device;       /* HIP device ordinal */
-    int32_t precision;    /* DS_PRECISION_FP32 */
+    int32_t precision;    /* DS_PRECISION_FP32 | DS_PRECISION_BF16 */
     int32_t max_batch;    /* largest n per device pass (workspaces are sized for it); larger n is looped */
     int32_t reserved[7];  /* reserved[0] != 0: debug mode — keep every module output for ds_get_intermediate;
                              reserved[1]: forwards in flight for ds_forward_device (pipeline slots; default 8 for

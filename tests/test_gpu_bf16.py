@@ -1,0 +1,107 @@
+"""GPU tests of the mixed-precision mode (BASELINE.json configs[2]: "bf16 conv+FC with fp32 BiLSTM accumulate,
+batch=4096, tolerance vs fp32 reported"; include/deepsignal_hip.h DS_PRECISION_BF16).
+
+Two bars:
+  * exactness of the implementation: against tests/torch_statement.forward_bf16, which rounds to bf16 at the same
+    points (weights after BN folding, every stored conv activation, the FC operand). Only the fp32 accumulation
+    order differs, which can flip an occasional bf16 rounding (and a flipped input moves downstream values), so
+    the bound on the intermediates is: worst element within 4 bf16 ulps of the tensor's largest value, mean
+    difference below 1/4 ulp (measured <= 0.09 ulp at module 11), and 3e-3 on the sigmoid outputs. A first flip is
+    rare (~1e-5 per element) but cascades: sites without one reproduce the statement to ~1e-7, sites with one end up
+    a different realisation of the same bf16 rounding noise (~1e-3 on the outputs, the size of the bf16-vs-fp32
+    distance itself). The test prints the share of sites that match to 1e-6.
+  * tolerance vs fp32 (the number configs[2] asks to report): max |p_bf16 - p_fp32| <= 5e-3 at batch 4096 and
+    equal labels wherever the fp32 margin |p1 - p0| exceeds 2e-2. The measured value is printed (-s) and recorded
+    in DESIGN.md.
+"""
+import numpy as np
+import pytest
+
+import torch_statement
+from deepsignal_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+EMU_TAP_TOL_ULPS = 4.0
+EMU_TAP_MEAN_ULPS = 0.25
+
+
+def _ulp(x):
+    """bf16 spacing (8 significant bits) at magnitude x"""
+    return 2.0 ** (np.floor(np.log2(max(float(x), 1e-30))) - 7)
+
+EMU_ACT_ATOL = 3e-3
+FP32_ACT_ATOL = 5e-3
+FP32_LABEL_MARGIN = 2e-2
+
+
+def _engine(weights, **kw):
+    from deepsignal_amd.engine import Engine
+    eng = Engine(**kw)
+    eng.load_weights(weights)
+    return eng
+
+
+@pytest.mark.parametrize("n", [1, 24, 130])
+def test_bf16_layerwise_vs_emulated_statement(small_weights, n):
+    feats = synth.synthetic_features(n, seed=300 + n)
+    eng = _engine(small_weights, max_batch=160, debug=True, precision="bf16")
+    act, pred = eng.run(feats["kmer"], feats["means"], feats["stds"], feats["sanums"], feats["signals"])
+    e_act, e_pred, taps = torch_statement.forward_bf16(small_weights, feats, return_taps=True)
+    bad = {}
+    for name, ref in taps.items():
+        got = eng.intermediate(name, ref.shape)
+        err = float(np.abs(got - ref).max())
+        if name.startswith("lstm_") or name in ("fc1", "logits"):
+            # fp32 tensors: the BiLSTM is untouched; fc1 / logits see the flips of their bf16 inputs
+            tol = (2e-5 if name.startswith("lstm_") else 1e-2) * max(1.0, float(np.abs(ref).max()))
+        else:
+            u = _ulp(max(1.0, float(np.abs(ref).max())))
+            tol = EMU_TAP_TOL_ULPS * u
+            if not float(np.abs(got - ref).mean()) <= EMU_TAP_MEAN_ULPS * u:
+                bad[name + ":mean"] = (float(np.abs(got - ref).mean()), EMU_TAP_MEAN_ULPS * u)
+        if not err <= tol:
+            bad[name] = (err, tol)
+        if n == 24:
+            print("%-14s max|d| %.3e  mean|d| %.3e  max|ref| %.3f" % (name, err, float(np.abs(got - ref).mean()), float(np.abs(ref).max())))
+    assert not bad, "bf16 intermediates out of tolerance: %s" % bad
+    assert np.isfinite(act).all()
+    assert np.abs(act - e_act).max() <= EMU_ACT_ATOL
+    print("n=%d: %.0f%% of the sites reproduce the emulated statement to 1e-6, worst |d act| = %.2e"
+          % (n, 100.0 * float((np.abs(act - e_act).max(axis=1) < 1e-6).mean()), float(np.abs(act - e_act).max())))
+    eng.close()
+
+
+def test_bf16_config3_tolerance_vs_fp32(small_weights):
+    n = 4096
+    feats = synth.synthetic_features(n, seed=4096)
+    args = [feats[k] for k in ("kmer", "means", "stds", "sanums", "signals")]
+    e32 = _engine(small_weights, max_batch=n, slots=1)
+    a32, p32 = e32.run(*args)
+    e32.close()
+    e16 = _engine(small_weights, max_batch=n, slots=1, precision="bf16")
+    a16, p16 = e16.run(*args)
+    # ragged / small batches go through the non-dense kernel variants and must agree with the big batch
+    a_small, p_small = e16.run(*(a[100:177] for a in args))
+    e16.close()
+    assert np.isfinite(a16).all()
+    diff = float(np.abs(a16 - a32).max())
+    decided = np.abs(a32[:, 1] - a32[:, 0]) > FP32_LABEL_MARGIN
+    agree = float((p16[decided] == p32[decided]).mean()) if decided.any() else 1.0
+    print("\nbf16 vs fp32 at batch %d: max|dp| = %.3e, mean|dp| = %.3e, labels equal on %.4f of %d decided sites"
+          % (n, diff, float(np.abs(a16 - a32).mean()), agree, int(decided.sum())))
+    assert diff <= FP32_ACT_ATOL
+    assert agree == 1.0
+    assert np.array_equal(a_small, a16[100:177]) and np.array_equal(p_small, p16[100:177])
+
+
+def test_bf16_against_oracle_small(small_weights):
+    """Same gate as the north star states for the path (outputs within 1e-4 of the reference) does NOT hold for
+    bf16 -- this test documents the actual distance to the fp32 CPU oracle on a small batch."""
+    from oracle import oracle
+    feats = synth.synthetic_features(64, seed=77)
+    eng = _engine(small_weights, max_batch=64, precision="bf16")
+    act, pred = eng.run(feats["kmer"], feats["means"], feats["stds"], feats["sanums"], feats["signals"])
+    o_act, o_pred = oracle.forward(small_weights, feats, "f32")
+    assert np.abs(act - o_act).max() <= FP32_ACT_ATOL
+    eng.close()

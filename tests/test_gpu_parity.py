@@ -71,6 +71,18 @@ def test_batch_512_and_ragged_tail(small_weights):
     eng.close()
 
 
+def test_dense_and_masked_kernel_variants_agree_bitwise(small_weights):
+    """Batches that are a multiple of 128 take the row-mask-free kernel instantiations; a site must get the same
+    bits either way (explicit fma chains in the LSTM epilogue keep the two instantiations' rounding identical)."""
+    feats = synth.synthetic_features(256, seed=12)
+    keys = ("kmer", "means", "stds", "sanums", "signals")
+    eng = _engine(small_weights, max_batch=256)
+    act, pred = eng.run(*(feats[k] for k in keys))
+    a2, p2 = eng.run(*(feats[k][100:177] for k in keys))
+    assert np.array_equal(a2, act[100:177]) and np.array_equal(p2, pred[100:177])
+    eng.close()
+
+
 def test_graph_and_eager_agree_and_are_deterministic(small_weights):
     feats = synth.synthetic_features(96, seed=9)
     eng = _engine(small_weights, max_batch=128)

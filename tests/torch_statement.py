@@ -123,3 +123,74 @@ def _event_model(w, feats, kmer, n, T, dtype, taps, is_base):
             taps["lstm_%s_l%d" % (direction, layer)] = seq if direction == "fw" else torch.flip(seq, dims=[1])
         outs.append(seq[:, -1, :])      # fw: t=T-1 ; bw: last processed step == original t=0
     return outs
+
+
+# ---------------------------------------------------------------------------------------------
+# Mixed-precision statement (BASELINE.json configs[2]; include/deepsignal_hip.h DS_PRECISION_BF16):
+# bf16 operands / fp32 accumulation for the signal model's convolutions and the joint FC, activations
+# between those layers stored as bf16; fp32 BiLSTM, Cin=1 stem conv, FC2, sigmoid, argmax.
+# It rounds at exactly the points the engine rounds, so the HIP path can be held to a tight bound
+# (differences come only from fp32 accumulation order flipping an occasional bf16 rounding).
+def _rb(x: torch.Tensor) -> torch.Tensor:
+    return x.to(torch.float32).to(torch.bfloat16).to(x.dtype)
+
+
+def _conv_folded(x, w, c: spec.ConvBN, round_w: bool):
+    """conv with BN folded into (weights, bias) in float64, like ds_engine.cpp fold_conv; bf16-rounded weights."""
+    ker = w[c.kernel_name][0].to(torch.float64)                      # [K, Cin, Cout]
+    g, b = w[c.bn_tensor("gamma")].to(torch.float64), w[c.bn_tensor("beta")].to(torch.float64)
+    m, v = w[c.bn_tensor("moving_mean")].to(torch.float64), w[c.bn_tensor("moving_variance")].to(torch.float64)
+    sc = g / torch.sqrt(v + spec.BN_EPS)
+    kf = (ker * sc[None, None, :]).to(torch.float32)
+    bf = (b - m * sc).to(torch.float32)
+    if round_w:
+        kf = kf.to(torch.bfloat16).to(torch.float32)
+    kt = kf.to(x.dtype).permute(2, 1, 0).contiguous()
+    return F.conv1d(_same(x, c.k, c.stride), kt, stride=c.stride) + bf.to(x.dtype)[None, :, None]
+
+
+def forward_bf16(weights: Dict[str, np.ndarray], feats: Dict[str, np.ndarray], return_taps: bool = False):
+    dtype = torch.float64
+    w = {k: torch.from_numpy(np.asarray(v)).to(torch.float32) for k, v in weights.items()}
+    w64 = {k: v.to(dtype) for k, v in w.items()}
+    kmer = torch.from_numpy(feats["kmer"]).long()
+    n, T = kmer.shape
+    d = spec.net_dims(T, feats["signals"].shape[1], w["dense_1/kernel"].shape[1])
+    taps = {}
+    ev = _event_model(w64, feats, kmer, n, T, dtype, taps, True)     # fp32 BiLSTM in the engine; float64 here
+    # signal model
+    x = torch.from_numpy(feats["signals"]).to(dtype)[:, None, :]
+    stem = spec.stem_convs()
+    x = _rb(_maxpool3(torch.relu(_conv_folded(x, w, stem[0], False)), 2)); taps["stem_pool"] = x
+    x = _rb(torch.relu(_conv_folded(x, w, stem[1], True))); taps["stem_conv2"] = x
+    x = _rb(torch.relu(_conv_folded(x, w, stem[2], True))); taps["stem_conv3"] = x
+    for mth in range(1, spec.N_INCEPTION + 1):
+        c = spec.inception_convs(mth, d.module_cin(mth))
+        cv = lambda inp, key: _conv_folded(inp, w, c[key], True)
+        b1 = _rb(torch.relu(cv(_maxpool3(x, 1), "b1")))
+        b2 = _rb(torch.relu(cv(x, "b2")))
+        b3 = _rb(torch.relu(cv(_rb(torch.relu(cv(x, "b3a"))), "b3b")))
+        b4 = _rb(torch.relu(cv(_rb(torch.relu(cv(x, "b4a"))), "b4b")))
+        stem_r = cv(x, "b5s").to(torch.float32).to(dtype)              # kept fp32 by the engine
+        r = cv(_rb(torch.relu(cv(_rb(torch.relu(cv(x, "b5a"))), "b5b"))), "b5c")
+        b5 = _rb(torch.relu(stem_r + r))
+        x = torch.cat([b1, b2, b3, b4, b5], dim=1)
+        taps["module%d" % mth] = x
+        if mth in (3, 8):
+            x = _maxpool3(x, 2)
+    x = _rb(F.avg_pool1d(x, 7, stride=1, padding=3, count_include_pad=False))
+    signal_feat = x.permute(0, 2, 1).reshape(n, -1)
+    taps["signal_feat"] = signal_feat
+    joint = torch.cat([_rb(ev[0]), _rb(ev[1]), signal_feat], dim=1)
+    fc1 = (joint @ _rb(w64["dense/kernel"])).to(torch.float32).to(dtype)
+    logits = fc1 @ w64["dense_1/kernel"]
+    act = torch.sigmoid(logits)
+    pred = torch.argmax(act, dim=1)
+    taps.update(joint=joint, fc1=fc1, logits=logits)
+    if return_taps:
+        out = {}
+        for k, v in taps.items():
+            v = v.permute(0, 2, 1) if (k.startswith("stem") or k.startswith("module")) else v
+            out[k] = v.contiguous().to(torch.float32).numpy()
+        return act.to(torch.float32).numpy(), pred.to(torch.int32).numpy(), out
+    return act.to(torch.float32).numpy(), pred.to(torch.int32).numpy()
