@@ -150,19 +150,114 @@ def _write_predstr_to_file(write_fp, predstr_q):
     print("write process {} ending".format(os.getpid()))
 
 
+def load_model_weights(model_path: str, kmer_len: int, cent_signals_len: int, class_num: int,
+                       is_cnn: bool = True, is_rnn: bool = True, is_base: bool = True):
+    """`--model_path` resolution. The reference passes a TensorFlow checkpoint prefix to Saver.restore
+    (call_modifications.py:210-211; files <prefix>.index / .data-00000-of-00001); such a prefix is imported by
+    deepsignal_amd.tf_checkpoint and returned as a weight dict. Anything else is taken as a DSAMDW01 weight file
+    and returned as None (the engine reads it itself)."""
+    from . import tf_checkpoint
+    if tf_checkpoint.is_checkpoint(model_path):
+        return tf_checkpoint.checkpoint_to_weights(model_path, kmer_len, cent_signals_len, class_num,
+                                                   is_cnn=is_cnn, is_rnn=is_rnn, is_base=is_base)
+    if not os.path.exists(model_path):
+        raise FileNotFoundError("%s: neither a TensorFlow checkpoint prefix (no %s.index) nor a weight file"
+                                % (model_path, model_path))
+    return None
+
+
 def make_engine(model_path: str, kmer_len: int, cent_signals_len: int, class_num: int, batch_size: int,
-                is_cnn: bool = True, is_rnn: bool = True, is_base: bool = True, device: int = 0):
+                is_cnn: bool = True, is_rnn: bool = True, is_base: bool = True, device: int = 0,
+                precision: str = "fp32"):
     """Model(...) + Session + Saver.restore (reference call_modifications.py:203-212)."""
     from .engine import Engine
+    weights = load_model_weights(model_path, kmer_len, cent_signals_len, class_num, is_cnn, is_rnn, is_base)
     eng = Engine(kmer_len=kmer_len, signal_len=cent_signals_len, class_num=class_num, device=device,
-                 max_batch=batch_size, is_cnn=is_cnn, is_rnn=is_rnn, is_base=is_base)
-    eng.load_weights_file(model_path)
+                 max_batch=batch_size, is_cnn=is_cnn, is_rnn=is_rnn, is_base=is_base, precision=precision)
+    if weights is None:
+        eng.load_weights_file(model_path)
+    else:
+        eng.load_weights(weights)
     return eng
+
+
+def _distributed_context(dist):
+    """(dist module or None, rank, world, local device). `dist` = an initialised torch.distributed, or None to
+    look at the launcher's environment (torchrun / torch.distributed.run sets WORLD_SIZE, RANK, LOCAL_RANK)."""
+    if dist is not None:
+        return dist, dist.get_rank(), dist.get_world_size(), int(os.environ.get("LOCAL_RANK", dist.get_rank()))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world <= 1:
+        return None, 0, 1, 0
+    import torch.distributed as tdist
+    local = int(os.environ.get("LOCAL_RANK", os.environ.get("RANK", "0")))
+    if not tdist.is_initialized():
+        import torch
+        if torch.cuda.device_count() > 0:
+            torch.cuda.set_device(local)
+            tdist.init_process_group("nccl")           # RCCL over xGMI
+        else:
+            tdist.init_process_group("gloo")
+    return tdist, tdist.get_rank(), tdist.get_world_size(), local
+
+
+def _call_mods_sharded(reader_items, engine, batch_size, result_file, dist, rank, world, device=None):
+    """One process per GPU: queue items hold whole reads, item k is run by rank k % world on its own
+    weight replica; after every round of `world` items the 12 B/site results are gathered to rank 0 (the only
+    collective), which formats and writes the rows in file order -- reads stay contiguous (README.rst:15)."""
+    from . import fastio, sharding
+    nsites = 0
+    wf = open(result_file, "wb") if rank == 0 else None
+    round_items = []
+
+    def flush():
+        nonlocal nsites
+        if not round_items:
+            return
+        base = 0
+        act = np.zeros((0, engine.class_num), np.float32)
+        pred = np.zeros((0,), np.int32)
+        index = np.zeros((0,), np.int64)
+        for k, item, a, p in round_items:
+            n = len(item.labels)
+            if a is not None:
+                act, pred, index = a, p, np.arange(base, base + n, dtype=np.int64)
+            base += n
+        g_act, g_pred = sharding.gather_results(act, pred, index, dist, dst=0, device=device)
+        if rank == 0:
+            base = 0
+            for k, item, _, _ in round_items:
+                n = len(item.labels)
+                wf.write(fastio.format_rows(item.info, item.info_off, g_act[base:base + n], g_pred[base:base + n],
+                                            item.kmer))
+                base += n
+            wf.flush()
+        nsites += base
+        round_items.clear()
+
+    for k, item in enumerate(reader_items):
+        a = p = None
+        if k % world == rank:
+            n = len(item.labels)
+            acts, preds = [], []
+            for s in range(0, n, batch_size):
+                e = min(n, s + batch_size)
+                ai, pi = engine.run(item.kmer[s:e], item.means[s:e], item.stds[s:e], item.lens[s:e], item.signals[s:e])
+                acts.append(ai)
+                preds.append(pi)
+            a, p = np.concatenate(acts), np.concatenate(preds)
+        round_items.append((k, item, a, p))
+        if len(round_items) == world:
+            flush()
+    flush()
+    if wf is not None:
+        wf.close()
+    return nsites
 
 
 def call_mods(input_path, model_path, result_file, kmer_len, cent_signals_len,
               batch_size, learning_rate, class_num, nproc, is_gpu, is_rnn, is_base, is_cnn,
-              f5_args, engine=None, f5_batch_num=None, native_io=True):
+              f5_args, engine=None, f5_batch_num=None, native_io=True, precision="fp32", dist=None):
     """Feature-file mode of the reference's call_mods (call_modifications.py:417-495).
 
     learning_rate / nproc / is_gpu are accepted for signature compatibility: inference ignores the
@@ -175,12 +270,25 @@ def call_mods(input_path, model_path, result_file, kmer_len, cent_signals_len,
                                       class_num, is_rnn, is_base, is_cnn, f5_args, engine)
     if f5_batch_num is None:
         f5_batch_num = f5_args[0] if f5_args else 50
+    dist, rank, world, local = _distributed_context(dist)
     own = engine is None
     if own:
         engine = make_engine(model_path, kmer_len, cent_signals_len, class_num, batch_size,
-                             is_cnn=is_cnn, is_rnn=is_rnn, is_base=is_base)
+                             is_cnn=is_cnn, is_rnn=is_rnn, is_base=is_base, device=local, precision=precision)
     nsites = 0
-    if native_io:
+    if world > 1:
+        # launched as `python -m torch.distributed.run --nproc-per-node N -m deepsignal_amd.deepsignal call_mods ...`
+        if not native_io:
+            raise ValueError("multi-GPU call_mods uses the native feature reader (native_io=True)")
+        from . import fastio
+        reader = fastio.FeatureReader(input_path, kmer_len, cent_signals_len)
+        device = None
+        if dist.get_backend() == "nccl":
+            import torch
+            device = torch.device("cuda", local)
+        nsites = _call_mods_sharded(reader.items(f5_batch_num), engine, batch_size, result_file, dist, rank, world, device)
+        reader.close()
+    elif native_io:
         # row f1: native reader (host threads) + native row formatter; same items, same row text
         from . import fastio
         reader = fastio.FeatureReader(input_path, kmer_len, cent_signals_len)
@@ -227,7 +335,8 @@ def call_mods(input_path, model_path, result_file, kmer_len, cent_signals_len,
                 nsites += len(pred_str)
     if own:
         engine.close()
-    print("call_mods costs %.2f seconds.. (%d sites)" % (time.time() - start, nsites))
+    if rank == 0:
+        print("call_mods costs %.2f seconds.. (%d sites)" % (time.time() - start, nsites))
     return nsites
 
 

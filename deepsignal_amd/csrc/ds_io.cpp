@@ -315,4 +315,37 @@ int64_t ds_format_rows(int64_t n, const char* info, const int64_t* info_off, con
     return (int64_t)(p - out);
 }
 
+
+// CRC-32C, slicing-by-8 (tables built on first use). TF checkpoint tensors / table blocks carry it masked.
+uint32_t ds_crc32c(const void* data, size_t n, uint32_t crc)
+{
+    static uint32_t T[8][256];
+    static bool ready = false;
+    if (!ready) {
+        for (uint32_t i = 0; i < 256; ++i) {
+            uint32_t c = i;
+            for (int k = 0; k < 8; ++k) c = (c & 1) ? (c >> 1) ^ 0x82F63B78u : c >> 1;
+            T[0][i] = c;
+        }
+        for (uint32_t i = 0; i < 256; ++i) {
+            uint32_t c = T[0][i];
+            for (int k = 1; k < 8; ++k) { c = T[0][c & 0xFF] ^ (c >> 8); T[k][i] = c; }
+        }
+        ready = true;
+    }
+    const unsigned char* p = static_cast<const unsigned char*>(data);
+    crc = ~crc;
+    while (n >= 8) {
+        uint32_t lo, hi;
+        memcpy(&lo, p, 4);
+        memcpy(&hi, p + 4, 4);
+        lo ^= crc;
+        crc = T[7][lo & 0xFF] ^ T[6][(lo >> 8) & 0xFF] ^ T[5][(lo >> 16) & 0xFF] ^ T[4][lo >> 24] ^
+              T[3][hi & 0xFF] ^ T[2][(hi >> 8) & 0xFF] ^ T[1][(hi >> 16) & 0xFF] ^ T[0][hi >> 24];
+        p += 8; n -= 8;
+    }
+    while (n--) crc = T[0][(crc ^ *p++) & 0xFF] ^ (crc >> 8);
+    return ~crc;
+}
+
 }  // extern "C"

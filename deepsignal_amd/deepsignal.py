@@ -1,5 +1,10 @@
 """`deepsignal call_mods` command line — the reference's flag surface for this sub-command
-(reference deepsignal/deepsignal.py:236-326, defaults included), driving the MI355X engine."""
+(reference deepsignal/deepsignal.py:236-326, defaults included), driving the MI355X engine.
+
+Multi-GPU: one process per GPU, e.g.
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
+        -m deepsignal_amd.deepsignal call_mods -i features.tsv -m model.ckpt -o calls.tsv
+reads are dealt to the ranks, rank 0 gathers the results over RCCL and writes the file."""
 from __future__ import absolute_import
 
 import argparse
@@ -16,7 +21,8 @@ def main_call_mods(args):
                args.reference_path)
     call_mods(args.input_path, args.model_path, args.result_file, args.kmer_len, args.cent_signals_len,
               args.batch_size, args.learning_rate, args.class_num, args.nproc, str2bool(args.is_gpu),
-              str2bool(args.is_rnn), str2bool(args.is_base), str2bool(args.is_cnn), f5_args)
+              str2bool(args.is_rnn), str2bool(args.is_base), str2bool(args.is_cnn), f5_args,
+              precision=args.precision)
 
 
 def build_parser():
@@ -28,7 +34,11 @@ def build_parser():
                    help="a file of extracted features (fast5 dirs need `extract` first)")
     g.add_argument("--f5_batch_num", type=int, default=50)
     g = p.add_argument_group("CALL")
-    g.add_argument("--model_path", "-m", required=True, help="weight file (DSAMDW01)")
+    g.add_argument("--model_path", "-m", required=True,
+                   help="TensorFlow checkpoint prefix of a reference-trained model (<prefix>.index + .data-*), "
+                        "or a DSAMDW01 weight file")
+    g.add_argument("--precision", default="fp32", choices=["fp32", "bf16"],
+                   help="fp32 (reference numerics) or bf16 conv+FC operands with fp32 accumulate and fp32 BiLSTM")
     g.add_argument("--is_cnn", default="yes")
     g.add_argument("--is_rnn", default="yes")
     g.add_argument("--is_base", default="yes")

@@ -142,6 +142,12 @@ int64_t ds_format_rows(int64_t n, const char *info, const int64_t *info_off, con
                        int32_t class_num, const int32_t *pred, const int32_t *kmer, int32_t kmer_len,
                        char *out, int64_t cap);
 
+/* ---- scope row f3: TensorFlow checkpoint import (deepsignal_amd/tf_checkpoint.py) ----
+ * CRC-32C (Castagnoli) of a host buffer, continuing from `crc` (0 to start): the checksum TensorFlow's
+ * Saver stores (masked) for every tensor and table block of the checkpoints the reference restores with
+ * tf.train.Saver().restore (call_modifications.py:210-211). Host code only. */
+uint32_t ds_crc32c(const void *data, size_t n, uint32_t crc);
+
 /* Use a captured hipGraph for the forward (default on). */
 int ds_set_graph(ds_handle *h, int32_t enable);
 
