@@ -135,6 +135,7 @@ struct ds_handle {
     bool finalized = false;
     bool debug = false;
     int profiling = 0;    // 0 off | 1 one event pair per run of same-kernel launches on a stream | 2 per launch
+                          // | 3 like 1 with every launch on ONE stream (stand-alone kernel times, nothing co-resident)
     bool use_graph = true;
     std::map<std::string, HostTensor> host;
     std::vector<void*> allocs;
@@ -799,7 +800,9 @@ int enqueue_forward(ds_handle* h, Plan& plan, int timed)
     HIPCHK(h, hipEventRecord(h->cur->ev_fork, h->cur->s0));
     HIPCHK(h, hipStreamWaitEvent(h->cur->s1, h->cur->ev_fork, 0));
     bool joined = false;
-    static const bool serial = getenv("DS_SERIAL") != nullptr;   // diagnostic: one stream, no overlap
+    static const bool serial_env = getenv("DS_SERIAL") != nullptr;   // diagnostic: one stream, no overlap
+    const bool serial = serial_env || timed == 3;
+    if (timed == 3) timed = 1;
     Op* head[2] = {nullptr, nullptr};       // open run per stream (timed == 1)
     auto close_run = [&](int si) -> int {
         if (head[si]) {
@@ -1258,7 +1261,7 @@ int ds_set_profiling(ds_handle* h, int32_t enable)
 {
     if (!h) return DS_ERR_INVALID;
     int rc = ds_sync(h);
-    h->profiling = enable < 0 ? 0 : (enable > 2 ? 2 : enable);
+    h->profiling = enable < 0 ? 0 : (enable > 3 ? 3 : enable);
     return rc;
 }
 

@@ -98,6 +98,8 @@ int64_t ds_get_intermediate(ds_handle *h, const char *name, float *out, int64_t 
  *   mode 1: one event pair around every RUN of consecutive launches of the same kernel on a stream
  *           (per-kernel statistics with negligible bracketing overhead; inter-launch gaps included);
  *   mode 2: one event pair per launch (per-stage breakdown; ~10 us of bracketing per launch);
+ *   mode 3: mode 1 with every launch of the forward on ONE stream (stand-alone kernel times: nothing
+ *           else is resident on the GPU while a kernel runs);
  *   mode 0: off.
  * ds_get_stage reports, for stage index i, its name, launches per forward, accumulated device
  * milliseconds (mode 2) and forward count since the last reset. */

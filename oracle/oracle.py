@@ -58,6 +58,23 @@ def _lib(precision: str) -> ctypes.CDLL:
     return _LIBS[precision]
 
 
+def usable_cores() -> int:
+    """Cores this process may use (affinity mask and cgroup CPU quota respected): an OpenMP team wider than the
+    quota thrashes on the GPU boxes (256 logical CPUs, 16-CPU quota)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, -(-int(quota) // int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
 def forward(weights: Dict[str, np.ndarray], feats: Dict[str, np.ndarray], precision: str = "f32",
             taps: bool = False, nthreads: int = 0, kmer_len: int = 17, signal_len: int = 360,
             class_num: int = 2, is_cnn: bool = True, is_rnn: bool = True, is_base: bool = True):
@@ -111,7 +128,7 @@ def forward(weights: Dict[str, np.ndarray], feats: Dict[str, np.ndarray], precis
                                ctypes.c_void_p(kmer.ctypes.data), ctypes.c_void_p(means.ctypes.data),
                                ctypes.c_void_p(stds.ctypes.data), ctypes.c_void_p(sanums.ctypes.data),
                                ctypes.c_void_p(signals.ctypes.data), ctypes.c_void_p(act.ctypes.data),
-                               ctypes.c_void_p(pred.ctypes.data), tp, ctypes.c_int(nthreads))
+                               ctypes.c_void_p(pred.ctypes.data), tp, ctypes.c_int(nthreads or usable_cores()))
     if rc != 0:
         raise RuntimeError("ds_oracle_forward failed: %d" % rc)
     if taps:

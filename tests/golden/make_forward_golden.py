@@ -16,7 +16,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 sys.path.insert(0, os.path.dirname(HERE))
 from deepsignal_amd import synth, weights  # noqa: E402
 from oracle import oracle  # noqa: E402
-import torch_statement  # noqa: E402
+from oracle import torch_statement  # noqa: E402
 
 WEIGHT_SEED, FEATURE_SEED, N = 7, 2024, 12
 w = weights.random_weights(seed=WEIGHT_SEED, lstm_bias_std=0.1)

@@ -2,7 +2,7 @@
 batch=4096, tolerance vs fp32 reported"; include/deepsignal_hip.h DS_PRECISION_BF16).
 
 Two bars:
-  * exactness of the implementation: against tests/torch_statement.forward_bf16, which rounds to bf16 at the same
+  * exactness of the implementation: against oracle/torch_statement.forward_bf16, which rounds to bf16 at the same
     points (weights after BN folding, every stored conv activation, the FC operand). Only the fp32 accumulation
     order differs, which can flip an occasional bf16 rounding (and a flipped input moves downstream values), so
     the bound on the intermediates is: worst element within 4 bf16 ulps of the tensor's largest value, mean
@@ -17,7 +17,7 @@ Two bars:
 import numpy as np
 import pytest
 
-import torch_statement
+from oracle import torch_statement
 from deepsignal_amd import synth
 
 pytestmark = pytest.mark.gpu

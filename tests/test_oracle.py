@@ -9,7 +9,7 @@ import torch
 
 from deepsignal_amd import spec, synth, weights
 from oracle import oracle
-import torch_statement
+from oracle import torch_statement
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden", "forward_golden.npz")
 
