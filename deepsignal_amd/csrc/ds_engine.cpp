@@ -67,7 +67,7 @@ struct Op {
 
 // per-kernel accumulators (one entry per __global__ function / template instantiation)
 enum KernelClass { K_GEMM_CONV = 0, K_GEMM_FC, K_GEMM_LSTM, K_GEMM_CONV_WIDE, K_GEMM_CONV_POOL, K_GEMM_FC_DENSE, K_GEMM_LSTM_DENSE, K_FUSED1, K_FUSED2, K_FUSED3, K_STEM1, K_MAXPOOL, K_AVGPOOL, K_HEAD,
-                   K_GEMM_BCONV, K_GEMM_BCONV_POOL, K_GEMM_BFC, K_GEMM_BFC_DENSE, K_PACKEV, K_COUNT };
+                   K_GEMM_BCONV, K_GEMM_BCONV_POOL, K_GEMM_BFC, K_GEMM_BFC_DENSE, K_PACKEV, K_GEMM_BLSTM, K_GEMM_BLSTM_DENSE, K_FUSEDB1, K_FUSEDB2, K_FUSEDB3, K_COUNT };
 const char* const kKernelNames[K_COUNT] = {"gemm_kernel<1,2,4,1,0,0,1,1>", "gemm_kernel<1,3,4,1,0,0,2,1>", "gemm_kernel<1,4,4,1,1,0,1,1>",
                                            "gemm_kernel<2,2,2,2,0,0,1,1>", "gemm_kernel<1,2,4,1,0,1,1,1>", "gemm_kernel<1,3,4,1,0,2,2,1>",
                                            "gemm_kernel<1,4,4,1,1,2,1,1>", "inception_fused_kernel<1>",
@@ -75,7 +75,9 @@ const char* const kKernelNames[K_COUNT] = {"gemm_kernel<1,2,4,1,0,0,1,1>", "gemm
                                            "maxpool_s2_kernel", "avgpool7_kernel", "head_kernel",
                                            "gemm_kernel<1,2,4,1,0,0,1,1,bf16>", "gemm_kernel<1,2,4,1,0,1,1,1,bf16>",
                                            "gemm_kernel<4,2,1,4,0,0,2,1,bf16>", "gemm_kernel<4,2,1,4,0,2,2,1,bf16>",
-                                           "pack_event_feat_bf16_kernel"};
+                                           "pack_event_feat_bf16_kernel", "gemm_kernel<1,4,4,1,1,0,1,1,bf16>",
+                                           "gemm_kernel<1,4,4,1,1,2,1,1,bf16>", "inception_fused_bf16_kernel<1>",
+                                           "inception_fused_bf16_kernel<2>", "inception_fused_bf16_kernel<3>"};
 struct KernelStat {
     int64_t launches = 0;
     double total_ms = 0;
@@ -131,6 +133,8 @@ struct ds_handle {
     int B = 512;
     bool is_cnn = true, is_rnn = true, is_base = true;   // model.py:28-29,59-75,89-95
     bool bf16 = false;    // DS_PRECISION_BF16: bf16 conv + FC operands (fp32 accumulate), fp32 BiLSTM
+    bool lstm_bf16 = false;   // DS_PRECISION_BF16_ALL: additionally bf16 h / weight operands in the LSTM matmuls (fp32 accumulate,
+                              // gates and cell state; the layer-0 input projection stays an fp32 table lookup)
     int JP = 0;           // J rounded up to a whole K chunk (32 bf16)
     bool finalized = false;
     bool debug = false;
@@ -385,11 +389,12 @@ int finalize_weights(ds_handle* h)
             const int row0 = l == 0 ? in0 : 0;
             const int K = l == 0 ? HID : 2 * HID;
             // packed n-tile p = ug*4 + g  <->  TF columns g*256 + ug*32 + [0,32)
-            std::vector<float> packed = pack_b(K, 4 * HID, [&](int k, int pc) {
+            auto wfun = [&](int k, int pc) {
                 const int p = pc / 32, j = pc % 32, ug = p / 4, g = p % 4;
                 return kd[(size_t)(row0 + k) * 4 * HID + g * HID + ug * 32 + j];
-            });
-            h->lstm[d][l].K = K; h->lstm[d][l].N = 4 * HID;
+            };
+            std::vector<float> packed = h->lstm_bf16 ? pack_b_bf16(K, 4 * HID, wfun) : pack_b(K, 4 * HID, wfun);
+            h->lstm[d][l].K = h->lstm_bf16 ? K / 2 : K; h->lstm[d][l].N = 4 * HID;
             if ((rc = upload(h, &h->lstm[d][l].Bp, packed))) return rc;
             if ((rc = upload(h, &h->lstm[d][l].bias, bias->data))) return rc;
             if (l == 0) {
@@ -580,7 +585,7 @@ int build_plan(ds_handle* h, int n, Plan* plan)
         const int W = module_width(h, m), M = n * W;
         float* y = h->cur->modout[m];
         static const bool no_fused = getenv("DS_NO_FUSED") != nullptr;
-        if (!no_fused && !bf && W <= 96) {
+        if (!no_fused && W <= 96) {
             // one fused launch per module; tile = spt whole sites (<= 96 rows). Pick the spt that
             // minimises padded rows while keeping >= 256 workgroups when the batch allows it.
             int best_spt = 1; long best_rows = -1;
@@ -594,7 +599,7 @@ int build_plan(ds_handle* h, int n, Plan* plan)
             Op op{};
             op.kind = OP_FUSED; op.stream = 0; op.stage = st;
             op.tm = (best_spt * W + 31) / 32;
-            op.fa.X = x; op.fa.Y = y; op.fa.n_sites = n; op.fa.W = W; op.fa.cin = cin; op.fa.spt = best_spt;
+            op.fa.X = x; op.fa.Y = y; op.fa.n_sites = n; op.fa.W = W; op.fa.cin = bf ? 128 : cin; op.fa.spt = best_spt;   // bf16: row pitch in units
             op.fa.pool_win = pend_pool_win; op.fa.pool_pad = pend_pool_pad;
             pend_pool_win = 0;
             op.fa.Bp1 = h->m_f1[m].Bp; op.fa.bias1 = h->m_f1[m].bias;
@@ -659,7 +664,7 @@ int build_plan(ds_handle* h, int n, Plan* plan)
         if (m == 2 || m == 7) {   // maxpool_layer2/3                            layers.py:211-213,224-226
             const int wout = m == 2 ? h->wb : h->wc, pad = m == 2 ? h->pl_pool2 : h->pl_pool3;
             static const bool no_fused2 = getenv("DS_NO_FUSED") != nullptr;
-            if (!no_fused2 && !bf && wout <= 96 && !h->debug_keep_pool) {
+            if (!no_fused2 && wout <= 96 && !h->debug_keep_pool) {
                 pend_pool_win = W; pend_pool_pad = pad;      // folded into module m+2's staging: no launch, no buffer
             } else {
                 Op op{};
@@ -685,7 +690,12 @@ int build_plan(ds_handle* h, int n, Plan* plan)
     st = stage_id(h, "bilstm", 1);
     const int T = h->T;
     // dense variants skip the per-row validity selects; legal when every tile row is a real site
-    const GemmCfg lstm_cfg = n % 128 == 0 ? CFG_LSTM_DENSE : CFG_LSTM;
+    const bool lbf = h->lstm_bf16;
+    const GemmCfg lstm_cfg = lbf ? (n % 128 == 0 ? CFG_BLSTM_DENSE : CFG_BLSTM) : (n % 128 == 0 ? CFG_LSTM_DENSE : CFG_LSTM);
+    const int HU = lbf ? HID / 2 : HID;                 // row pitch / K of an h operand in 4-byte units
+    auto hptr = [&](int dir, int l, int t) {            // h(dir, l, t): [n][256] fp32, or bf16 when lbf
+        return h->cur->H[dir][l] + (size_t)t * h->B * HU;
+    };
     const GemmCfg fc_cfg = bf ? (n % 128 == 0 ? CFG_BFC_DENSE : CFG_BFC) : (n % 128 == 0 ? CFG_FC_DENSE : CFG_FC);
     for (int d = 0; h->is_rnn && d < T + NLAYER - 1; ++d) {
         GemmLaunch L{};
@@ -696,13 +706,13 @@ int build_plan(ds_handle* h, int n, Plan* plan)
                 const int t = dir == 0 ? s : T - 1 - s;
                 const int tprev = dir == 0 ? t - 1 : t + 1;
                 GemmProblem P = base_problem(n, 4 * HID, n, h->lstm[dir][l]);
-                if (l > 0) add_seg(P, h->cur->H[dir][l - 1] + (size_t)t * h->B * HID, HID, 0, HID);
-                if (s > 0) add_seg(P, h->cur->H[dir][l] + (size_t)tprev * h->B * HID, HID, 0, HID);
+                if (l > 0) add_seg(P, hptr(dir, l - 1, t), HU, 0, HU);
+                if (s > 0) add_seg(P, hptr(dir, l, tprev), HU, 0, HU);
                 P.lstm.table = l == 0 ? h->lstm_table[dir] : nullptr;
                 P.lstm.wfeat = h->lstm_wfeat[dir];
                 P.lstm.codes = h->cur->d_kmer; P.lstm.means = h->cur->d_means; P.lstm.stds = h->cur->d_stds; P.lstm.lens = h->cur->d_sanums;
                 P.lstm.c = h->cur->Cst[dir][l];
-                P.lstm.h_out = h->cur->H[dir][l] + (size_t)t * h->B * HID;
+                P.lstm.h_out = hptr(dir, l, t);
                 P.lstm.t = t; P.lstm.T = T; P.lstm.c_zero = s == 0; P.lstm.use_feat = l == 0;
                 add_tiles(L, P, lstm_cfg);
             }
@@ -778,11 +788,12 @@ int issue_op(ds_handle* h, Plan& plan, const Op& op, hipStream_t s)
         else HIPCHK(h, launch_avgpool7(op.in, op.out, n, op.a, op.d, s));
         break;
     case OP_PACKEV:
-        HIPCHK(h, launch_pack_event_feat_bf16(h->cur->H[0][NLAYER - 1] + (size_t)(h->T - 1) * h->B * HID, h->cur->H[1][NLAYER - 1],
-                                              h->cur->joint, n, h->JP, s));
+        HIPCHK(h, launch_pack_event_feat_bf16(h->cur->H[0][NLAYER - 1] + (size_t)(h->T - 1) * h->B * (h->lstm_bf16 ? HID / 2 : HID),
+                                              h->cur->H[1][NLAYER - 1], h->cur->joint, n, h->JP, h->lstm_bf16, s));
         break;
     case OP_FUSED:
-        HIPCHK(h, launch_inception_fused(op.tm, op.fa, s));
+        if (h->bf16) HIPCHK(h, launch_inception_fused_bf16(op.tm, op.fa, s));
+        else HIPCHK(h, launch_inception_fused(op.tm, op.fa, s));
         break;
     case OP_HEAD:
         HIPCHK(h, launch_head(h->cur->fc1o, h->fc2, h->cur->logits, h->cur->act, h->cur->pred, n, h->J, h->C, s));
@@ -863,8 +874,11 @@ int kernel_class(const Op& op)
                : op.cfg == CFG_CONV_POOL ? K_GEMM_CONV_POOL : op.cfg == CFG_FC_DENSE ? K_GEMM_FC_DENSE
                : op.cfg == CFG_LSTM_DENSE ? K_GEMM_LSTM_DENSE : op.cfg == CFG_BCONV ? K_GEMM_BCONV
                : op.cfg == CFG_BCONV_POOL ? K_GEMM_BCONV_POOL : op.cfg == CFG_BFC ? K_GEMM_BFC
-               : op.cfg == CFG_BFC_DENSE ? K_GEMM_BFC_DENSE : K_GEMM_CONV_WIDE;
-    case OP_FUSED: return op.tm == 1 ? K_FUSED1 : op.tm == 2 ? K_FUSED2 : K_FUSED3;
+               : op.cfg == CFG_BFC_DENSE ? K_GEMM_BFC_DENSE : op.cfg == CFG_BLSTM ? K_GEMM_BLSTM
+               : op.cfg == CFG_BLSTM_DENSE ? K_GEMM_BLSTM_DENSE : K_GEMM_CONV_WIDE;
+    case OP_FUSED:
+        if (op.fa.cin == 128) return op.tm == 1 ? K_FUSEDB1 : op.tm == 2 ? K_FUSEDB2 : K_FUSEDB3;   // bf16 rows: pitch in units
+        return op.tm == 1 ? K_FUSED1 : op.tm == 2 ? K_FUSED2 : K_FUSED3;
     case OP_STEM1: return K_STEM1;
     case OP_MAXPOOL: return K_MAXPOOL;
     case OP_AVGPOOL: return K_AVGPOOL;
@@ -953,8 +967,8 @@ int ds_create(const ds_config* cfg, ds_handle** out)
     *out = nullptr;
     if (!(cfg->is_cnn || cfg->is_rnn))
         return fail(nullptr, DS_ERR_INVALID, "at least one of is_cnn/is_rnn should be True");      // model.py:28-29
-    if (cfg->precision != DS_PRECISION_FP32 && cfg->precision != DS_PRECISION_BF16)
-        return fail(nullptr, DS_ERR_UNSUPPORTED, "precision must be DS_PRECISION_FP32 or DS_PRECISION_BF16");
+    if (cfg->precision != DS_PRECISION_FP32 && cfg->precision != DS_PRECISION_BF16 && cfg->precision != DS_PRECISION_BF16_ALL)
+        return fail(nullptr, DS_ERR_UNSUPPORTED, "precision must be DS_PRECISION_FP32, DS_PRECISION_BF16 or DS_PRECISION_BF16_ALL");
     if (cfg->kmer_len < 1 || cfg->kmer_len > 255 || (cfg->kmer_len & 1) == 0)
         return fail(nullptr, DS_ERR_INVALID, "kmer_len must be odd and in [1,255]");
     if (cfg->signal_len < 16 || cfg->class_num < 1 || cfg->class_num > 16)
@@ -977,7 +991,8 @@ int ds_create(const ds_config* cfg, ds_handle** out)
     h->is_cnn = cfg->is_cnn != 0; h->is_rnn = cfg->is_rnn != 0; h->is_base = cfg->is_base != 0;
     h->SF = h->wc * INC_OUT;
     h->J = (h->is_rnn ? 2 * HID : 0) + (h->is_cnn ? h->SF : 0);     // layers.py:248-255
-    h->bf16 = cfg->precision == DS_PRECISION_BF16;
+    h->bf16 = cfg->precision == DS_PRECISION_BF16 || cfg->precision == DS_PRECISION_BF16_ALL;
+    h->lstm_bf16 = cfg->precision == DS_PRECISION_BF16_ALL && h->is_rnn;
     h->JP = (h->J + 31) / 32 * 32;
     h->debug = cfg->reserved[0] != 0;
 #define CK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { fail(nullptr, DS_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); ds_destroy(h); return DS_ERR_HIP; } } while (0)
@@ -1212,6 +1227,17 @@ int64_t ds_get_intermediate(ds_handle* h, const char* name, float* out, int64_t 
         if (l < 0 || l >= NLAYER) return fail(h, DS_ERR_INVALID, "bad lstm layer");
         const int64_t count = (int64_t)n * h->T * HID;
         if (count > capacity) return fail(h, DS_ERR_INVALID, "capacity too small");
+        if (h->lstm_bf16) {
+            std::vector<uint16_t> tb((size_t)h->T * h->B * HID);
+            if (hipMemcpy(tb.data(), h->cur->H[d][l], tb.size() * 2, hipMemcpyDeviceToHost) != hipSuccess) return fail(h, DS_ERR_HIP, "hipMemcpy D2H");
+            for (int i = 0; i < n; ++i)
+                for (int t = 0; t < h->T; ++t)
+                    for (int c = 0; c < HID; ++c) {
+                        const uint32_t u = (uint32_t)tb[((size_t)t * h->B + i) * HID + c] << 16;
+                        memcpy(out + ((size_t)i * h->T + t) * HID + c, &u, 4);
+                    }
+            return count;
+        }
         std::vector<float> tmp((size_t)h->T * h->B * HID);
         if (hipMemcpy(tmp.data(), h->cur->H[d][l], tmp.size() * 4, hipMemcpyDeviceToHost) != hipSuccess) return fail(h, DS_ERR_HIP, "hipMemcpy D2H");
         for (int i = 0; i < n; ++i)

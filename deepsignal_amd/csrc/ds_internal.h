@@ -43,7 +43,7 @@ struct LstmEp {
     const float* stds;
     const float* lens;
     float* c;             // [n][256] cell state (read-modify-write)
-    float* h_out;         // [n][256]
+    float* h_out;         // [n][256] (bf16 [n][256] in the bf16-operand instantiations)
     int t;                // original time index this step consumes
     int T;
     int c_zero;           // 1: previous c is zero (first step)
@@ -74,7 +74,7 @@ struct GemmLaunch {
 
 enum GemmCfg { CFG_CONV = 0, CFG_FC = 1, CFG_LSTM = 2, CFG_CONV_WIDE = 3, CFG_CONV_POOL = 4, CFG_FC_DENSE = 5, CFG_LSTM_DENSE = 6,
                // bf16-operand variants (mixed-precision mode)
-               CFG_BCONV = 7, CFG_BCONV_POOL = 8, CFG_BFC = 9, CFG_BFC_DENSE = 10 };
+               CFG_BCONV = 7, CFG_BCONV_POOL = 8, CFG_BFC = 9, CFG_BFC_DENSE = 10, CFG_BLSTM = 11, CFG_BLSTM_DENSE = 12 };
 
 // tile geometry per config (host needs it for grid sizing)
 struct TileGeom { int bm, bn, threads, ksplit; };
@@ -98,6 +98,9 @@ struct FusedArgs {
 // tm = 32-row m-tiles per workgroup (1..3), spt*W <= 32*tm
 hipError_t launch_inception_fused(int tm, const FusedArgs& a, hipStream_t s);
 size_t inception_fused_lds_bytes(int tm, int W, int spt);
+// bf16-operand variant: X / Y are bf16 rows of 256-channel pitch, a.cin is the row pitch in 4-byte units (128)
+hipError_t launch_inception_fused_bf16(int tm, const FusedArgs& a, hipStream_t s);
+size_t inception_fused_bf16_lds_bytes(int tm, int W, int spt);
 
 // stem conv1 (K=7, stride 2, Cin=1) + folded BN + ReLU + maxpool(3, stride 2)   layers.py:183-191
 hipError_t launch_stem1(const float* signals, const float* w7x64, const float* bias64, float* out,
@@ -106,7 +109,8 @@ hipError_t launch_stem1(const float* signals, const float* w7x64, const float* b
 hipError_t launch_maxpool_s2_bf16(const float* in, float* out, int n, int win, int wout, int pad_l, int ch_ld, hipStream_t s);
 hipError_t launch_avgpool7_bf16(const float* in, float* joint, int n, int w, int ch, int ld_in, int joint_ld, int joint_off,
                                 hipStream_t s);
-hipError_t launch_pack_event_feat_bf16(const float* hfw, const float* hbw, float* joint, int n, int joint_ld, hipStream_t s);
+hipError_t launch_pack_event_feat_bf16(const float* hfw, const float* hbw, float* joint, int n, int joint_ld, int src_bf16,
+                                       hipStream_t s);
 // maxpool(3, stride 2, SAME) over [n, win, ch] -> [n, wout, ch]                 layers.py:211-213,224-226
 hipError_t launch_maxpool_s2(const float* in, float* out, int n, int win, int wout, int pad_l, int ch, hipStream_t s);
 // avgpool(7, stride 1, SAME, divisor = valid taps) + flatten                    layers.py:233-238

@@ -60,6 +60,18 @@ __device__ __forceinline__ float4 bf8max(float4 a, float4 b)
 {
     return make_float4(bf2max(a.x, b.x), bf2max(a.y, b.y), bf2max(a.z, b.z), bf2max(a.w, b.w));
 }
+// Max of packed bf16 values that are all >= 0 (or -0): every pooled tensor of this network is a ReLU output, and for
+// non-negative floats the bit patterns order like signed 16-bit integers (-0 = 0x8000 is the smallest, so
+// max(-0, x) = x as it should). One v_pk_max_i16 per pair instead of ~9 VALU ops.
+typedef short short2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float bf2max_nn(float a, float b)
+{
+    return __builtin_bit_cast(float, __builtin_elementwise_max(__builtin_bit_cast(short2v, a), __builtin_bit_cast(short2v, b)));
+}
+__device__ __forceinline__ float4 bf8max_nn(float4 a, float4 b)
+{
+    return make_float4(bf2max_nn(a.x, b.x), bf2max_nn(a.y, b.y), bf2max_nn(a.z, b.z), bf2max_nn(a.w, b.w));
+}
 __device__ __forceinline__ unsigned short f2bf(float v)     // round to nearest even (v_cvt_pk_bf16_f32)
 {
     return __builtin_bit_cast(unsigned short, (__bf16)v);
@@ -219,7 +231,7 @@ __global__ __launch_bounds__(64 * WM * WN * KS, (EPI == 1 && KS == 1) ? 2 : 1) v
         for (int i = 0; i < SLOTS; ++i) {
             const int idx = tid + i * NTHR;
             float4 v = R[X][i];
-            if (AMODE == 1) v = BF ? bf8max(bf8max(v, Rm[X][i]), Rp[X][i])
+            if (AMODE == 1) v = BF ? bf8max_nn(bf8max_nn(v, Rm[X][i]), Rp[X][i])
                                    : f4max(f4max(v, Rm[X][i]), Rp[X][i]);   // maxpool(3, s1, SAME): padded taps ignored
             if (AMODE != 2) {     // AMODE 2 = dense: every row of every tile is valid, no taps -> no select
                 v.x = lok[X][i] ? v.x : 0.0f;
@@ -447,6 +459,7 @@ __global__ __launch_bounds__(64 * WM * WN * KS, (EPI == 1 && KS == 1) ? 2 : 1) v
             const gptr1 cg = (gptr1)E.c;
             const gptr1w cgw = (gptr1w)E.c;
             const gptr1w hg = (gptr1w)E.h_out;
+            __attribute__((address_space(1))) unsigned short* const hbg = (__attribute__((address_space(1))) unsigned short*)E.h_out;   // BF: h is stored as bf16
             const gptr1 tabg = (gptr1)E.table;
             const gptr1 meang = (gptr1)E.means, stdg = (gptr1)E.stds, leng = (gptr1)E.lens;
             const __attribute__((address_space(1))) int* codeg = (const __attribute__((address_space(1))) int*)E.codes;
@@ -496,7 +509,7 @@ __global__ __launch_bounds__(64 * WM * WN * KS, (EPI == 1 && KS == 1) ? 2 : 1) v
                         const float hn = fast_sigmoid(zo) * fast_tanh(cn);
                         if (ok[k]) {
                             cgw[off[k]] = cn;
-                            hg[off[k]] = hn;
+                            if (BF) hbg[off[k]] = f2bf(hn); else hg[off[k]] = hn;
                         }
                     }
                 }
@@ -518,6 +531,8 @@ TileGeom gemm_geom(GemmCfg cfg)
     case CFG_BCONV_POOL: return {128, 64, 256, 1};
     case CFG_BFC: return {128, 256, 256, 1};        // MT4 NT2 WM1 WN4: every wave owns all 128 rows x 64 columns, so a
     case CFG_BFC_DENSE: return {128, 256, 256, 1};  // weight fragment is loaded by exactly one wave of the workgroup
+    case CFG_BLSTM: return {128, 128, 256, 1};      // CFG_LSTM with bf16 h / weight operands (fp32 accumulate, gates, cell state)
+    case CFG_BLSTM_DENSE: return {128, 128, 256, 1};
     }
     return {0, 0, 0, 1};
 }
@@ -537,6 +552,8 @@ hipError_t launch_gemm(GemmCfg cfg, const GemmLaunch* d_launch, int total_tiles,
     case CFG_BCONV_POOL: hipLaunchKernelGGL((gemm_kernel<1, 2, 4, 1, 0, 1, 1, 1, true>), dim3(total_tiles), dim3(256), 0, s, d_launch); break;
     case CFG_BFC: hipLaunchKernelGGL((gemm_kernel<4, 2, 1, 4, 0, 0, 2, 1, true>), dim3(total_tiles), dim3(256), 0, s, d_launch); break;
     case CFG_BFC_DENSE: hipLaunchKernelGGL((gemm_kernel<4, 2, 1, 4, 0, 2, 2, 1, true>), dim3(total_tiles), dim3(256), 0, s, d_launch); break;
+    case CFG_BLSTM: hipLaunchKernelGGL((gemm_kernel<1, 4, 4, 1, 1, 0, 1, 1, true>), dim3(total_tiles), dim3(256), 0, s, d_launch); break;
+    case CFG_BLSTM_DENSE: hipLaunchKernelGGL((gemm_kernel<1, 4, 4, 1, 1, 2, 1, 1, true>), dim3(total_tiles), dim3(256), 0, s, d_launch); break;
     }
     return hipGetLastError();
 }
@@ -940,6 +957,382 @@ hipError_t launch_inception_fused(int tm, const FusedArgs& a, hipStream_t s)
 }
 
 // ---------------------------------------------------------------------------------------------
+// Fused inception module, bf16 operands (DS_PRECISION_BF16*). Same phases and wave roles as
+// inception_fused_kernel; what changes is the data: activations are bf16 rows of 256-channel pitch (channels
+// 240..255 are zero), a K chunk is 16 four-byte units = 32 channels = two v_mfma_f32_32x32x16_bf16 steps, the
+// 32/64-channel intermediates live in LDS as bf16 (T1 row = 104, T2 row = 72 elements: odd numbers of 16-B
+// slots, conflict-free ds_read_b128), accumulation / bias / ReLU / residual are fp32 and every value is rounded
+// to bf16 (nearest even) exactly once, when it is stored. HBM traffic per module row: 512 B in, 480 B out.
+#ifndef DS_FUSEDB_WPS
+#define DS_FUSEDB_WPS 2
+#endif
+constexpr int B_LDA = 132;      // staged input row stride in units (256 channels + 8 pad: 33 x 16 B, odd)
+constexpr int B_LD1 = 52;       // T1 / output-tile row stride in units (96 channels + 8 pad)
+constexpr int B_LD2 = 36;       // T2 row stride in units (64 channels + 8 pad)
+
+size_t inception_fused_bf16_lds_bytes(int tm, int W, int spt)
+{
+    const int tr32 = tm * 32;
+    return (size_t)(2 * tr32 * B_LDA + (spt * (W + 4) + 5) * B_LD1 + tr32 + 192) * sizeof(float);    // input + pooled tile (T2, Ys alias the input tile) | T1 | rowmap | 3x64 biases
+}
+
+__device__ __forceinline__ floatx16 mfma_bf(float4 a, float4 b, floatx16 c)
+{
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+// weights of one conv unit: ntaps x 2 k-steps (<= 10 fragments); the packed panel of an n-tile holds KS k-steps
+__device__ __forceinline__ void fusedb_unit_prefetch(const float* __restrict__ Bp, int ntaps, int nt, int lane, float4 (&ub)[10])
+{
+    const int ks = (ntaps * 32 + 63) / 64 * 4;      // K padded to 64 elements by pack_b_bf16
+    const float* bsrc = Bp + ((size_t)(nt * ks) * 64 + lane) * 4;
+#pragma unroll
+    for (int g = 0; g < 10; ++g)
+        if (g < ntaps * 2) ub[g] = gload4(bsrc + g * 256);
+}
+
+template <int NTAPS>
+__device__ __forceinline__ void fusedb_conv_unit(const float* T1, int rm, int coloff_units, int lane, const float4 (&ub)[10], floatx16& acc)
+{
+    const float* base = T1 + rm * B_LD1 + coloff_units + (lane >> 5) * 4;
+#pragma unroll
+    for (int t = 0; t < NTAPS; ++t) {
+        const float* arow = base + (t - NTAPS / 2) * B_LD1;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            acc = mfma_bf(ub[t * 2 + j], *reinterpret_cast<const float4*>(arow + j * 8), acc);     // transposed: see the kernel
+    }
+}
+
+template <int TM>
+__global__ __launch_bounds__(512, DS_FUSEDB_WPS) void inception_fused_bf16_kernel(const FusedArgs a)
+{
+    constexpr int TR32 = TM * 32;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;                         // [TR32][B_LDA] the WHOLE input tile (256 channels per row)
+    float* Ys = smem;                         // [TR32][B_LD1] b1|b2 output tile, aliases As once P1 is done
+    float* T2 = smem + TR32 * B_LD1;          // [TR32][B_LD2], aliases As too (behind Ys; B_LD1 + B_LD2 <= B_LDA)
+    float* Ap = smem + TR32 * B_LDA;          // [TR32][B_LDA] 3-tap max-pooled input tile (branch 1's operand)
+    float* T1 = Ap + TR32 * B_LDA;            // [spt*(W+4)+5][B_LD1]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int W = a.W, spt = a.spt, cinu = a.cin;          // cin in units (128)
+    int* rowmap = reinterpret_cast<int*>(T1 + (spt * (W + 4) + 5) * B_LD1);
+    float* const Bs = reinterpret_cast<float*>(rowmap + TR32);                    // [3][64] biases of b5b | b3b | b4b
+    unsigned short* const T1h = reinterpret_cast<unsigned short*>(T1);
+    unsigned short* const T2h = reinterpret_cast<unsigned short*>(T2);
+    unsigned short* const Ysh = reinterpret_cast<unsigned short*>(Ys);
+    const int ntiles = (a.n_sites + spt - 1) / spt;
+    const int h4 = 4 * (lane >> 5), rlane = lane & 31;
+    const bool pooled_in = a.pool_win > 0;
+    constexpr int NSLOT = TR32 * 32 / 512;    // 16-B slots of the input tile per thread: 2 * TM
+
+    const bool stamp = a.dbg != nullptr && lane == 0 && (wave == 0 || wave == 7) && blockIdx.x < 1024;
+    unsigned long long* sdst = a.dbg + ((size_t)blockIdx.x * 2 + (wave == 7)) * 8;
+#define DS_STAMP(i) do { if (stamp) sdst[i] = __builtin_amdgcn_s_memtime(); } while (0)
+
+    // Input rows of one tile -> registers. With bf16 MFMAs a K chunk is only ~200 matrix-pipe cycles, far too short to
+    // hide a global load behind, so nothing is pipelined per chunk: every thread requests its share of the WHOLE
+    // 96 x 512 B tile at once, the tile is parked in LDS and P1 runs its 16 k-steps back to back out of LDS.
+    float4 st[NSLOT];
+    auto request_tile = [&](int tile) {
+        const int site0 = tile * spt;
+        const int TRv = min(spt, a.n_sites - site0) * W;
+        const size_t grow0 = (size_t)site0 * W;
+        if (!pooled_in) {
+#pragma unroll
+            for (int i = 0; i < NSLOT; ++i) {
+                const int id = tid + i * 512, row = id >> 5, q = id & 31;
+                const int rr = row < TRv ? row : TRv - 1;
+                st[i] = gload4(a.X + (grow0 + rr) * cinu + q * 4);
+            }
+        } else {
+            // module right after maxpool_layer2/3: staged row (site s, w) = max of the input rows 2w - pad + {0,1,2} that exist
+#pragma unroll
+            for (int i = 0; i < NSLOT; ++i) {
+                const int id = tid + i * 512, row = id >> 5, q = id & 31;
+                const int rr = row < TRv ? row : TRv - 1;
+                const int s_ = rr / W, w_ = rr % W;
+                const int i0 = 2 * w_ - a.pool_pad;
+                const int ia = i0 < 0 ? i0 + 1 : i0;
+                const int ib = i0 + 1 < a.pool_win ? (i0 + 1 < 0 ? ia : i0 + 1) : ia;
+                const int ic = i0 + 2 < a.pool_win ? i0 + 2 : ib;
+                const float* sb = a.X + ((size_t)(site0 + s_) * a.pool_win) * cinu + q * 4;
+                st[i] = bf8max_nn(bf8max_nn(gload4(sb + (size_t)ia * cinu), gload4(sb + (size_t)ib * cinu)), gload4(sb + (size_t)ic * cinu));
+            }
+        }
+    };
+    if ((int)blockIdx.x < ntiles) request_tile(blockIdx.x);
+    if (tid < 192) Bs[tid] = gload((tid < 64 ? a.bias5b : tid < 128 ? a.bias3b : a.bias4b) + (tid & 63));
+    const float* const bp = a.Bp1 + ((size_t)wave * ((cinu + 31) / 32 * 4) * 64 + lane) * 4;
+
+    // relu + round four consecutive channels to bf16 -> one 8-byte group
+    auto pack4 = [](float x0, float x1, float x2, float x3) -> uint2 {
+        return make_uint2((unsigned)f2bf(fmaxf(x0, 0.0f)) | ((unsigned)f2bf(fmaxf(x1, 0.0f)) << 16),
+                          (unsigned)f2bf(fmaxf(x2, 0.0f)) | ((unsigned)f2bf(fmaxf(x3, 0.0f)) << 16));
+    };
+    typedef unsigned int u2v __attribute__((ext_vector_type(2)));
+
+    // static wave -> unit assignment of P2 (wave-uniform). kind: 0 none, 1 b5b, 2 b3b, 3 b4b
+    int a1k = 0, a1m = 0, a1n = 0, a2k = 0, a2m = 0, a2n = 0;
+    int b1k = 0, b1m = 0, b1n = 0, b2k = 0, b2m = 0, b2n = 0;
+    if (TM == 3) {
+        if (wave < 6) { a1k = 1; a1m = wave % 3; a1n = wave / 3; }
+        else { a1k = 2; a1m = 0; a1n = wave - 6; a2k = 2; a2m = 1; a2n = wave - 6; }
+        if (wave >= 2) { b1k = 3; b1m = (wave - 2) % 3; b1n = (wave - 2) / 3; }
+        if (wave == 2 || wave == 3) { b2k = 2; b2m = 2; b2n = wave - 2; }
+    } else if (TM == 2) {
+        if (wave < 4) { a1k = 1; a1m = wave & 1; a1n = wave >> 1; }
+        else { a1k = 2; a1m = wave & 1; a1n = (wave - 4) >> 1; }
+        if (wave >= 2 && wave < 6) { b1k = 3; b1m = (wave - 2) & 1; b1n = (wave - 2) >> 1; }
+    } else {
+        if (wave < 2) { a1k = 1; a1n = wave; }
+        else if (wave < 4) { a1k = 2; a1n = wave - 2; }
+        else if (wave < 6) { a1k = 3; a1n = wave - 4; }
+    }
+    auto unit_Bp = [&](int k) { return k == 1 ? a.Bp5b : k == 2 ? a.Bp3b : a.Bp4b; };
+    auto unit_taps = [&](int k) { return k == 3 ? 5 : 3; };
+
+    float4 bv[4];       // this wave's P1 bias (register 4g+e of every accumulator), resident across tiles
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        bv[g] = gload4(a.bias1 + wave * 32 + 8 * g + h4);                  // bias1 is zero-padded to 256
+        if (wave < 2) {                                                     // b5 stem columns also carry the tail's BN shift
+            const float4 t = gload4(a.bias5c + wave * 32 + 8 * g + h4);     // (zero-padded to 64)
+            bv[g].x += t.x; bv[g].y += t.y; bv[g].z += t.z; bv[g].w += t.w;
+        }
+    }
+
+    {   // one tile per workgroup. (A persistent loop with next-tile prefetch was tried: hipcc hoists ~100 loop-invariant
+        // address registers out of it, spills them, and the scratch reloads cost more than the hidden latency.)
+        const int tile = blockIdx.x;
+        const int site0 = tile * spt;
+        const int TRv = min(spt, a.n_sites - site0) * W;
+        __attribute__((address_space(1))) unsigned short* const Yg =
+            (__attribute__((address_space(1))) unsigned short*)(reinterpret_cast<unsigned short*>(a.Y) + (size_t)site0 * W * 256);
+        DS_STAMP(0);
+        // P1 weights of this wave's n-tile (16 fragments, L2-resident): in flight while the tile is parked
+        float4 bw[16];
+#pragma unroll
+        for (int g = 0; g < 16; ++g) bw[g] = gload4(bp + g * 256);
+
+        // Every MFMA of this kernel is issued TRANSPOSED: mfma(weight fragment, activation fragment) gives (X W)^T, so
+        // a lane ends up holding, for ONE activation row (lane & 31), 4 x 4 consecutive output channels
+        // (register 4g+e <-> channel 32*ntile + 8g + 4*(lane >> 5) + e). Results leave as packed 8-byte groups of four
+        // bf16 (LDS and HBM) instead of 2-byte scalars, and the bias is simply the accumulator's initial value.
+        floatx16 acc[TM];
+        {
+#pragma unroll
+            for (int mt = 0; mt < TM; ++mt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    acc[mt][4 * g + 0] = bv[g].x; acc[mt][4 * g + 1] = bv[g].y;
+                    acc[mt][4 * g + 2] = bv[g].z; acc[mt][4 * g + 3] = bv[g].w;
+                }
+        }
+
+        for (int i = tid; i < (spt * (W + 4) + 5) * B_LD1; i += 512) T1[i] = 0.0f;   // halos (and everything else) = 0
+        if (tid < TR32)
+            rowmap[tid] = tid < TRv ? (tid / W) * (W + 4) + 2 + tid % W : spt * (W + 4) + 2;
+#pragma unroll
+        for (int i = 0; i < NSLOT; ++i) {
+            const int id = tid + i * 512, row = id >> 5, q = id & 31;
+            *reinterpret_cast<float4*>(As + row * B_LDA + q * 4) = st[i];
+        }
+        __syncthreads();   // input tile, zeroed T1, rowmap (and, first time, the biases) are in place
+        // branch 1's maxpool(3, stride 1, SAME) of the tile, once, by everybody: pooled row = max(previous, own, next),
+        // a missing neighbour at a site edge = the own row ("padded taps ignored")        layers.py:90-91
+#pragma unroll
+        for (int i = 0; i < NSLOT; ++i) {
+            const int id = tid + i * 512, row = id >> 5, q = id & 31;
+            const int w = row % W;
+            const int om = (row < TRv && w > 0) ? -B_LDA : 0, op = (row < TRv && w < W - 1) ? B_LDA : 0;
+            const float* src = As + row * B_LDA + q * 4;
+            *reinterpret_cast<float4*>(Ap + row * B_LDA + q * 4) =
+                bf8max_nn(bf8max_nn(*reinterpret_cast<const float4*>(src), *reinterpret_cast<const float4*>(src + om)),
+                          *reinterpret_cast<const float4*>(src + op));
+        }
+        __syncthreads();   // the pooled tile is complete
+        DS_STAMP(1);
+
+        {
+            const float* const src = (wave >= 6 ? Ap : As) + rlane * B_LDA + h4;      // wave-uniform choice
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {          // four k-steps at a time: bounds how many fragments are in flight
+                float4 af[4][TM];
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int mt = 0; mt < TM; ++mt)
+                        af[g][mt] = *reinterpret_cast<const float4*>(src + mt * 32 * B_LDA + (g4 * 4 + g) * 8);
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int mt = 0; mt < TM; ++mt) acc[mt] = mfma_bf(bw[g4 * 4 + g], af[g][mt], acc[mt]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        DS_STAMP(2);
+        __syncthreads();   // all fragment reads of the input tile are done before the output tile aliases it
+        float4 pf[10];
+        if (a1k) fusedb_unit_prefetch(unit_Bp(a1k), unit_taps(a1k), a1n, lane, pf);
+
+        // ---- P1 epilogue (bias already inside acc)
+        if (wave >= 3 && wave <= 5) {            // b3a | b4a | b5a -> T1 (bf16), through the row map (SAME-padding halos)
+#pragma unroll
+            for (int mt = 0; mt < TM; ++mt) {
+                const int rm = rowmap[mt * 32 + rlane];
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    *reinterpret_cast<uint2*>(T1h + rm * (2 * B_LD1) + (wave * 32 - 96) + 8 * g + h4) =
+                        pack4(acc[mt][4 * g], acc[mt][4 * g + 1], acc[mt][4 * g + 2], acc[mt][4 * g + 3]);
+            }
+        } else if (wave != 0) {                  // b5s tail | b2 and b1 | padding -> output tile
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int col = wave * 32 + 8 * g + h4;          // groups of 4 never straddle 48 / 240
+                if (col >= 48 && col < 240) {
+                    const int ycol = col < 96 ? col : col - 192;
+#pragma unroll
+                    for (int mt = 0; mt < TM; ++mt)
+                        *reinterpret_cast<uint2*>(Ysh + (mt * 32 + rlane) * (2 * B_LD1) + ycol) =
+                            pack4(acc[mt][4 * g], acc[mt][4 * g + 1], acc[mt][4 * g + 2], acc[mt][4 * g + 3]);
+                }
+            }
+        }
+        __syncthreads();   // T1 and the b1|b2 tile complete
+        DS_STAMP(3);
+        for (int idx = tid; idx < TR32 * 12; idx += 512) {      // 96 channels = 12 x 16 B per row
+            const int row = idx / 12, q = idx - row * 12;
+            if (row < TRv) {
+                const float4 v = *reinterpret_cast<const float4*>(Ys + row * B_LD1 + q * 4);
+                v4f o = {v.x, v.y, v.z, v.w};
+                *(__attribute__((address_space(1))) v4f*)(Yg + (unsigned)(row * 256 + q * 8)) = o;
+            }
+        }
+        DS_STAMP(4);
+
+        auto run_unit = [&](int kind, int mt, int nt, const float4 (&pf)[10]) {
+            floatx16 u;
+            const float* bsrc = Bs + (kind == 1 ? 0 : kind == 2 ? 64 : 128) + nt * 32 + h4;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 t = *reinterpret_cast<const float4*>(bsrc + 8 * g);
+                u[4 * g] = t.x; u[4 * g + 1] = t.y; u[4 * g + 2] = t.z; u[4 * g + 3] = t.w;
+            }
+            const int row = mt * 32 + rlane;
+            const int rm = rowmap[row];
+            if (kind == 1) {          // 1x3, 32 -> 64, ReLU, to T2                            layers.py:127-131
+                fusedb_conv_unit<3>(T1, rm, 32, lane, pf, u);          // b5a = channels 64..95 = units 32..47
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    *reinterpret_cast<uint2*>(T2h + row * (2 * B_LD2) + nt * 32 + 8 * g + h4) = pack4(u[4 * g], u[4 * g + 1], u[4 * g + 2], u[4 * g + 3]);
+            } else {
+                // kind 2: 1x3, 32 -> 48, ReLU, to Y[96,144)   layers.py:106-110 ; kind 3: 1x5, 32 -> 48, to Y[144,192)   layers.py:115-119
+                if (kind == 2) fusedb_conv_unit<3>(T1, rm, 0, lane, pf, u);       // b3a = channels 0..31
+                else fusedb_conv_unit<5>(T1, rm, 16, lane, pf, u);                // b4a = channels 32..63
+                const int ybase = kind == 2 ? 96 : 144;
+                if (row < TRv) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        if (nt * 32 + 8 * g < 48) {      // wave-uniform: 48 output channels = n-tile 0 and half of n-tile 1
+                            const uint2 o = pack4(u[4 * g], u[4 * g + 1], u[4 * g + 2], u[4 * g + 3]);
+                            const u2v ov = {o.x, o.y};
+                            *(__attribute__((address_space(1))) u2v*)(Yg + (unsigned)(row * 256 + ybase + nt * 32 + 8 * g + h4)) = ov;
+                        }
+                }
+            }
+        };
+
+        // ---- P2a
+        if (a1k) run_unit(a1k, a1m, a1n, pf);
+        if (a2k) {
+            fusedb_unit_prefetch(unit_Bp(a2k), unit_taps(a2k), a2n, lane, pf);
+            run_unit(a2k, a2m, a2n, pf);
+        }
+        float4 b5c[4];
+        float4 pf2[10];
+        if (wave < 2) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) b5c[g] = gload4(a.Bp5c + ((size_t)(wave * 4 + g) * 64 + lane) * 4);
+        } else if (b1k) {
+            fusedb_unit_prefetch(unit_Bp(b1k), unit_taps(b1k), b1n, lane, pf);
+            if (b2k) fusedb_unit_prefetch(unit_Bp(b2k), unit_taps(b2k), b2n, lane, pf2);
+        }
+        DS_STAMP(5);
+        __syncthreads();   // T2 complete
+        DS_STAMP(6);
+
+        // ---- P2b
+        if (wave < 2) {
+            // branch 5 tail: 1x1 64 -> 48 (BN, no ReLU) accumulated on top of the stem conv held in acc, then relu(stem + tail)
+#pragma unroll
+            for (int mt = 0; mt < TM; ++mt) {
+                const float* base = T2 + (mt * 32 + rlane) * B_LD2 + h4;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) acc[mt] = mfma_bf(b5c[g], *reinterpret_cast<const float4*>(base + g * 8), acc[mt]);
+            }
+#pragma unroll
+            for (int mt = 0; mt < TM; ++mt) {
+                const int row = mt * 32 + rlane;
+                if (row < TRv) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        if (wave * 32 + 8 * g < 48) {
+                            const uint2 o = pack4(acc[mt][4 * g], acc[mt][4 * g + 1], acc[mt][4 * g + 2], acc[mt][4 * g + 3]);
+                            const u2v ov = {o.x, o.y};
+                            *(__attribute__((address_space(1))) u2v*)(Yg + (unsigned)(row * 256 + 192 + wave * 32 + 8 * g + h4)) = ov;
+                        }
+                }
+            }
+        } else {
+            if (b1k) run_unit(b1k, b1m, b1n, pf);
+            if (b2k) run_unit(b2k, b2m, b2n, pf2);
+        }
+        DS_STAMP(7);
+    }
+#undef DS_STAMP
+}
+
+hipError_t launch_inception_fused_bf16(int tm, const FusedArgs& a, hipStream_t s)
+{
+    if (a.n_sites <= 0) return hipSuccess;
+    const size_t lds = inception_fused_bf16_lds_bytes(tm, a.W, a.spt);
+    const int ntiles = (a.n_sites + a.spt - 1) / a.spt;
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+        if (cus <= 0) cus = 256;
+    }
+    (void)cus;
+    const int grid = ntiles;
+    static bool attr_set[4] = {false, false, false, false};
+    auto set_attr = [&](const void* f) {
+        if (attr_set[tm]) return hipSuccess;
+        attr_set[tm] = true;
+        return hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    };
+    hipError_t e = hipSuccess;
+    switch (tm) {
+    case 1:
+        if ((e = set_attr((const void*)inception_fused_bf16_kernel<1>)) != hipSuccess) return e;
+        hipLaunchKernelGGL(inception_fused_bf16_kernel<1>, dim3(grid), dim3(512), lds, s, a);
+        break;
+    case 2:
+        if ((e = set_attr((const void*)inception_fused_bf16_kernel<2>)) != hipSuccess) return e;
+        hipLaunchKernelGGL(inception_fused_bf16_kernel<2>, dim3(grid), dim3(512), lds, s, a);
+        break;
+    case 3:
+        if ((e = set_attr((const void*)inception_fused_bf16_kernel<3>)) != hipSuccess) return e;
+        hipLaunchKernelGGL(inception_fused_bf16_kernel<3>, dim3(grid), dim3(512), lds, s, a);
+        break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
 // stem conv1: conv(K=7, stride 2, Cin=1 -> 64, SAME) + folded BN + ReLU + maxpool(3, stride 2, SAME)
 // One block per site; the window sits in LDS with a zero halo (SAME padding, no bounds checks in the
 // tap loop); lane = output channel, so the 64-float output rows are written as whole 256-B lines.
@@ -1190,23 +1583,34 @@ hipError_t launch_avgpool7_bf16(const float* in, float* joint, int n, int w, int
 }
 
 // joint[:, 0:256] = bf16(h_fw), joint[:, 256:512] = bf16(h_bw)     (layers.py:171-172, bf16 FC operand)
+template <bool SRC_BF>
 __global__ __launch_bounds__(256) void pack_event_feat_bf16_kernel(const float* __restrict__ hfw, const float* __restrict__ hbw,
                                                                     unsigned short* __restrict__ joint, int n, long joint_ld)
 {
     const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;      // one thread per 4 values
     if (i >= (long)n * 128) return;
     const int site = (int)(i / 128), q = (int)(i % 128);
-    const float* src = q < 64 ? hfw + (size_t)site * 256 + q * 4 : hbw + (size_t)site * 256 + (q - 64) * 4;
-    const float4 v = *reinterpret_cast<const float4*>(src);
-    const unsigned lo = (unsigned)f2bf(v.x) | ((unsigned)f2bf(v.y) << 16), hi = (unsigned)f2bf(v.z) | ((unsigned)f2bf(v.w) << 16);
-    *reinterpret_cast<uint2*>(joint + site * joint_ld + q * 4) = make_uint2(lo, hi);
+    uint2 o;
+    if (SRC_BF) {        // h already bf16 ([n][256] bf16): plain copy
+        const unsigned short* src = reinterpret_cast<const unsigned short*>(q < 64 ? hfw : hbw) + (size_t)site * 256 + (q & 63) * 4;
+        o = *reinterpret_cast<const uint2*>(src);
+    } else {
+        const float* src = (q < 64 ? hfw : hbw) + (size_t)site * 256 + (q & 63) * 4;
+        const float4 v = *reinterpret_cast<const float4*>(src);
+        o = make_uint2((unsigned)f2bf(v.x) | ((unsigned)f2bf(v.y) << 16), (unsigned)f2bf(v.z) | ((unsigned)f2bf(v.w) << 16));
+    }
+    *reinterpret_cast<uint2*>(joint + site * joint_ld + q * 4) = o;
 }
 
-hipError_t launch_pack_event_feat_bf16(const float* hfw, const float* hbw, float* joint, int n, int joint_ld, hipStream_t s)
+hipError_t launch_pack_event_feat_bf16(const float* hfw, const float* hbw, float* joint, int n, int joint_ld, int src_bf16,
+                                       hipStream_t s)
 {
     if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(pack_event_feat_bf16_kernel, dim3((unsigned)(((long)n * 128 + 255) / 256)), dim3(256), 0, s, hfw, hbw,
-                       (unsigned short*)joint, n, (long)joint_ld);
+    const dim3 grid((unsigned)(((long)n * 128 + 255) / 256));
+    if (src_bf16)
+        hipLaunchKernelGGL(pack_event_feat_bf16_kernel<true>, grid, dim3(256), 0, s, hfw, hbw, (unsigned short*)joint, n, (long)joint_ld);
+    else
+        hipLaunchKernelGGL(pack_event_feat_bf16_kernel<false>, grid, dim3(256), 0, s, hfw, hbw, (unsigned short*)joint, n, (long)joint_ld);
     return hipGetLastError();
 }
 

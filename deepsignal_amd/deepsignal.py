@@ -37,7 +37,7 @@ def build_parser():
     g.add_argument("--model_path", "-m", required=True,
                    help="TensorFlow checkpoint prefix of a reference-trained model (<prefix>.index + .data-*), "
                         "or a DSAMDW01 weight file")
-    g.add_argument("--precision", default="fp32", choices=["fp32", "bf16"],
+    g.add_argument("--precision", default="fp32", choices=["fp32", "bf16", "bf16_all"],
                    help="fp32 (reference numerics) or bf16 conv+FC operands with fp32 accumulate and fp32 BiLSTM")
     g.add_argument("--is_cnn", default="yes")
     g.add_argument("--is_rnn", default="yes")

@@ -41,8 +41,9 @@ class DsConfig(ctypes.Structure):
     ]
 
 
-# ds_config.precision (include/deepsignal_hip.h): "bf16" = bf16 conv + FC operands with fp32 accumulation, fp32 BiLSTM
-PRECISIONS = {"fp32": 0, "bf16": 1}
+# ds_config.precision (include/deepsignal_hip.h): "bf16" = bf16 conv + FC operands with fp32 accumulation, fp32 BiLSTM;
+# "bf16_all" = also bf16 h / weight operands in the LSTM matmuls (fp32 accumulate, gates, cell state)
+PRECISIONS = {"fp32": 0, "bf16": 1, "bf16_all": 2}
 
 _lib: Optional[ctypes.CDLL] = None
 

@@ -33,6 +33,10 @@ extern "C" {
  * FC (activations between those layers are stored as bf16); the BiLSTM, the Cin=1 stem conv, FC2, sigmoid and
  * argmax stay fp32. Same ABI, same outputs to the tolerance stated in DESIGN.md. */
 #define DS_PRECISION_BF16 1
+/* DS_PRECISION_BF16 plus bf16 operands in the BiLSTM matmuls: h is stored as bf16 and multiplied with bf16 weights,
+ * accumulation, gate non-linearities and the cell state c stay fp32, and the layer-0 input projection stays an
+ * fp32 table lookup ("fp32 LSTM state/accumulate" reading of configs[2]). */
+#define DS_PRECISION_BF16_ALL 2
 
 typedef struct ds_handle ds_handle;
 
@@ -45,7 +49,7 @@ typedef struct ds_config {
     int32_t is_rnn;
     int32_t is_base;
     int32_t device;       /* HIP device ordinal */
-    int32_t precision;    /* DS_PRECISION_FP32 | DS_PRECISION_BF16 */
+    int32_t precision;    /* DS_PRECISION_FP32 | DS_PRECISION_BF16 | DS_PRECISION_BF16_ALL */
     int32_t max_batch;    /* largest n per device pass (workspaces are sized for it); larger n is looped */
     int32_t reserved[7];  /* reserved[0] != 0: debug mode — keep every module output for ds_get_intermediate;
                              reserved[1]: forwards in flight for ds_forward_device (pipeline slots; default 8 for

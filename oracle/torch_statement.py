@@ -149,7 +149,38 @@ def _conv_folded(x, w, c: spec.ConvBN, round_w: bool):
     return F.conv1d(_same(x, c.k, c.stride), kt, stride=c.stride) + bf.to(x.dtype)[None, :, None]
 
 
-def forward_bf16(weights: Dict[str, np.ndarray], feats: Dict[str, np.ndarray], return_taps: bool = False):
+def _event_model_bf16(w, feats, kmer, n, T, dtype, taps):
+    """BiLSTM of DS_PRECISION_BF16_ALL: the recurrent / lower-layer h operands and the weights they meet are bf16,
+    the layer-0 input projection ([embedding, mean, std, len] @ K[:131]) is full precision, accumulation, gates and
+    the cell state are full precision, and every h is stored (hence consumed downstream) as bf16."""
+    extra = [torch.from_numpy(feats[k]).to(dtype)[:, :, None] for k in ("means", "stds", "sanums")]
+    x0 = torch.cat([w[spec.MODEL_PREFIX + "embedding"][kmer]] + extra, dim=2)
+    outs = []
+    for direction in ("fw", "bw"):
+        seq = x0 if direction == "fw" else torch.flip(x0, dims=[1])
+        for layer in range(spec.LSTM_LAYERS):
+            K = w[spec.lstm_tensor(direction, layer, "kernel")]
+            b = w[spec.lstm_tensor(direction, layer, "bias")]
+            nin = K.shape[0] - spec.HIDDEN
+            Kx = K[:nin] if layer == 0 else _rb(K[:nin])
+            Kh = _rb(K[nin:])
+            h = torch.zeros(n, spec.HIDDEN, dtype=dtype)
+            c = torch.zeros(n, spec.HIDDEN, dtype=dtype)
+            hs = []
+            for t in range(T):
+                z = seq[:, t, :] @ Kx + h @ Kh + b
+                i, j, f, o = torch.split(z, spec.HIDDEN, dim=1)
+                c = torch.sigmoid(f + spec.FORGET_BIAS) * c + torch.sigmoid(i) * torch.tanh(j)
+                h = _rb(torch.sigmoid(o) * torch.tanh(c))
+                hs.append(h)
+            seq = torch.stack(hs, dim=1)
+            taps["lstm_%s_l%d" % (direction, layer)] = seq if direction == "fw" else torch.flip(seq, dims=[1])
+        outs.append(seq[:, -1, :])
+    return outs
+
+
+def forward_bf16(weights: Dict[str, np.ndarray], feats: Dict[str, np.ndarray], return_taps: bool = False,
+                 lstm_bf16: bool = False):
     dtype = torch.float64
     w = {k: torch.from_numpy(np.asarray(v)).to(torch.float32) for k, v in weights.items()}
     w64 = {k: v.to(dtype) for k, v in w.items()}
@@ -157,7 +188,10 @@ def forward_bf16(weights: Dict[str, np.ndarray], feats: Dict[str, np.ndarray], r
     n, T = kmer.shape
     d = spec.net_dims(T, feats["signals"].shape[1], w["dense_1/kernel"].shape[1])
     taps = {}
-    ev = _event_model(w64, feats, kmer, n, T, dtype, taps, True)     # fp32 BiLSTM in the engine; float64 here
+    if lstm_bf16:
+        ev = _event_model_bf16(w64, feats, kmer, n, T, dtype, taps)
+    else:
+        ev = _event_model(w64, feats, kmer, n, T, dtype, taps, True)     # fp32 BiLSTM in the engine; float64 here
     # signal model
     x = torch.from_numpy(feats["signals"]).to(dtype)[:, None, :]
     stem = spec.stem_convs()

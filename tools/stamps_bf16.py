@@ -1,0 +1,18 @@
+import os, sys
+os.environ["DS_DEBUG_STAMPS"] = "1"; os.environ["DS_SERIAL"] = "1"
+sys.path.insert(0, os.getcwd())
+import numpy as np
+from deepsignal_amd import synth, weights as W
+from deepsignal_amd.engine import Engine
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024     # stamp buffer holds 1024 workgroups per module
+w = W.random_weights(seed=1)
+e = Engine(max_batch=B, precision="bf16_all", slots=1); e.load_weights(w)
+f = synth.synthetic_features(B, seed=2)
+args = [f[k] for k in ("kmer", "means", "stds", "sanums", "signals")]
+for _ in range(3): e.run(*args)
+names = ["(n)", "load+stage", "P1 mfma", "P1 epi+sync", "Ys store", "P2a", "sync", "P2b"]
+for m in (2, 5, 10):
+    st = e.intermediate("stamps%d" % m, (16,))
+    print("module", m, "wgs", int(st[0]))
+    for wv in range(2):
+        print("   wave", (0, 7)[wv], " ".join("%s=%.0f" % (names[i], st[wv * 8 + i]) for i in range(1, 8)), "total=%.0f ticks (100 MHz)" % st[wv*8+1:wv*8+8].sum())
