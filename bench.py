@@ -122,6 +122,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile-pass", action="store_true")
+    ap.add_argument("--no-standalone-pass", action="store_true",
+                    help="skip pass C (every launch on one stream); used for the rocprofv3 cross-check, whose per-kernel "
+                         "averages would otherwise blend co-resident and stand-alone launches")
     args = ap.parse_args()
 
     import numpy as np
@@ -222,12 +225,14 @@ def main():
         prof_ms = 1e3 * (time.perf_counter() - tp) / max(K, 1)
         ks = [k for k in eng.kernel_stats() if k["launches"]]
         # pass C (mode 3): the same, with every launch on one stream -> stand-alone duration of each kernel
-        eng.set_profiling(3)
-        eng.reset_stage_times()
-        for i in range(K):
-            step(i, i)
-        eng.sync()
-        alone = {k["name"]: k for k in eng.kernel_stats() if k["launches"]}
+        alone = {}
+        if not args.no_standalone_pass:
+            eng.set_profiling(3)
+            eng.reset_stage_times()
+            for i in range(K):
+                step(i, i)
+            eng.sync()
+            alone = {k["name"]: k for k in eng.kernel_stats() if k["launches"]}
         eng.set_profiling(0)
         dom = max(ks, key=lambda k: k["total_ms"])
         per_launch_flops = dom["flops"] / dom["launches"]
