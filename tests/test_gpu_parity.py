@@ -201,3 +201,28 @@ def test_pipelined_device_forwards_match_blocking(small_weights):
     o_act, o_pred = oracle.forward(small_weights, sub, "f32")
     _check_outputs(got_act[1][:64], got_pred[1][:64], o_act, o_pred)
     eng.close()
+
+
+@pytest.mark.parametrize("geom", [dict(kmer_len=9, signal_len=100), dict(kmer_len=21, signal_len=128),
+                                  dict(kmer_len=5, signal_len=40)])
+@pytest.mark.parametrize("precision", ["fp32", "bf16_all"])
+def test_other_kmer_and_signal_lengths(geom, precision):
+    """--kmer_len / --cent_signals_len are free parameters of the reference CLI (deepsignal.py:258-263): widths,
+    SAME paddings, the joint width and every tile shape follow them."""
+    from deepsignal_amd import weights as W
+    from oracle import oracle, torch_statement
+    w = W.random_weights(seed=33, lstm_bias_std=0.1, **geom)
+    feats = synth.synthetic_features(70, seed=8, **geom)
+    eng = _engine(w, max_batch=128, debug=True, precision=precision, **geom)
+    act, pred = eng.run(feats["kmer"], feats["means"], feats["stds"], feats["sanums"], feats["signals"])
+    if precision == "fp32":
+        o_act, o_pred, taps = oracle.forward(w, feats, "f32", taps=True, **geom)
+        for name, ref in taps.items():
+            got = eng.intermediate(name, ref.shape)
+            err = float(np.abs(got - ref).max())
+            assert err <= INTERMEDIATE_RTOL * max(1.0, float(np.abs(ref).max())), (name, err)
+        _check_outputs(act, pred, o_act, o_pred)
+    else:
+        e_act, _ = torch_statement.forward_bf16(w, feats, lstm_bf16=True)
+        assert np.isfinite(act).all() and np.abs(act - e_act).max() <= 3e-3
+    eng.close()
