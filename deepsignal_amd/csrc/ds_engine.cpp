@@ -466,16 +466,15 @@ int alloc_workspace(ds_handle* h)
 
 int module_width(const ds_handle* h, int m) { return m < 3 ? h->wa : (m < 8 ? h->wb : h->wc); }
 
-const float* g_zero_seg = nullptr;   // 16 zero floats on the device (per process; set by ds_create)
-
-void add_tiles(GemmLaunch& L, GemmProblem& P, GemmCfg cfg)
+// zero16: 16 zero floats on the handle's device (the A operand of the zero-padding segment K-split kernels append)
+void add_tiles(GemmLaunch& L, GemmProblem& P, GemmCfg cfg, const float* zero16)
 {
     const TileGeom g = gemm_geom(cfg);
     // K-split kernels need a chunk count divisible by the split: append a zero A segment (ld = 0, so
     // every row reads the same 16 zeros); the packed weights are zero-padded past K as well.
     while ((P.K / KC) % g.ksplit != 0) {
         ASeg& z = P.seg[P.nseg++];
-        z.base = g_zero_seg; z.ld = 0; z.row_shift = 0; z.klen = KC;
+        z.base = zero16; z.ld = 0; z.row_shift = 0; z.klen = KC;
         P.K += KC;
     }
     P.tiles_m = (P.M + g.bm - 1) / g.bm;
@@ -524,7 +523,6 @@ int stage_id(ds_handle* h, const std::string& name, int stream)
 int build_plan(ds_handle* h, int n, Plan* plan)
 {
     plan->n = n;
-    g_zero_seg = h->zero_seg;
     std::vector<Op> cnn, rnn;
     auto& LS = plan->launches;
     const bool first_plan = !h->stages_done;
@@ -566,13 +564,13 @@ int build_plan(ds_handle* h, int n, Plan* plan)
         GemmProblem P = base_problem(M, 128, h->wa, h->conv2);                 // conv_layer2 1x1 (layers.py:192-197)
         add_seg(P, h->cur->stem_pool, U(64), 0, U(64));
         add_out(P, h->cur->conv2o, 128, 0, 128, 1, nullptr, 0, bf);
-        add_tiles(L, P, ccfg);
+        add_tiles(L, P, ccfg, h->zero_seg);
         add_gemm_op(cnn, 0, st, ccfg, L);
         GemmLaunch L3{};
         GemmProblem P3 = base_problem(M, 256, h->wa, h->conv3);                // conv_layer3 1x3 (layers.py:198-203)
         for (int t = 0; t < 3; ++t) add_seg(P3, h->cur->conv2o, U(128), t - 1, U(128));
         add_out(P3, h->cur->conv3o, 256, 0, 256, 1, nullptr, 0, bf);
-        add_tiles(L3, P3, ccfg);
+        add_tiles(L3, P3, ccfg, h->zero_seg);
         add_gemm_op(cnn, 0, st, ccfg, L3);
     }
     const float* x = h->cur->conv3o;
@@ -623,14 +621,14 @@ int build_plan(ds_handle* h, int n, Plan* plan)
             add_out(P, eoff(y, 48), CL, 0, 48, 1, nullptr, 0, bf);          // branch2
             add_out(P, h->cur->tmpS, 48, 48, 48, 0);                        // branch5 stem (BN, no ReLU), kept fp32
             add_out(P, h->cur->tmpA, 96, 96, 96, 1, nullptr, 0, bf);        // b3a | b4a | b5a
-            add_tiles(L, P, ccfg);
+            add_tiles(L, P, ccfg, h->zero_seg);
             add_gemm_op(cnn, 0, st, ccfg, L, ks);
             GemmLaunch L1{};
             GemmProblem Q = base_problem(M, 48, W, h->m_b1[m]);
             Q.a_mode = 1;                                   // maxpool(3, s1) fused into the A load (layers.py:90-91)
             add_seg(Q, x, U(xld), 0, U(xld));
             add_out(Q, y, CL, 0, 48, 1, nullptr, 0, bf);    // branch1
-            add_tiles(L1, Q, pcfg);
+            add_tiles(L1, Q, pcfg, h->zero_seg);
             add_gemm_op(cnn, 0, st, pcfg, L1, ks);
         }
         {   // second-stage convs from the 32-channel intermediates             layers.py:106-110,115-119,127-131
@@ -639,15 +637,15 @@ int build_plan(ds_handle* h, int n, Plan* plan)
             GemmProblem P = base_problem(M, 48, W, h->m_b3b[m]);
             for (int t = 0; t < 3; ++t) add_seg(P, eoff(h->cur->tmpA, 0), U(96), t - 1, U(32));
             add_out(P, eoff(y, 96), CL, 0, 48, 1, nullptr, 0, bf);
-            add_tiles(L, P, ccfg);
+            add_tiles(L, P, ccfg, h->zero_seg);
             GemmProblem Q = base_problem(M, 48, W, h->m_b4b[m]);
             for (int t = 0; t < 5; ++t) add_seg(Q, eoff(h->cur->tmpA, 32), U(96), t - 2, U(32));
             add_out(Q, eoff(y, 144), CL, 0, 48, 1, nullptr, 0, bf);
-            add_tiles(L, Q, ccfg);
+            add_tiles(L, Q, ccfg, h->zero_seg);
             GemmProblem R = base_problem(M, 64, W, h->m_b5b[m]);
             for (int t = 0; t < 3; ++t) add_seg(R, eoff(h->cur->tmpA, 64), U(96), t - 1, U(32));
             add_out(R, h->cur->tmpB, 64, 0, 64, 1, nullptr, 0, bf);
-            add_tiles(L, R, ccfg);
+            add_tiles(L, R, ccfg, h->zero_seg);
             add_gemm_op(cnn, 0, st, ccfg, L);
         }
         {   // residual tail: relu(stem + BN(1x1 48 of tmpB))                    layers.py:132-138
@@ -656,7 +654,7 @@ int build_plan(ds_handle* h, int n, Plan* plan)
             GemmProblem P = base_problem(M, 48, W, h->m_b5c[m]);
             add_seg(P, h->cur->tmpB, U(64), 0, U(64));
             add_out(P, eoff(y, 192), CL, 0, 48, 1, h->cur->tmpS, 48, bf);
-            add_tiles(L, P, ccfg);
+            add_tiles(L, P, ccfg, h->zero_seg);
             add_gemm_op(cnn, 0, st, ccfg, L);
         }
         }
@@ -714,7 +712,7 @@ int build_plan(ds_handle* h, int n, Plan* plan)
                 P.lstm.c = h->cur->Cst[dir][l];
                 P.lstm.h_out = hptr(dir, l, t);
                 P.lstm.t = t; P.lstm.T = T; P.lstm.c_zero = s == 0; P.lstm.use_feat = l == 0;
-                add_tiles(L, P, lstm_cfg);
+                add_tiles(L, P, lstm_cfg, h->zero_seg);
             }
         add_gemm_op(rnn, 1, st, lstm_cfg, L);
     }
@@ -741,7 +739,7 @@ int build_plan(ds_handle* h, int n, Plan* plan)
         if (h->is_cnn) add_seg(P, h->cur->sigfeat, h->SF, 0, h->SF);
         }
         add_out(P, h->cur->fc1o, h->J, 0, h->J, 0);
-        add_tiles(L, P, fc_cfg);
+        add_tiles(L, P, fc_cfg, h->zero_seg);
         add_gemm_op(tail, 0, st, fc_cfg, L, bf ? (double)h->J / h->JP : 1.0);
     }
     st = stage_id(h, "head", 0);
@@ -997,9 +995,10 @@ int ds_create(const ds_config* cfg, ds_handle** out)
     h->debug = cfg->reserved[0] != 0;
 #define CK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { fail(nullptr, DS_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); ds_destroy(h); return DS_ERR_HIP; } } while (0)
     CK(hipSetDevice(cfg->device));
+    CK(configure_fused_kernels());
     // reserved[1] = forwards in flight (pipeline slots); 0 -> default
     int nslots = cfg->reserved[1] > 0 ? cfg->reserved[1] : (getenv("DS_SLOTS") ? atoi(getenv("DS_SLOTS")) : (h->B <= 1024 ? 8 : 4));
-    nslots = std::max(1, std::min(nslots, 8));
+    nslots = std::max(1, std::min(nslots, 16));
     h->slots.resize(nslots);
     int rc = DS_OK;
     for (Slot& sl : h->slots) {

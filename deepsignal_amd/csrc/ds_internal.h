@@ -98,6 +98,8 @@ struct FusedArgs {
 // tm = 32-row m-tiles per workgroup (1..3), spt*W <= 32*tm
 hipError_t launch_inception_fused(int tm, const FusedArgs& a, hipStream_t s);
 size_t inception_fused_lds_bytes(int tm, int W, int spt);
+// once per device, before the first fused launch (raises the kernels' dynamic LDS limit to 160 KB)
+hipError_t configure_fused_kernels();
 // bf16-operand variant: X / Y are bf16 rows of 256-channel pitch, a.cin is the row pitch in 4-byte units (128)
 hipError_t launch_inception_fused_bf16(int tm, const FusedArgs& a, hipStream_t s);
 size_t inception_fused_bf16_lds_bytes(int tm, int W, int spt);

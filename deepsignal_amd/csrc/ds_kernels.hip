@@ -931,26 +931,10 @@ hipError_t launch_inception_fused(int tm, const FusedArgs& a, hipStream_t s)
     if (a.n_sites <= 0) return hipSuccess;
     const size_t lds = inception_fused_lds_bytes(tm, a.W, a.spt);
     const int grid = (a.n_sites + a.spt - 1) / a.spt;
-    static bool attr_set[4] = {false, false, false, false};
-    auto set_attr = [&](const void* f) {
-        if (attr_set[tm]) return hipSuccess;
-        attr_set[tm] = true;
-        return hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    };
-    hipError_t e = hipSuccess;
     switch (tm) {
-    case 1:
-        if ((e = set_attr((const void*)inception_fused_kernel<1>)) != hipSuccess) return e;
-        hipLaunchKernelGGL(inception_fused_kernel<1>, dim3(grid), dim3(512), lds, s, a);
-        break;
-    case 2:
-        if ((e = set_attr((const void*)inception_fused_kernel<2>)) != hipSuccess) return e;
-        hipLaunchKernelGGL(inception_fused_kernel<2>, dim3(grid), dim3(512), lds, s, a);
-        break;
-    case 3:
-        if ((e = set_attr((const void*)inception_fused_kernel<3>)) != hipSuccess) return e;
-        hipLaunchKernelGGL(inception_fused_kernel<3>, dim3(grid), dim3(512), lds, s, a);
-        break;
+    case 1: hipLaunchKernelGGL(inception_fused_kernel<1>, dim3(grid), dim3(512), lds, s, a); break;
+    case 2: hipLaunchKernelGGL(inception_fused_kernel<2>, dim3(grid), dim3(512), lds, s, a); break;
+    case 3: hipLaunchKernelGGL(inception_fused_kernel<3>, dim3(grid), dim3(512), lds, s, a); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
@@ -1293,40 +1277,29 @@ __global__ __launch_bounds__(512, DS_FUSEDB_WPS) void inception_fused_bf16_kerne
 #undef DS_STAMP
 }
 
+// The fused kernels need more than the default 64 KB of dynamic LDS: opt in once per device (ds_create calls this
+// after hipSetDevice; function attributes are per device and must not be changed during stream capture).
+hipError_t configure_fused_kernels()
+{
+    const void* fns[6] = {(const void*)inception_fused_kernel<1>, (const void*)inception_fused_kernel<2>,
+                          (const void*)inception_fused_kernel<3>, (const void*)inception_fused_bf16_kernel<1>,
+                          (const void*)inception_fused_bf16_kernel<2>, (const void*)inception_fused_bf16_kernel<3>};
+    for (const void* f : fns) {
+        const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
 hipError_t launch_inception_fused_bf16(int tm, const FusedArgs& a, hipStream_t s)
 {
     if (a.n_sites <= 0) return hipSuccess;
     const size_t lds = inception_fused_bf16_lds_bytes(tm, a.W, a.spt);
-    const int ntiles = (a.n_sites + a.spt - 1) / a.spt;
-    static int cus = 0;
-    if (!cus) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
-        if (cus <= 0) cus = 256;
-    }
-    (void)cus;
-    const int grid = ntiles;
-    static bool attr_set[4] = {false, false, false, false};
-    auto set_attr = [&](const void* f) {
-        if (attr_set[tm]) return hipSuccess;
-        attr_set[tm] = true;
-        return hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    };
-    hipError_t e = hipSuccess;
+    const int grid = (a.n_sites + a.spt - 1) / a.spt;
     switch (tm) {
-    case 1:
-        if ((e = set_attr((const void*)inception_fused_bf16_kernel<1>)) != hipSuccess) return e;
-        hipLaunchKernelGGL(inception_fused_bf16_kernel<1>, dim3(grid), dim3(512), lds, s, a);
-        break;
-    case 2:
-        if ((e = set_attr((const void*)inception_fused_bf16_kernel<2>)) != hipSuccess) return e;
-        hipLaunchKernelGGL(inception_fused_bf16_kernel<2>, dim3(grid), dim3(512), lds, s, a);
-        break;
-    case 3:
-        if ((e = set_attr((const void*)inception_fused_bf16_kernel<3>)) != hipSuccess) return e;
-        hipLaunchKernelGGL(inception_fused_bf16_kernel<3>, dim3(grid), dim3(512), lds, s, a);
-        break;
+    case 1: hipLaunchKernelGGL(inception_fused_bf16_kernel<1>, dim3(grid), dim3(512), lds, s, a); break;
+    case 2: hipLaunchKernelGGL(inception_fused_bf16_kernel<2>, dim3(grid), dim3(512), lds, s, a); break;
+    case 3: hipLaunchKernelGGL(inception_fused_bf16_kernel<3>, dim3(grid), dim3(512), lds, s, a); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
