@@ -262,8 +262,10 @@ def call_mods(input_path, model_path, result_file, kmer_len, cent_signals_len,
 
     learning_rate / nproc / is_gpu are accepted for signature compatibility: inference ignores the
     learning rate and the engine always runs on the GPU. `f5_args` is the reference's
-    tuple (its first element is f5_batch_num); fast5 directories need the feature extractor, which is
-    a "next" row of the scope table."""
+    tuple (its first element is f5_batch_num); a directory as input_path takes the fast5 route
+    (features extracted on the host, deepsignal_amd/extract_features.py). With the native reader the engine is
+    driven through its asynchronous boundary (submit / wait, several batches in flight) and, when launched by
+    torch.distributed.run with WORLD_SIZE > 1, one process per GPU shares the reads."""
     start = time.time()
     if os.path.isdir(input_path):
         return _call_mods_from_fast5s(input_path, model_path, result_file, kmer_len, cent_signals_len, batch_size,
@@ -308,7 +310,16 @@ def call_mods(input_path, model_path, result_file, kmer_len, cent_signals_len,
 
         th = threading.Thread(target=_produce, daemon=True)
         th.start()
+        import collections
+        inflight = collections.deque()
+        pipelined = hasattr(engine, "submit") and hasattr(engine, "wait") and batch_size <= getattr(engine, "max_batch", 0)
         with open(result_file, "wb") as wf:
+            def drain(limit):
+                while len(inflight) > limit:
+                    ticket, it_, s_, e_ = inflight.popleft()
+                    act_, pred_ = engine.wait(ticket)
+                    wf.write(fastio.format_rows(it_.info, it_.info_off[s_:e_ + 1], act_, pred_, it_.kmer[s_:e_]))
+
             while True:
                 item = q.get()
                 if item is None:
@@ -318,11 +329,18 @@ def call_mods(input_path, model_path, result_file, kmer_len, cent_signals_len,
                 n = len(item.labels)
                 for s in range(0, n, batch_size):
                     e = min(n, s + batch_size)
-                    act, pred = engine.run(item.kmer[s:e], item.means[s:e], item.stds[s:e], item.lens[s:e],
-                                           item.signals[s:e])
-                    wf.write(fastio.format_rows(item.info, item.info_off[s:e + 1], act, pred, item.kmer[s:e]))
-                wf.flush()
+                    if pipelined:
+                        # asynchronous boundary: up to `slots` batches in flight; rows leave in submission order
+                        drain(engine.slots - 1)
+                        inflight.append((engine.submit(item.kmer[s:e], item.means[s:e], item.stds[s:e], item.lens[s:e],
+                                                       item.signals[s:e]), item, s, e))
+                    else:
+                        act, pred = engine.run(item.kmer[s:e], item.means[s:e], item.stds[s:e], item.lens[s:e],
+                                               item.signals[s:e])
+                        wf.write(fastio.format_rows(item.info, item.info_off[s:e + 1], act, pred, item.kmer[s:e]))
                 nsites += n
+            drain(0)
+            wf.flush()
         th.join()
         reader.close()
     else:

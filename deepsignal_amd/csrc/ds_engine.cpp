@@ -120,6 +120,12 @@ struct Slot {
     int* pred = nullptr;
     float* joint = nullptr;              // bf16 mode: [B][JP] bf16 FC operand (event features | signal features | zero pad)
 
+    // ds_submit / ds_wait: pinned host staging of one batch (inputs in, 12 B/site out), allocated on first use
+    char* pin_in = nullptr;
+    float* pin_act = nullptr;
+    int* pin_pred = nullptr;
+    int submitted_n = -1;                 // sites of the forward in flight on this slot (-1: none)
+
     std::map<int, Plan> plans;
     int last_n = 0;
 };
@@ -1037,6 +1043,9 @@ void ds_destroy(ds_handle* h)
             if (kv.second.graph) hipGraphExecDestroy(kv.second.graph);
             for (Op& op : kv.second.ops) { if (op.ev0) hipEventDestroy(op.ev0); if (op.ev1) hipEventDestroy(op.ev1); }
         }
+        if (sl.pin_in) hipHostFree(sl.pin_in);
+        if (sl.pin_act) hipHostFree(sl.pin_act);
+        if (sl.pin_pred) hipHostFree(sl.pin_pred);
         if (sl.ev_fork) hipEventDestroy(sl.ev_fork);
         if (sl.ev_join) hipEventDestroy(sl.ev_join);
         if (sl.s0) hipStreamDestroy(sl.s0);
@@ -1162,6 +1171,64 @@ int ds_forward(ds_handle* h, int32_t n, const int32_t* kmer, const float* means,
     }
     return DS_OK;
 }
+
+// Asynchronous host-buffer boundary: ds_submit copies one batch into the next slot's pinned staging buffer and
+// enqueues H2D + forward + D2H on that slot's streams; ds_wait(ticket) blocks until that forward is done and hands
+// the results out. Up to `slots` forwards are in flight, so PCIe copies, the 19-launch LSTM chain of one batch and
+// the host's own work (parsing, formatting) overlap.
+int ds_submit(ds_handle* h, int32_t n, const int32_t* kmer, const float* means, const float* stds, const float* sanums,
+              const float* signals, int32_t* ticket)
+{
+    if (!h || !ticket) return DS_ERR_INVALID;
+    if (!h->finalized) return fail(h, DS_ERR_INVALID, "weights not loaded");
+    if (n <= 0 || n > h->B) return fail(h, DS_ERR_INVALID, "ds_submit: n must be in [1, max_batch]");
+    if (!kmer || !means || !stds || !sanums || !signals) return fail(h, DS_ERR_INVALID, "null buffer");
+    if (h->profiling) return fail(h, DS_ERR_INVALID, "ds_submit is not available while profiling is on");
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    const int si = (int)(h->next_slot % h->slots.size());
+    Slot& sl = h->slots[si];
+    if (sl.submitted_n >= 0) return fail(h, DS_ERR_INVALID, "ds_submit: every slot is in flight; ds_wait the oldest ticket first");
+    const size_t B = h->B, T = h->T, S = h->S;
+    const size_t in_bytes = B * (4 * T * 4 + S * 4);
+    if (!sl.pin_in) {
+        HIPCHK(h, hipHostMalloc((void**)&sl.pin_in, in_bytes, hipHostMallocDefault));
+        HIPCHK(h, hipHostMalloc((void**)&sl.pin_act, B * h->C * 4, hipHostMallocDefault));
+        HIPCHK(h, hipHostMalloc((void**)&sl.pin_pred, B * 4, hipHostMallocDefault));
+    }
+    h->next_slot++;
+    h->cur = &sl;
+    const size_t nt = (size_t)n * T * 4;
+    char* p = sl.pin_in;
+    memcpy(p, kmer, nt); memcpy(p + B * T * 4, means, nt); memcpy(p + 2 * B * T * 4, stds, nt);
+    memcpy(p + 3 * B * T * 4, sanums, nt); memcpy(p + 4 * B * T * 4, signals, (size_t)n * S * 4);
+    HIPCHK(h, hipMemcpyAsync(sl.d_kmer, p, nt, hipMemcpyHostToDevice, sl.s0));
+    HIPCHK(h, hipMemcpyAsync(sl.d_means, p + B * T * 4, nt, hipMemcpyHostToDevice, sl.s0));
+    HIPCHK(h, hipMemcpyAsync(sl.d_stds, p + 2 * B * T * 4, nt, hipMemcpyHostToDevice, sl.s0));
+    HIPCHK(h, hipMemcpyAsync(sl.d_sanums, p + 3 * B * T * 4, nt, hipMemcpyHostToDevice, sl.s0));
+    HIPCHK(h, hipMemcpyAsync(sl.d_signals, p + 4 * B * T * 4, (size_t)n * S * 4, hipMemcpyHostToDevice, sl.s0));
+    int rc = run_resident(h, n);
+    if (rc) return rc;
+    HIPCHK(h, hipMemcpyAsync(sl.pin_act, sl.act, (size_t)n * h->C * 4, hipMemcpyDeviceToHost, sl.s0));
+    HIPCHK(h, hipMemcpyAsync(sl.pin_pred, sl.pred, (size_t)n * 4, hipMemcpyDeviceToHost, sl.s0));
+    sl.submitted_n = n;
+    *ticket = si;
+    return DS_OK;
+}
+
+int ds_wait(ds_handle* h, int32_t ticket, float* act, int32_t* pred)
+{
+    if (!h || !act || !pred) return DS_ERR_INVALID;
+    if (ticket < 0 || ticket >= (int)h->slots.size() || h->slots[ticket].submitted_n < 0)
+        return fail(h, DS_ERR_INVALID, "ds_wait: no forward in flight for this ticket");
+    Slot& sl = h->slots[ticket];
+    HIPCHK(h, hipStreamSynchronize(sl.s0));
+    memcpy(act, sl.pin_act, (size_t)sl.submitted_n * h->C * 4);
+    memcpy(pred, sl.pin_pred, (size_t)sl.submitted_n * 4);
+    sl.submitted_n = -1;
+    return DS_OK;
+}
+
+int ds_num_slots(ds_handle* h) { return h ? (int)h->slots.size() : DS_ERR_INVALID; }
 
 int ds_alloc_host(size_t bytes, void** out)
 {

@@ -16,12 +16,14 @@
 #include <charconv>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <thread>
 #include <vector>
 
 #include <fcntl.h>
+#include <sched.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
@@ -170,6 +172,25 @@ int format_f32(float x, char* out)
 
 }  // namespace
 
+// CPUs this process may actually use: the affinity mask and the cgroup-v2 CPU quota (cpu.max) both count; the GPU
+// boxes expose 256 logical CPUs under a 16-CPU quota, and 256 parser threads on 16 CPUs only thrash.
+static int usable_cpus()
+{
+    int n = (int)std::max(1u, std::thread::hardware_concurrency());
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof set, &set) == 0) n = std::min(n, std::max(1, CPU_COUNT(&set)));
+    if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        char quota[32] = {0};
+        long period = 0;
+        if (fscanf(f, "%31s %ld", quota, &period) == 2 && strcmp(quota, "max") != 0 && period > 0) {
+            const long q = atol(quota);
+            if (q > 0) n = std::min<long>(n, std::max<long>(1, (q + period - 1) / period));
+        }
+        fclose(f);
+    }
+    return n;
+}
+
 extern "C" {
 
 int ds_tsv_open(const char* path, int32_t kmer_len, int32_t signal_len, int32_t nthreads, ds_tsv** out)
@@ -178,7 +199,7 @@ int ds_tsv_open(const char* path, int32_t kmer_len, int32_t signal_len, int32_t 
     *out = nullptr;
     ds_tsv* t = new ds_tsv();
     t->kmer_len = kmer_len; t->signal_len = signal_len;
-    t->nthreads = nthreads > 0 ? nthreads : std::max(1u, std::thread::hardware_concurrency());
+    t->nthreads = nthreads > 0 ? nthreads : usable_cpus();
     t->fd = open(path, O_RDONLY);
     if (t->fd < 0) { delete t; return DS_ERR_IO; }
     struct stat st;

@@ -23,7 +23,7 @@ EXPORTED_SYMBOLS = (
     "ds_create", "ds_destroy", "ds_last_error", "ds_version", "ds_load_weights", "ds_set_tensor",
     "ds_finalize_weights", "ds_forward", "ds_forward_device", "ds_sync", "ds_alloc_host", "ds_free_host",
     "ds_get_intermediate", "ds_set_profiling", "ds_num_stages", "ds_get_stage", "ds_reset_stage_times",
-    "ds_set_graph", "ds_num_kernels", "ds_get_kernel_stat",
+    "ds_set_graph", "ds_num_kernels", "ds_get_kernel_stat", "ds_submit", "ds_wait", "ds_num_slots",
     # scope row f1 (host I/O)
     "ds_tsv_open", "ds_tsv_close", "ds_tsv_error", "ds_tsv_next", "ds_tsv_kmer", "ds_tsv_means", "ds_tsv_stds",
     "ds_tsv_lens", "ds_tsv_signals", "ds_tsv_labels", "ds_tsv_info", "ds_tsv_info_offsets", "ds_format_rows",
@@ -97,6 +97,8 @@ def load_library() -> ctypes.CDLL:
     lib.ds_forward.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp]
     lib.ds_forward_device.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp]
     lib.ds_sync.argtypes = [vp]
+    lib.ds_submit.argtypes = [vp, i32, vp, vp, vp, vp, vp, ctypes.POINTER(i32)]
+    lib.ds_wait.argtypes = [vp, i32, vp, vp]
     lib.ds_alloc_host.argtypes = [ctypes.c_size_t, ctypes.POINTER(vp)]
     lib.ds_free_host.argtypes = [vp]
     lib.ds_get_intermediate.argtypes = [vp, ctypes.c_char_p, vp, i64]
@@ -135,6 +137,8 @@ class Engine:
             self._h = ctypes.c_void_p()
             raise RuntimeError("ds_create failed (%d): %s" % (rc, msg))
         self.kmer_len, self.signal_len, self.class_num = kmer_len, signal_len, class_num
+        self._lib.ds_num_slots.argtypes = [ctypes.c_void_p]
+        self._slots = int(self._lib.ds_num_slots(self._h))
         self.device, self.max_batch = device, max_batch
 
     # -- lifecycle -----------------------------------------------------------------------------
@@ -193,6 +197,28 @@ class Engine:
 
     def sync(self) -> None:
         self._check(self._lib.ds_sync(self._h), "ds_sync")
+
+    def submit(self, kmer, means, stds, sanums, signals) -> Tuple[int, int]:
+        """Asynchronous run() of one batch (n <= max_batch): returns a ticket for wait(). Up to `slots` batches may be
+        in flight; wait() them in submission order."""
+        kmer = np.ascontiguousarray(kmer, dtype=np.int32)
+        n = int(kmer.shape[0])
+        arrs = [np.ascontiguousarray(a, dtype=np.float32) for a in (means, stds, sanums, signals)]
+        t = ctypes.c_int32()
+        self._check(self._lib.ds_submit(self._h, n, kmer.ctypes.data, *(a.ctypes.data for a in arrs), ctypes.byref(t)),
+                    "ds_submit")
+        return (int(t.value), n)
+
+    def wait(self, ticket: Tuple[int, int]) -> Tuple[np.ndarray, np.ndarray]:
+        slot, n = ticket
+        act = np.empty((n, self.class_num), np.float32)
+        pred = np.empty((n,), np.int32)
+        self._check(self._lib.ds_wait(self._h, slot, act.ctypes.data, pred.ctypes.data), "ds_wait")
+        return act, pred
+
+    @property
+    def slots(self) -> int:
+        return self._slots
 
     # -- diagnostics ---------------------------------------------------------------------------
     def intermediate(self, name: str, shape) -> np.ndarray:

@@ -88,6 +88,17 @@ int ds_forward_device(ds_handle *h, int32_t n, const int32_t *d_kmer, const floa
                       float *d_act, int32_t *d_pred);
 int ds_sync(ds_handle *h);
 
+/* Asynchronous form of ds_forward for host buffers (n <= max_batch): ds_submit stages the batch in pinned memory of
+ * the next pipeline slot and enqueues H2D + forward + D2H there; ds_wait blocks on that one forward and copies its
+ * act[n, class_num] / pred[n] out. Tickets must be waited in submission order at the latest when all slots
+ * (ds_config.reserved[1], default 8) are in flight. Replaces the blocking tf_sess.run (call_modifications.py:177-178)
+ * where the caller has other work to overlap (parsing the next queue item, formatting the previous rows). */
+int ds_submit(ds_handle *h, int32_t n, const int32_t *kmer, const float *means, const float *stds,
+              const float *sanums, const float *signals, int32_t *ticket);
+int ds_wait(ds_handle *h, int32_t ticket, float *act, int32_t *pred);
+/* Forwards that may be in flight at once (pipeline slots of this handle). */
+int ds_num_slots(ds_handle *h);
+
 /* Pinned host allocation helpers for callers that want async H2D/D2H overlap. */
 int ds_alloc_host(size_t bytes, void **out);
 int ds_free_host(void *p);

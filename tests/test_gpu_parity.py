@@ -226,3 +226,29 @@ def test_other_kmer_and_signal_lengths(geom, precision):
         e_act, _ = torch_statement.forward_bf16(w, feats, lstm_bf16=True)
         assert np.isfinite(act).all() and np.abs(act - e_act).max() <= 3e-3
     eng.close()
+
+
+def test_submit_wait_matches_run(small_weights):
+    """Asynchronous host boundary (ds_submit / ds_wait): tickets waited in order give the bits of the blocking run();
+    over-subscription and stale tickets are refused."""
+    feats = synth.synthetic_features(5 * 96 + 17, seed=41)
+    keys = ("kmer", "means", "stds", "sanums", "signals")
+    eng = _engine(small_weights, max_batch=96, slots=3)
+    assert eng.slots == 3
+    ref_act, ref_pred = eng.run(*(feats[k] for k in keys))
+    chunks = [(s, min(s + 96, len(feats["kmer"]))) for s in range(0, len(feats["kmer"]), 96)]
+    got_act, got_pred, inflight = [], [], []
+    for s, e in chunks:
+        if len(inflight) == eng.slots:
+            a, p = eng.wait(inflight.pop(0))
+            got_act.append(a); got_pred.append(p)
+        inflight.append(eng.submit(*(feats[k][s:e] for k in keys)))
+    with pytest.raises(RuntimeError):          # all three slots are in flight
+        eng.submit(*(feats[k][:8] for k in keys))
+    while inflight:
+        a, p = eng.wait(inflight.pop(0))
+        got_act.append(a); got_pred.append(p)
+    assert np.array_equal(np.concatenate(got_act), ref_act) and np.array_equal(np.concatenate(got_pred), ref_pred)
+    with pytest.raises(RuntimeError):          # nothing in flight any more
+        eng.wait((0, 8))
+    eng.close()
