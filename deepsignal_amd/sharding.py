@@ -27,12 +27,13 @@ def shard_indices(read_ids: Sequence[str], world: int, rank: int) -> np.ndarray:
     return np.nonzero(assign_reads(read_ids, world) == rank)[0]
 
 
-def gather_results(act, pred, index, dist=None, dst: int = 0, device=None):
+def gather_results(act, pred, index, dist=None, dst: int = 0, device=None, as_numpy: bool = True):
     """Gather (act float32[n_i,C], pred int32[n_i], index int64[n_i]) from all ranks to `dst`.
 
     Ragged: every rank pads to the max shard length; returns on dst (act, pred) re-ordered so that
     row j is the site with global index j, and (None, None) elsewhere. `dist` = torch.distributed
-    (already initialised) or None for single-process."""
+    (already initialised) or None for single-process. as_numpy=False keeps the re-ordered results as tensors on
+    `device` (no device-to-host copy inside the call: what bench.py times is the RCCL exchange itself)."""
     import torch
     act_t = torch.as_tensor(act, dtype=torch.float32)
     pred_t = torch.as_tensor(pred, dtype=torch.int32)
@@ -60,6 +61,15 @@ def gather_results(act, pred, index, dist=None, dst: int = 0, device=None):
     if rank != dst:
         return None, None
     total = sum(counts)
+    if not as_numpy:
+        t_act = torch.empty((total, C), dtype=torch.float32, device=dev)
+        t_pred = torch.empty((total,), dtype=torch.int32, device=dev)
+        for r in range(world):
+            blk = gl[r][:counts[r]]
+            gi = blk[:, C + 1].to(torch.int64)
+            t_act[gi] = blk[:, :C].to(torch.float32)
+            t_pred[gi] = blk[:, C].to(torch.int32)
+        return t_act, t_pred
     out_act = np.empty((total, C), np.float32)
     out_pred = np.empty((total,), np.int32)
     for r in range(world):

@@ -35,7 +35,9 @@ def _worker(rank, world, port, tmp):
     sub = {k: v[mine] for k, v in feats.items()}
     act, pred = oracle.forward(w, sub, "f32", nthreads=2) if len(mine) else (np.zeros((0, 2), np.float32), np.zeros((0,), np.int32))
     g_act, g_pred = sharding.gather_results(act, pred, mine, dist)
+    t_act, t_pred = sharding.gather_results(act, pred, mine, dist, as_numpy=False)      # tensor form used by bench.py
     if rank == 0:
+        assert np.array_equal(t_act.numpy(), g_act) and np.array_equal(t_pred.numpy(), g_pred)
         np.savez(os.path.join(tmp, "gathered.npz"), act=g_act, pred=g_pred)
     else:
         assert g_act is None
