@@ -75,8 +75,8 @@ const char* const kKernelNames[K_COUNT] = {"gemm_kernel<1,2,4,1,0,0,1,1>", "gemm
                                            "maxpool_s2_kernel", "avgpool7_kernel", "head_kernel",
                                            "gemm_kernel<1,2,4,1,0,0,1,1,bf16>", "gemm_kernel<1,2,4,1,0,1,1,1,bf16>",
                                            "gemm_kernel<4,2,1,4,0,0,2,1,bf16>", "gemm_kernel<4,2,1,4,0,2,2,1,bf16>",
-                                           "pack_event_feat_bf16_kernel", "gemm_kernel<1,4,4,1,1,0,1,1,bf16>",
-                                           "gemm_kernel<1,4,4,1,1,2,1,1,bf16>", "inception_fused_bf16_kernel<1>",
+                                           "pack_event_feat_bf16_kernel", "gemm_kernel<1,4,4,1,1,0,3,1,bf16>",
+                                           "gemm_kernel<1,4,4,1,1,2,3,1,bf16>", "inception_fused_bf16_kernel<1>",
                                            "inception_fused_bf16_kernel<2>", "inception_fused_bf16_kernel<3>"};
 struct KernelStat {
     int64_t launches = 0;

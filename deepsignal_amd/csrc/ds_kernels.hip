@@ -204,9 +204,14 @@ __global__ __launch_bounds__(64 * WM * WN * KS, (EPI == 1 && KS == 1) ? 2 : 1) v
     //   (5) ds_read chunk c+1 fragments -> a[X^1]   (latency hidden by (6))
     //   (6) MFMAs of read-step 1 of chunk c
     // One barrier per chunk, no load / LDS latency on the MFMA critical path.
-    float4 R[2][SLOTS], Rm[2][SLOTS], Rp[2][SLOTS];
-    bool lok[2][SLOTS];
-    float4 bq[2 * BD][NT][2];   // weight ring: 2 buffers (BD=1) or 4 (BD=2), statically indexed
+    // BD == 3 ("deep"): activations AND weights are requested two full chunks ahead through rings of three register
+    // buffers (chunk k in R[k % 3] / bq[k % 3]; four would not fit 256 VGPRs next to a 1x4 accumulator tile). For
+    // bf16 operands a chunk is only ~256 matrix-pipe cycles, so one step of look-ahead cannot cover an L2 / HBM
+    // round trip.
+    constexpr int RA = BD == 3 ? 3 : 2;
+    float4 R[RA][SLOTS], Rm[RA][SLOTS], Rp[RA][SLOTS];
+    bool lok[RA][SLOTS];
+    float4 bq[BD == 3 ? 3 : 2 * BD][NT][2];   // weight ring: 2 buffers (BD=1), 4 (BD=2) or 3 (BD=3), statically indexed
     float4 af[2][2][MT];
     auto load_a = [&](int X) {
 #pragma unroll
@@ -225,8 +230,8 @@ __global__ __launch_bounds__(64 * WM * WN * KS, (EPI == 1 && KS == 1) ? 2 : 1) v
 #pragma unroll
         for (int j = 1; j < KS; ++j) skip_chunk();
     };
-    auto store_a = [&](int X) {
-        float* dst = X ? As1 : As0;
+    auto store_a = [&](int X, int P = -1) {      // ring slot X -> LDS buffer P (default: the slot's own parity)
+        float* dst = (P < 0 ? X : P) ? As1 : As0;
 #pragma unroll
         for (int i = 0; i < SLOTS; ++i) {
             const int idx = tid + i * NTHR;
@@ -284,6 +289,35 @@ __global__ __launch_bounds__(64 * WM * WN * KS, (EPI == 1 && KS == 1) ? 2 : 1) v
     constexpr int N_ALOADS = SLOTS * (AMODE == 1 ? 3 : 1);
     constexpr int N_BLOADS = 2 * NT;
     constexpr int N_VALU_PER_STORE = (AMODE == 1 ? 12 : AMODE == 2 ? 0 : 4);
+    // deep variant: chunk c sits in ring slot Q = c % 3 and LDS buffer X = c & 1
+#define DS_STEPD(X, Q, HAS1, HAS3)                                                        \
+    do {                                                                                  \
+        if (HAS3) { load_a(((Q) + 2) % 3); load_b(((Q) + 2) % 3); }                       \
+        if (HAS1) store_a(((Q) + 1) % 3, (X) ^ 1);                                        \
+        mfma_rs2(X, Q, 0);                                                                \
+        if (HAS1) {                                                                       \
+            _Pragma("unroll") for (int i_ = 0; i_ < SLOTS; ++i_) {                        \
+                __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);                          \
+                if (N_VALU_PER_STORE) __builtin_amdgcn_sched_group_barrier(0x2, N_VALU_PER_STORE, 0); \
+                __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);                        \
+            }                                                                             \
+        }                                                                                 \
+        if (HAS3) {                                                                       \
+            _Pragma("unroll") for (int i_ = 0; i_ < N_ALOADS + N_BLOADS; ++i_) {          \
+                __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);                          \
+                __builtin_amdgcn_sched_group_barrier(0x20, 1, 0);                         \
+            }                                                                             \
+        }                                                                                 \
+        __builtin_amdgcn_sched_group_barrier(0x8, N_MFMA_HALF, 0);                        \
+        __builtin_amdgcn_sched_barrier(0);                                                \
+        __syncthreads();                                                                  \
+        if (HAS1) read_frags((X) ^ 1);                                                    \
+        mfma_rs2(X, Q, 1);                                                                \
+        __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);                                  \
+        if (HAS1) __builtin_amdgcn_sched_group_barrier(0x100, 2 * MT, 0);                 \
+        __builtin_amdgcn_sched_group_barrier(0x8, N_MFMA_HALF, 0);                        \
+        __builtin_amdgcn_sched_barrier(0);                                                \
+    } while (0)
 #define DS_STEP(X, JC, JN, HAS1, HAS2, HASB)                                              \
     do {                                                                                  \
         if (HAS2) load_a(X);                                                              \
@@ -329,11 +363,40 @@ __global__ __launch_bounds__(64 * WM * WN * KS, (EPI == 1 && KS == 1) ? 2 : 1) v
         load_b(0);
         store_a(0);
         if (nchunks > 1) load_a(1);
-        if (BD == 2 && nchunks > 1) load_b(1);
+        if (BD >= 2 && nchunks > 1) load_b(1);
         __syncthreads();
         read_frags(0);
         int c = 0;
-        if (BD == 1) {
+        if (BD == 3) {
+            // six steps per trip: LDS parity has period 2, the register rings period 3
+            while (c + 7 < nchunks) {      // chunks c .. c+5 with every look-ahead (up to c+7) in range
+                DS_STEPD(0, 0, true, true);
+                DS_STEPD(1, 1, true, true);
+                DS_STEPD(0, 2, true, true);
+                DS_STEPD(1, 0, true, true);
+                DS_STEPD(0, 1, true, true);
+                DS_STEPD(1, 2, true, true);
+                c += 6;
+            }
+            // tail: 1..7 chunks left, runtime (wave-uniform) look-ahead flags
+            DS_STEPD(0, 0, c + 1 < nchunks, c + 2 < nchunks);
+            if (++c < nchunks) {
+                DS_STEPD(1, 1, c + 1 < nchunks, c + 2 < nchunks);
+                if (++c < nchunks) {
+                    DS_STEPD(0, 2, c + 1 < nchunks, c + 2 < nchunks);
+                    if (++c < nchunks) {
+                        DS_STEPD(1, 0, c + 1 < nchunks, c + 2 < nchunks);
+                        if (++c < nchunks) {
+                            DS_STEPD(0, 1, c + 1 < nchunks, c + 2 < nchunks);
+                            if (++c < nchunks) {
+                                DS_STEPD(1, 2, c + 1 < nchunks, false);
+                                if (++c < nchunks) DS_STEPD(0, 0, false, false);
+                            }
+                        }
+                    }
+                }
+            }
+        } else if (BD == 1) {
             while (c + 3 < nchunks) {      // steady state: every look-ahead exists, no conditionals
                 DS_STEP(0, 0, 1, true, true, true);
                 DS_STEP(1, 1, 0, true, true, true);
@@ -373,6 +436,7 @@ __global__ __launch_bounds__(64 * WM * WN * KS, (EPI == 1 && KS == 1) ? 2 : 1) v
         }
     }
 #undef DS_STEP
+#undef DS_STEPD
 
     // ---------------- K-lane exchange: each lane ends up owning half of the accumulator rows ----------------
     constexpr int R0 = 0;
@@ -552,8 +616,8 @@ hipError_t launch_gemm(GemmCfg cfg, const GemmLaunch* d_launch, int total_tiles,
     case CFG_BCONV_POOL: hipLaunchKernelGGL((gemm_kernel<1, 2, 4, 1, 0, 1, 1, 1, true>), dim3(total_tiles), dim3(256), 0, s, d_launch); break;
     case CFG_BFC: hipLaunchKernelGGL((gemm_kernel<4, 2, 1, 4, 0, 0, 2, 1, true>), dim3(total_tiles), dim3(256), 0, s, d_launch); break;
     case CFG_BFC_DENSE: hipLaunchKernelGGL((gemm_kernel<4, 2, 1, 4, 0, 2, 2, 1, true>), dim3(total_tiles), dim3(256), 0, s, d_launch); break;
-    case CFG_BLSTM: hipLaunchKernelGGL((gemm_kernel<1, 4, 4, 1, 1, 0, 1, 1, true>), dim3(total_tiles), dim3(256), 0, s, d_launch); break;
-    case CFG_BLSTM_DENSE: hipLaunchKernelGGL((gemm_kernel<1, 4, 4, 1, 1, 2, 1, 1, true>), dim3(total_tiles), dim3(256), 0, s, d_launch); break;
+    case CFG_BLSTM: hipLaunchKernelGGL((gemm_kernel<1, 4, 4, 1, 1, 0, 3, 1, true>), dim3(total_tiles), dim3(256), 0, s, d_launch); break;
+    case CFG_BLSTM_DENSE: hipLaunchKernelGGL((gemm_kernel<1, 4, 4, 1, 1, 2, 3, 1, true>), dim3(total_tiles), dim3(256), 0, s, d_launch); break;
     }
     return hipGetLastError();
 }
