@@ -643,7 +643,7 @@ size_t inception_fused_lds_bytes(int tm, int W, int spt)
 {
     const int tr32 = tm * 32;
     // region A (chunk staging, later the b1|b2 output tile) | T1 | T2 | rowmap
-    return (size_t)(tr32 * F_LD1 + (spt * (W + 4) + 5) * F_LD1 + tr32 * F_LD2 + tr32) * sizeof(float);
+    return (size_t)(tr32 * F_LD1 + (spt * (W + 4) + 5) * F_LD1 + tr32 * F_LD2 + tr32 + 192) * sizeof(float);
 }
 
 // All weights of a conv unit (ntaps x 4 k-groups, <= 20 float4): requested EARLY — before the barrier or
@@ -666,10 +666,10 @@ __device__ __forceinline__ void fused_conv_unit(const float* T1, int rm, int col
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const float4 a = *reinterpret_cast<const float4*>(arow + g * 8);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, ub[t * 4 + g].x, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, ub[t * 4 + g].y, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, ub[t * 4 + g].z, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, ub[t * 4 + g].w, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ub[t * 4 + g].x, a.x, acc, 0, 0, 0);     // transposed: see the kernel
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ub[t * 4 + g].y, a.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ub[t * 4 + g].z, a.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ub[t * 4 + g].w, a.w, acc, 0, 0, 0);
         }
     }
 }
@@ -689,6 +689,7 @@ __global__ __launch_bounds__(512, DS_FUSED_WPS) void inception_fused_kernel(cons
     const int W = a.W, spt = a.spt, cin = a.cin;
     float* T2 = T1 + (spt * (W + 4) + 5) * F_LD1;   // [TR32*F_LD2]  (T1 has 5 spare rows: a dump row for padding rows + its halo)
     int* rowmap = reinterpret_cast<int*>(T2 + TR32 * F_LD2);   // [TR32] tile row -> T1 row
+    float* const Bs = reinterpret_cast<float*>(rowmap + TR32); // [3][64] biases of b5b | b3b | b4b
     const int site0 = blockIdx.x * spt;
     const int nhere = min(spt, a.n_sites - site0);
     const int TRv = nhere * W;                // valid rows of this tile
@@ -703,6 +704,10 @@ __global__ __launch_bounds__(512, DS_FUSED_WPS) void inception_fused_kernel(cons
     for (int i = tid; i < (spt * (W + 4) + 5) * F_LD1; i += 512) T1[i] = 0.0f;   // halos (and everything else) = 0
     if (tid < TR32)   // rows past the tile's last site map to the dump row, so LDS writes need no predicate
         rowmap[tid] = tid < TRv ? (tid / W) * (W + 4) + 2 + tid % W : spt * (W + 4) + 2;
+    if (tid >= 256 && tid < 448) {
+        const int q = tid - 256;
+        Bs[q] = gload((q < 64 ? a.bias5b : q < 128 ? a.bias3b : a.bias4b) + (q & 63));
+    }
 
     // ---- P1 staging cursor: thread -> (row, 16-byte slot); rows past the tile end re-read row TRv-1
     const bool stager = tid < TR32 * 4;
@@ -727,11 +732,30 @@ __global__ __launch_bounds__(512, DS_FUSED_WPS) void inception_fused_kernel(cons
     }
     const float* bp = a.Bp1 + ((size_t)wave * ((cin + 31) / 32 * 4) * 64 + lane) * 4;   // K padded to 32 in the pack
 
+    // Every MFMA of this kernel is issued TRANSPOSED -- mfma(weight fragment, activation fragment) computes (X W)^T --
+    // so a lane ends up holding, for ONE activation row (lane & 31), 4 x 4 consecutive output channels
+    // (register 4g+e <-> channel 32*ntile + 8g + 4*(lane >> 5) + e). Results leave as float4 groups (LDS and HBM)
+    // instead of scalars, and the bias is simply the accumulator's initial value.
+    const int h4 = 4 * (lane >> 5), rlane = lane & 31;
     floatx16 acc[TM];
+    {
+        float4 bv[4];
 #pragma unroll
-    for (int mt = 0; mt < TM; ++mt)
+        for (int g = 0; g < 4; ++g) {
+            bv[g] = gload4(a.bias1 + wave * 32 + 8 * g + h4);                  // bias1 is zero-padded to 256
+            if (wave < 2) {                                                     // b5 stem columns also carry the tail's BN shift
+                const float4 t = gload4(a.bias5c + wave * 32 + 8 * g + h4);     // (zero-padded to 64)
+                bv[g].x += t.x; bv[g].y += t.y; bv[g].z += t.z; bv[g].w += t.w;
+            }
+        }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[mt][r] = 0.0f;
+        for (int mt = 0; mt < TM; ++mt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                acc[mt][4 * g + 0] = bv[g].x; acc[mt][4 * g + 1] = bv[g].y;
+                acc[mt][4 * g + 2] = bv[g].z; acc[mt][4 * g + 3] = bv[g].w;
+            }
+    }
 
     // branch 1's maxpool(3, stride 1, SAME): waves 6,7 build their A fragments as the max of three staged
     // rows (previous / own / next; at a site edge the missing neighbour is the own row = "padded taps
@@ -745,8 +769,6 @@ __global__ __launch_bounds__(512, DS_FUSED_WPS) void inception_fused_kernel(cons
         offp[mt] = (row < TRv && w < W - 1) ? F_LDA : 0;
     }
 
-    const float bias_p1 = (wave * 32 + (lane & 31)) < 240 ? gload(a.bias1 + wave * 32 + (lane & 31)) : 0.0f;
-    const float bias_tail = (wave < 2 && (wave * 32 + (lane & 31)) < 48) ? gload(a.bias5c + wave * 32 + (lane & 31)) : 0.0f;
     const int nchunks = cin / KC;      // >= 15
 
     // P1 main loop: same software pipeline as gemm_kernel (fragments of chunk c+1 are read into
@@ -787,10 +809,10 @@ __global__ __launch_bounds__(512, DS_FUSED_WPS) void inception_fused_kernel(cons
         auto mfma_rs = [&](int X, int rs) {
 #pragma unroll
             for (int mt = 0; mt < TM; ++mt) {
-                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[X][rs][mt].x, bq[X][rs].x, acc[mt], 0, 0, 0);
-                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[X][rs][mt].y, bq[X][rs].y, acc[mt], 0, 0, 0);
-                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[X][rs][mt].z, bq[X][rs].z, acc[mt], 0, 0, 0);
-                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[X][rs][mt].w, bq[X][rs].w, acc[mt], 0, 0, 0);
+                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(bq[X][rs].x, af[X][rs][mt].x, acc[mt], 0, 0, 0);
+                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(bq[X][rs].y, af[X][rs][mt].y, acc[mt], 0, 0, 0);
+                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(bq[X][rs].z, af[X][rs][mt].z, acc[mt], 0, 0, 0);
+                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(bq[X][rs].w, af[X][rs][mt].w, acc[mt], 0, 0, 0);
             }
         };
 #define DS_FSTEP(X, HAS1, HAS2)                                   \
@@ -837,14 +859,15 @@ __global__ __launch_bounds__(512, DS_FUSED_WPS) void inception_fused_kernel(cons
     __syncthreads();   // all fragment reads of the staging area are done before T2 aliases it
     DS_STAMP(2);
 
-    // ---- static wave -> unit assignment of P2 (wave-uniform). kind: 0 none, 1 b5b, 2 b3b, 3 b4b
+    // ---- static wave -> unit assignment of P2 (wave-uniform). kind: 0 none, 1 b5b, 2 b3b, 3 b4b. Waves w and w+4 share
+    // a SIMD; the table keeps the MFMA count per SIMD within 5 % across P2a + P2b.
     int a1k = 0, a1m = 0, a1n = 0, a2k = 0, a2m = 0, a2n = 0;      // P2a units
-    int b1k = 0, b1m = 0, b1n = 0, b2k = 0, b2m = 0, b2n = 0;      // P2b units (waves 0,1 run the residual tail instead)
+    int b1k = 0, b1m = 0, b1n = 0, b2k = 0, b2m = 0, b2n = 0;      // P2b units (waves 0,1 run the residual tail first)
     if (TM == 3) {
         if (wave < 6) { a1k = 1; a1m = wave % 3; a1n = wave / 3; }
-        else { a1k = 2; a1m = 0; a1n = wave - 6; a2k = 2; a2m = 1; a2n = wave - 6; }
+        else { a1k = 2; a1m = 0; a1n = wave - 6; }
         if (wave >= 2) { b1k = 3; b1m = (wave - 2) % 3; b1n = (wave - 2) / 3; }
-        if (wave == 2 || wave == 3) { b2k = 2; b2m = 2; b2n = wave - 2; }
+        if (wave >= 4) { b2k = 2; b2m = 1 + ((wave - 4) >> 1); b2n = (wave - 4) & 1; }
     } else if (TM == 2) {
         if (wave < 4) { a1k = 1; a1m = wave & 1; a1n = wave >> 1; }
         else { a1k = 2; a1m = wave & 1; a1n = (wave - 4) >> 1; }
@@ -856,40 +879,33 @@ __global__ __launch_bounds__(512, DS_FUSED_WPS) void inception_fused_kernel(cons
     }
     auto unit_Bp = [&](int k) { return k == 1 ? a.Bp5b : k == 2 ? a.Bp3b : a.Bp4b; };
     auto unit_taps = [&](int k) { return k == 3 ? 5 : 3; };
-    auto unit_bias = [&](int k, int nt) -> float {
-        const int col = nt * 32 + (lane & 31);
-        if (k == 1) return gload(a.bias5b + col);
-        if (k == 0 || col >= 48) return 0.0f;
-        return gload((k == 2 ? a.bias3b : a.bias4b) + col);
-    };
-    // every bias this wave will need, requested now (off the critical path of the unit epilogues)
-    const float ba1 = unit_bias(a1k, a1n), ba2 = unit_bias(a2k, a2n), bb1 = unit_bias(b1k, b1n), bb2 = unit_bias(b2k, b2n);
     float4 pf[20];                                   // prefetched weights of the next unit
     if (a1k) fused_unit_prefetch(unit_Bp(a1k), unit_taps(a1k), a1n, lane, pf);
 
-    // ---- P1 epilogue: route the 256 columns. b1|b2 go through an LDS tile and leave as whole
-    // 384-B row segments (16-B stores) instead of 48 scalar stores per lane.
-    const int rl = 4 * (lane >> 5);
-    if (wave >= 3 && wave <= 5) {            // wave-uniform: n-tiles 3,4,5 = b3a | b4a | b5a -> T1
-        const int c = wave * 32 + (lane & 31) - 96;
-        int rmv[TM][16];
+    // ---- P1 epilogue (bias already inside acc): route the 256 columns. b1|b2 go through an LDS tile and leave as
+    // whole 384-B row segments.
+    if (wave >= 3 && wave <= 5) {            // wave-uniform: n-tiles 3,4,5 = b3a | b4a | b5a -> T1, through the row map
 #pragma unroll
-        for (int mt = 0; mt < TM; ++mt)
+        for (int mt = 0; mt < TM; ++mt) {
+            const int rm = rowmap[mt * 32 + rlane];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) rmv[mt][r] = rowmap[mt * 32 + rl + (r & 3) + 8 * (r >> 2)];
-#pragma unroll
-        for (int mt = 0; mt < TM; ++mt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) T1[rmv[mt][r] * F_LD1 + c] = fmaxf(acc[mt][r] + bias_p1, 0.0f);
+            for (int g = 0; g < 4; ++g)
+                *reinterpret_cast<float4*>(T1 + rm * F_LD1 + (wave * 32 - 96) + 8 * g + h4) =
+                    make_float4(fmaxf(acc[mt][4 * g], 0.0f), fmaxf(acc[mt][4 * g + 1], 0.0f), fmaxf(acc[mt][4 * g + 2], 0.0f),
+                                fmaxf(acc[mt][4 * g + 3], 0.0f));
+        }
     } else if (wave != 0) {                  // n-tiles 1,2 (b5s tail | b2) and 6,7 (b1 | padding) -> output tile
-        const int col = wave * 32 + (lane & 31);
-        const int ycol = col < 96 ? col : col - 192;        // position inside Y[:, 0:96) (b1 first, then b2)
-        if (col >= 48 && col < 240) {
 #pragma unroll
-            for (int mt = 0; mt < TM; ++mt)
+        for (int g = 0; g < 4; ++g) {
+            const int col = wave * 32 + 8 * g + h4;          // groups of 4 never straddle 48 / 240
+            if (col >= 48 && col < 240) {
+                const int ycol = col < 96 ? col : col - 192;        // position inside Y[:, 0:96) (b1 first, then b2)
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    Ys[(mt * 32 + rl + (r & 3) + 8 * (r >> 2)) * F_LD1 + ycol] = fmaxf(acc[mt][r] + bias_p1, 0.0f);
+                for (int mt = 0; mt < TM; ++mt)
+                    *reinterpret_cast<float4*>(Ys + (mt * 32 + rlane) * F_LD1 + ycol) =
+                        make_float4(fmaxf(acc[mt][4 * g], 0.0f), fmaxf(acc[mt][4 * g + 1], 0.0f), fmaxf(acc[mt][4 * g + 2], 0.0f),
+                                    fmaxf(acc[mt][4 * g + 3], 0.0f));
+            }
         }
     }
     DS_STAMP(3);
@@ -904,41 +920,44 @@ __global__ __launch_bounds__(512, DS_FUSED_WPS) void inception_fused_kernel(cons
         }
     }
 
-    const int rm_of = lane & 31;
-    auto run_unit = [&](int kind, int mt, int nt, float bv) {
+    auto run_unit = [&](int kind, int mt, int nt) {
         floatx16 u;
+        const float* bsrc = Bs + (kind == 1 ? 0 : kind == 2 ? 64 : 128) + nt * 32 + h4;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) u[r] = 0.0f;
-        const int rm = rowmap[mt * 32 + rm_of];
-        const int col = nt * 32 + (lane & 31);
+        for (int g = 0; g < 4; ++g) {
+            const float4 t = *reinterpret_cast<const float4*>(bsrc + 8 * g);
+            u[4 * g] = t.x; u[4 * g + 1] = t.y; u[4 * g + 2] = t.z; u[4 * g + 3] = t.w;
+        }
+        const int row = mt * 32 + rlane;
+        const int rm = rowmap[row];
         if (kind == 1) {          // 1x3, 32 -> 64, ReLU, to T2                            layers.py:127-131
             fused_conv_unit<3>(T1, rm, 64, lane, pf, u);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = mt * 32 + rl + (r & 3) + 8 * (r >> 2);
-                T2[row * F_LD2 + col] = fmaxf(u[r] + bv, 0.0f);
-            }
+            for (int g = 0; g < 4; ++g)
+                *reinterpret_cast<float4*>(T2 + row * F_LD2 + nt * 32 + 8 * g + h4) =
+                    make_float4(fmaxf(u[4 * g], 0.0f), fmaxf(u[4 * g + 1], 0.0f), fmaxf(u[4 * g + 2], 0.0f), fmaxf(u[4 * g + 3], 0.0f));
         } else {
             // kind 2: 1x3, 32 -> 48, ReLU, to Y[96,144)   layers.py:106-110
             // kind 3: 1x5, 32 -> 48, ReLU, to Y[144,192)  layers.py:115-119
             if (kind == 2) fused_conv_unit<3>(T1, rm, 0, lane, pf, u);
             else fused_conv_unit<5>(T1, rm, 32, lane, pf, u);
-            if (col < 48) {
-                const int ybase = kind == 2 ? 96 : 144;
+            const int ybase = kind == 2 ? 96 : 144;
+            if (row < TRv) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = mt * 32 + rl + (r & 3) + 8 * (r >> 2);
-                    if (row < TRv) Yg[(unsigned)(row * 240 + ybase + col)] = fmaxf(u[r] + bv, 0.0f);
-                }
+                for (int g = 0; g < 4; ++g)
+                    if (nt * 32 + 8 * g < 48) {      // wave-uniform: 48 output channels = n-tile 0 and half of n-tile 1
+                        v4f o = {fmaxf(u[4 * g], 0.0f), fmaxf(u[4 * g + 1], 0.0f), fmaxf(u[4 * g + 2], 0.0f), fmaxf(u[4 * g + 3], 0.0f)};
+                        *(__attribute__((address_space(1))) v4f*)(Yg + (unsigned)(row * 240 + ybase + nt * 32 + 8 * g + h4)) = o;
+                    }
             }
         }
     };
 
     // ---- P2a
-    if (a1k) run_unit(a1k, a1m, a1n, ba1);
+    if (a1k) run_unit(a1k, a1m, a1n);
     if (a2k) {
         fused_unit_prefetch(unit_Bp(a2k), unit_taps(a2k), a2n, lane, pf);
-        run_unit(a2k, a2m, a2n, ba2);
+        run_unit(a2k, a2m, a2n);
     }
     // weights of the first P2b job are requested before the barrier
     float4 b5c[8];
@@ -958,32 +977,34 @@ __global__ __launch_bounds__(512, DS_FUSED_WPS) void inception_fused_kernel(cons
         // then relu(stem + tail)                                                         layers.py:132-138
 #pragma unroll
         for (int mt = 0; mt < TM; ++mt) {
-            const float* base = T2 + (mt * 32 + (lane & 31)) * F_LD2 + (lane >> 5) * 4;
+            const float* base = T2 + (mt * 32 + rlane) * F_LD2 + h4;
 #pragma unroll
             for (int g = 0; g < 8; ++g) {
                 const float4 av = *reinterpret_cast<const float4*>(base + g * 8);
-                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, b5c[g].x, acc[mt], 0, 0, 0);
-                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, b5c[g].y, acc[mt], 0, 0, 0);
-                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, b5c[g].z, acc[mt], 0, 0, 0);
-                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, b5c[g].w, acc[mt], 0, 0, 0);
+                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(b5c[g].x, av.x, acc[mt], 0, 0, 0);
+                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(b5c[g].y, av.y, acc[mt], 0, 0, 0);
+                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(b5c[g].z, av.z, acc[mt], 0, 0, 0);
+                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(b5c[g].w, av.w, acc[mt], 0, 0, 0);
             }
         }
-        const int col = wave * 32 + (lane & 31);
-        if (col < 48) {
-            const float bv = bias_p1 + bias_tail;
 #pragma unroll
-            for (int mt = 0; mt < TM; ++mt)
+        for (int mt = 0; mt < TM; ++mt) {
+            const int row = mt * 32 + rlane;
+            if (row < TRv) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = mt * 32 + rl + (r & 3) + 8 * (r >> 2);
-                    if (row < TRv) Yg[(unsigned)(row * 240 + 192 + col)] = fmaxf(acc[mt][r] + bv, 0.0f);
-                }
+                for (int g = 0; g < 4; ++g)
+                    if (wave * 32 + 8 * g < 48) {
+                        v4f o = {fmaxf(acc[mt][4 * g], 0.0f), fmaxf(acc[mt][4 * g + 1], 0.0f), fmaxf(acc[mt][4 * g + 2], 0.0f),
+                                 fmaxf(acc[mt][4 * g + 3], 0.0f)};
+                        *(__attribute__((address_space(1))) v4f*)(Yg + (unsigned)(row * 240 + 192 + wave * 32 + 8 * g + h4)) = o;
+                    }
+            }
         }
     } else {
-        if (b1k) run_unit(b1k, b1m, b1n, bb1);
+        if (b1k) run_unit(b1k, b1m, b1n);
         if (b2k) {
             fused_unit_prefetch(unit_Bp(b2k), unit_taps(b2k), b2n, lane, pf);
-            run_unit(b2k, b2m, b2n, bb2);
+            run_unit(b2k, b2m, b2n);
         }
     }
     DS_STAMP(7);
