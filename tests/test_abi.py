@@ -67,3 +67,25 @@ def test_invalid_variant_is_rejected(lib):
     rc = lib.ds_create(ctypes.byref(cfg), ctypes.byref(h))
     assert rc == -1 and not h.value
     assert b"at least one" in lib.ds_last_error(None)
+
+
+def test_header_is_plain_c99_and_client_links(tmp_path):
+    """The boundary is a C ABI: the public header must compile as C99 and a plain C client must link against the
+    library with nothing else on the command line (no HIP, no torch, no C++ runtime flags)."""
+    import shutil
+    import subprocess
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no gcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "hdr.c"
+    src.write_text('#include "deepsignal_hip.h"\nint main(void) { ds_config c; (void)c; return 0; }\n')
+    subprocess.run([gcc, "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-I",
+                    os.path.join(root, "include"), str(src)], check=True)
+    lib = os.path.join(root, "deepsignal_amd", "libdeepsignal_hip.so")
+    if not os.path.exists(lib):
+        pytest.skip("native library not built")
+    out = tmp_path / "abi_client"
+    subprocess.run([gcc, "-std=c99", "-Wall", "-O1", os.path.join(root, "tests", "abi_client.c"), "-o", str(out),
+                    "-L" + os.path.dirname(lib), "-ldeepsignal_hip", "-Wl,-rpath," + os.path.dirname(lib)], check=True)
+    assert out.exists()

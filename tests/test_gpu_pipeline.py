@@ -61,3 +61,39 @@ def test_call_mods_cli_1k_rows_batch32(small_weights, tmp_path):
         if abs(float(rc[7]) - float(rc[6])) > 1e-3:
             assert rg[8] == rc[8]
     assert [r[4] for r in g] == reads                                          # reads stay contiguous and ordered
+
+
+def test_plain_c_client_matches_python_engine(small_weights, tmp_path):
+    """tests/abi_client.c (C99, links only libdeepsignal_hip.so) must produce the Python binding's bits, through the
+    blocking call and through ds_submit / ds_wait."""
+    import os
+    import shutil
+    import subprocess
+    from deepsignal_amd.engine import Engine, LIB_PATH
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no gcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "abi_client")
+    subprocess.run([gcc, "-std=c99", "-O1", os.path.join(root, "tests", "abi_client.c"), "-o", exe,
+                    "-L" + os.path.dirname(LIB_PATH), "-ldeepsignal_hip", "-Wl,-rpath," + os.path.dirname(LIB_PATH)], check=True)
+    n = 150
+    feats = synth.synthetic_features(n, seed=99)
+    wfile, ffile, ofile = str(tmp_path / "m.dsw"), str(tmp_path / "f.bin"), str(tmp_path / "o.bin")
+    W.save_weights(wfile, small_weights)
+    with open(ffile, "wb") as f:
+        for k, dt in (("kmer", np.int32), ("means", np.float32), ("stds", np.float32), ("sanums", np.float32), ("signals", np.float32)):
+            f.write(np.ascontiguousarray(feats[k], dtype=dt).tobytes())
+    r = subprocess.run([exe, wfile, ffile, str(n), ofile], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    raw = np.fromfile(ofile, dtype=np.uint8)
+    act = raw[:n * 8].view(np.float32).reshape(n, 2)
+    pred = raw[n * 8:n * 12].view(np.int32)
+    act2 = raw[n * 12:n * 20].view(np.float32).reshape(n, 2)
+    pred2 = raw[n * 20:].view(np.int32)
+    eng = Engine(max_batch=64)
+    eng.load_weights(small_weights)
+    e_act, e_pred = eng.run(*(feats[k] for k in ("kmer", "means", "stds", "sanums", "signals")))
+    eng.close()
+    assert np.array_equal(act, e_act) and np.array_equal(pred, e_pred)
+    assert np.array_equal(act2, e_act) and np.array_equal(pred2, e_pred)
