@@ -1,0 +1,73 @@
+"""BASELINE configs[3]: per-read shard of 10 M synthetic sites over the GPUs of one node, RCCL gather of the results.
+
+    python tools/config4.py [--sites 10000000] [--batch 512] [--precision fp32]                      # 1 GPU
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 tools/config4.py   # 8 GPUs
+
+20 sites per read, reads dealt round-robin to the ranks (deepsignal_amd.sharding), every rank runs its shard through
+ds_forward_device in `batch`-site forwards from a resident pool of synthetic batches (the shard is far larger than the
+pool; features repeat, work does not), results stay on the device, and the run ends with ONE gather of
+f32[n_i,2] + i32[n_i] to rank 0. Strong scaling: total work is fixed. Prints one JSON line on rank 0."""
+import argparse, json, os, sys, time
+sys.path.insert(0, os.getcwd())
+import numpy as np
+import torch
+from deepsignal_amd import sharding, synth, weights as W
+from deepsignal_amd.engine import Engine
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--sites", type=int, default=10_000_000)
+ap.add_argument("--batch", type=int, default=512)
+ap.add_argument("--precision", default="fp32")
+args = ap.parse_args()
+rank, local, world = int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+dist = None
+if world > 1:
+    import torch.distributed as dist
+    torch.cuda.set_device(local)
+    dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+dev = torch.device("cuda", local)
+torch.cuda.set_device(dev)
+B = args.batch
+# shard by read: read r (sites 20r .. 20r+19) belongs to rank r % world
+nreads = args.sites // 20
+my_reads = np.arange(rank, nreads, world, dtype=np.int64)
+n_mine = int(my_reads.size) * 20
+eng = Engine(device=local, max_batch=B, precision=args.precision)
+eng.load_weights(W.random_weights(seed=W.WEIGHT_SEED))
+NPOOL = max(1, 4096 // B)
+f = synth.synthetic_features(NPOOL * B, seed=synth.FEATURE_SEED + rank)
+keys = ("kmer", "means", "stds", "sanums", "signals")
+d = {k: torch.from_numpy(f[k]).to(dev) for k in keys}
+nsteps = (n_mine + B - 1) // B
+out_act = torch.zeros((nsteps * B, 2), dtype=torch.float32, device=dev)
+out_pred = torch.zeros((nsteps * B,), dtype=torch.int32, device=dev)
+
+def step(i):
+    b = (i % NPOOL) * B
+    eng.run_device(B, *(d[k][b:b + B].data_ptr() for k in keys), out_act[i * B:].data_ptr(), out_pred[i * B:].data_ptr())
+
+for i in range(min(8, nsteps)): step(i)
+eng.sync(); torch.cuda.synchronize()
+if dist is not None: dist.barrier(); torch.cuda.synchronize()
+t0 = time.perf_counter()
+for i in range(nsteps): step(i)
+eng.sync()
+t_compute = time.perf_counter() - t0
+# global site index of my j-th site: read my_reads[j // 20], position j % 20
+gidx = (torch.from_numpy(my_reads).to(dev).repeat_interleave(20) * 20 + torch.arange(20, device=dev).repeat(my_reads.size))
+g_act, g_pred = sharding.gather_results(out_act[:n_mine], out_pred[:n_mine], gidx, dist, dst=0, device=dev, as_numpy=False)
+torch.cuda.synchronize()
+if dist is not None: dist.barrier()
+elapsed = time.perf_counter() - t0
+if dist is not None:
+    t = torch.tensor([elapsed, t_compute], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed, t_compute = float(t[0]), float(t[1])
+if rank == 0:
+    total = nreads * 20
+    if world > 1: assert g_act.shape[0] == total and bool(torch.isfinite(g_act).all())
+    print(json.dumps({"config": "configs[3]: per-read shard of %d synthetic sites, %d GPU(s), batch %d, %s" % (total, world, B, args.precision),
+                      "n_gpus": world, "sites": total, "seconds": round(elapsed, 3), "seconds_compute_max_rank": round(t_compute, 3),
+                      "sites_per_s": round(total / elapsed, 1), "gather_bytes": total * 12}))
+eng.close()
+if dist is not None: dist.destroy_process_group()
