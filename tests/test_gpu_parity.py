@@ -252,3 +252,30 @@ def test_submit_wait_matches_run(small_weights):
     with pytest.raises(RuntimeError):          # nothing in flight any more
         eng.wait((0, 8))
     eng.close()
+
+
+def test_config2_full_size_with_sampled_oracle_check():
+    """BASELINE configs[1] / SURVEY.md 8d "Config 2" at its full size: 512 x 200 sites in memory, benchmark weights,
+    fp32. The oracle (~1 k sites/s) checks a 2,048-site random sample; size-independent properties cover the rest:
+    finite outputs, probabilities in (0, 1), and a site's bits do not depend on where in the stream it sits."""
+    from deepsignal_amd import weights as W
+    from oracle import oracle
+    n = 512 * 200
+    w = W.random_weights(seed=W.WEIGHT_SEED)
+    feats = synth.synthetic_features(n, seed=synth.FEATURE_SEED)
+    keys = ("kmer", "means", "stds", "sanums", "signals")
+    eng = _engine(w, max_batch=512)
+    act, pred = eng.run(*(feats[k] for k in keys))
+    assert act.shape == (n, 2) and np.isfinite(act).all() and (act > 0).all() and (act < 1).all()
+    assert np.array_equal(pred, np.argmax(act, axis=1).astype(np.int32))
+    rng = np.random.default_rng(0)
+    sel = np.sort(rng.choice(n, 2048, replace=False))
+    sub = {k: v[sel] for k, v in feats.items()}
+    o_act, o_pred = oracle.forward(w, sub, "f32")
+    pn = _norm(act[sel]), _norm(o_act)
+    assert np.abs(pn[0] - pn[1]).max() <= 1e-4            # the north-star gate; measured ~4e-7
+    _check_outputs(act[sel], pred[sel], o_act, o_pred)
+    # the same sites, re-run as one odd-sized batch elsewhere in the stream: identical bits
+    a2, p2 = eng.run(*(feats[k][sel[:300]] for k in keys))
+    assert np.array_equal(a2, act[sel[:300]]) and np.array_equal(p2, pred[sel[:300]])
+    eng.close()
