@@ -97,3 +97,31 @@ def test_plain_c_client_matches_python_engine(small_weights, tmp_path):
     eng.close()
     assert np.array_equal(act, e_act) and np.array_equal(pred, e_pred)
     assert np.array_equal(act2, e_act) and np.array_equal(pred2, e_pred)
+
+
+def test_cli_accepts_a_tf_checkpoint_prefix_and_precision(small_weights, tmp_path):
+    """`--model_path` is a TensorFlow checkpoint prefix in the reference (call_modifications.py:210-211): the CLI must
+    take one as is (plus Adam slots it has to ignore) and give the bytes it gives for the flat weight file; and
+    `--precision bf16_all` must stay within the documented distance of fp32."""
+    from deepsignal_amd import tf_checkpoint
+    from deepsignal_amd.deepsignal import main
+    n = 400
+    feats = synth.synthetic_features(n, seed=11)
+    reads = ["read_%04d" % (i // 20) for i in range(n)]
+    tsv = str(tmp_path / "features.tsv")
+    _write_feature_tsv(tsv, feats, reads)
+    dsw, ckpt = str(tmp_path / "model.dsw"), str(tmp_path / "bn_17.sn_360.epoch_7.ckpt")
+    W.save_weights(dsw, small_weights)
+    tensors = dict(small_weights)
+    tensors["dense/kernel/Adam"] = np.zeros_like(small_weights["dense/kernel"])
+    tensors["beta1_power"] = np.array(0.9, np.float32)
+    tf_checkpoint.write_checkpoint(ckpt, tensors)
+    outs = {}
+    for tag, model, extra in (("dsw", dsw, []), ("ckpt", ckpt, []), ("bf16", ckpt, ["--precision", "bf16_all"])):
+        outs[tag] = str(tmp_path / (tag + ".tsv"))
+        assert main(["call_mods", "-i", tsv, "-m", model, "-o", outs[tag], "-b", "128"] + extra) == 0
+    a, b = open(outs["dsw"], "rb").read(), open(outs["ckpt"], "rb").read()
+    assert a == b and a.count(b"\n") == n
+    p32 = np.array([[float(x) for x in l.split("\t")[6:8]] for l in open(outs["dsw"])])
+    p16 = np.array([[float(x) for x in l.split("\t")[6:8]] for l in open(outs["bf16"])])
+    assert np.abs(p32 - p16).max() <= 5e-3 and np.abs(p16.sum(axis=1) - 1.0).max() <= 1e-6
