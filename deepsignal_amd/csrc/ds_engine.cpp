@@ -67,7 +67,7 @@ struct Op {
 
 // per-kernel accumulators (one entry per __global__ function / template instantiation)
 enum KernelClass { K_GEMM_CONV = 0, K_GEMM_FC, K_GEMM_LSTM, K_GEMM_CONV_WIDE, K_GEMM_CONV_POOL, K_GEMM_FC_DENSE, K_GEMM_LSTM_DENSE, K_FUSED1, K_FUSED2, K_FUSED3, K_STEM1, K_MAXPOOL, K_AVGPOOL, K_HEAD,
-                   K_GEMM_BCONV, K_GEMM_BCONV_POOL, K_GEMM_BFC, K_GEMM_BFC_DENSE, K_PACKEV, K_GEMM_BLSTM, K_GEMM_BLSTM_DENSE, K_FUSEDB1, K_FUSEDB2, K_FUSEDB3, K_COUNT };
+                   K_GEMM_BCONV, K_GEMM_BCONV_POOL, K_GEMM_BFC, K_GEMM_BFC_DENSE, K_PACKEV, K_GEMM_BLSTM, K_GEMM_BLSTM_DENSE, K_FUSEDB1, K_FUSEDB2, K_FUSEDB3, K_GEMM_LSTM_T, K_GEMM_LSTM_T_DENSE, K_GEMM_BLSTM_T, K_GEMM_BLSTM_T_DENSE, K_COUNT };
 const char* const kKernelNames[K_COUNT] = {"gemm_kernel<1,2,4,1,0,0,1,1>", "gemm_kernel<1,3,4,1,0,0,2,1>", "gemm_kernel<1,4,4,1,1,0,1,1>",
                                            "gemm_kernel<2,2,2,2,0,0,1,1>", "gemm_kernel<1,2,4,1,0,1,1,1>", "gemm_kernel<1,3,4,1,0,2,2,1>",
                                            "gemm_kernel<1,4,4,1,1,2,1,1>", "inception_fused_kernel<1>",
@@ -77,7 +77,9 @@ const char* const kKernelNames[K_COUNT] = {"gemm_kernel<1,2,4,1,0,0,1,1>", "gemm
                                            "gemm_kernel<4,2,1,4,0,0,2,1,bf16>", "gemm_kernel<4,2,1,4,0,2,2,1,bf16>",
                                            "pack_event_feat_bf16_kernel", "gemm_kernel<1,4,4,1,1,0,3,1,bf16>",
                                            "gemm_kernel<1,4,4,1,1,2,3,1,bf16>", "inception_fused_bf16_kernel<1>",
-                                           "inception_fused_bf16_kernel<2>", "inception_fused_bf16_kernel<3>"};
+                                           "inception_fused_bf16_kernel<2>", "inception_fused_bf16_kernel<3>",
+                                           "gemm_kernel<1,1,4,1,2,0,1,1>", "gemm_kernel<1,1,4,1,2,2,1,1>",
+                                           "gemm_kernel<1,1,4,1,2,0,3,1,bf16>", "gemm_kernel<1,1,4,1,2,2,3,1,bf16>"};
 struct KernelStat {
     int64_t launches = 0;
     double total_ms = 0;
@@ -139,6 +141,7 @@ struct ds_handle {
     int B = 512;
     bool is_cnn = true, is_rnn = true, is_base = true;   // model.py:28-29,59-75,89-95
     bool bf16 = false;    // DS_PRECISION_BF16: bf16 conv + FC operands (fp32 accumulate), fp32 BiLSTM
+    bool lstm_t = false;      // fp32 LSTM cells on 128 x 32 tiles (CFG_LSTM_T): weights packed [gate][8 units] per n-tile
     bool lstm_bf16 = false;   // DS_PRECISION_BF16_ALL: additionally bf16 h / weight operands in the LSTM matmuls (fp32 accumulate,
                               // gates and cell state; the layer-0 input projection stays an fp32 table lookup)
     int JP = 0;           // J rounded up to a whole K chunk (32 bf16)
@@ -395,10 +398,17 @@ int finalize_weights(ds_handle* h)
             const int row0 = l == 0 ? in0 : 0;
             const int K = l == 0 ? HID : 2 * HID;
             // packed n-tile p = ug*4 + g  <->  TF columns g*256 + ug*32 + [0,32)
-            auto wfun = [&](int k, int pc) {
+            auto wfun_wide = [&](int k, int pc) {
                 const int p = pc / 32, j = pc % 32, ug = p / 4, g = p % 4;
                 return kd[(size_t)(row0 + k) * 4 * HID + g * HID + ug * 32 + j];
             };
+            // CFG_LSTM_T: n-tile p holds units 8p..8p+7, column i of the tile = gate (i >> 3) of unit 8p + (i & 7)
+            auto wfun_t = [&](int k, int pc) {
+                const int p = pc / 32, i = pc % 32;
+                return kd[(size_t)(row0 + k) * 4 * HID + (i >> 3) * HID + p * 8 + (i & 7)];
+            };
+            std::function<float(int, int)> wfun = wfun_wide;
+            if (h->lstm_t) wfun = wfun_t;
             std::vector<float> packed = h->lstm_bf16 ? pack_b_bf16(K, 4 * HID, wfun) : pack_b(K, 4 * HID, wfun);
             h->lstm[d][l].K = h->lstm_bf16 ? K / 2 : K; h->lstm[d][l].N = 4 * HID;
             if ((rc = upload(h, &h->lstm[d][l].Bp, packed))) return rc;
@@ -487,6 +497,8 @@ void add_tiles(GemmLaunch& L, GemmProblem& P, GemmCfg cfg, const float* zero16)
     P.tiles_n = (P.N + g.bn - 1) / g.bn;
     P.ntiles32 = (P.N + 31) / 32;
     P.n_fast = (double)P.M > (double)P.N ? 1 : 0;      // A bytes (M*K) vs B bytes (K*N)
+    if (cfg == CFG_LSTM_T || cfg == CFG_LSTM_T_DENSE || cfg == CFG_BLSTM_T || cfg == CFG_BLSTM_T_DENSE)
+        P.n_fast = 1;                                   // 128 x 32 tiles: the activation tile is the big operand
     P.tile_start = L.total_tiles;
     L.total_tiles += P.tiles_m * P.tiles_n;
     L.prob[L.nprob++] = P;
@@ -540,7 +552,8 @@ int build_plan(ds_handle* h, int n, Plan* plan)
         Op op{};
         op.kind = OP_GEMM; op.stream = stream; op.stage = stage; op.cfg = cfg;
         op.launch_index = (int)LS.size(); op.total_tiles = L.total_tiles;
-        const double kelems = (cfg >= CFG_BCONV ? 2.0 : 1.0) * kscale;        // bf16 problems count K in units; kscale removes zero pad
+        const bool bf_cfg = (cfg >= CFG_BCONV && cfg <= CFG_BLSTM_DENSE) || cfg == CFG_BLSTM_T || cfg == CFG_BLSTM_T_DENSE;
+        const double kelems = (bf_cfg ? 2.0 : 1.0) * kscale;   // bf16 problems count K in units; kscale removes zero pad
         for (int i = 0; i < L.nprob; ++i) op.flops += 2.0 * L.prob[i].M * (double)L.prob[i].N * L.prob[i].K * kelems;
         LS.push_back(L);
         list.push_back(op);
@@ -695,7 +708,9 @@ int build_plan(ds_handle* h, int n, Plan* plan)
     const int T = h->T;
     // dense variants skip the per-row validity selects; legal when every tile row is a real site
     const bool lbf = h->lstm_bf16;
-    const GemmCfg lstm_cfg = lbf ? (n % 128 == 0 ? CFG_BLSTM_DENSE : CFG_BLSTM) : (n % 128 == 0 ? CFG_LSTM_DENSE : CFG_LSTM);
+    const bool dense = n % 128 == 0;
+    const GemmCfg lstm_cfg = lbf ? (h->lstm_t ? (dense ? CFG_BLSTM_T_DENSE : CFG_BLSTM_T) : (dense ? CFG_BLSTM_DENSE : CFG_BLSTM))
+                                 : (h->lstm_t ? (dense ? CFG_LSTM_T_DENSE : CFG_LSTM_T) : (dense ? CFG_LSTM_DENSE : CFG_LSTM));
     const int HU = lbf ? HID / 2 : HID;                 // row pitch / K of an h operand in 4-byte units
     auto hptr = [&](int dir, int l, int t) {            // h(dir, l, t): [n][256] fp32, or bf16 when lbf
         return h->cur->H[dir][l] + (size_t)t * h->B * HU;
@@ -879,7 +894,9 @@ int kernel_class(const Op& op)
                : op.cfg == CFG_LSTM_DENSE ? K_GEMM_LSTM_DENSE : op.cfg == CFG_BCONV ? K_GEMM_BCONV
                : op.cfg == CFG_BCONV_POOL ? K_GEMM_BCONV_POOL : op.cfg == CFG_BFC ? K_GEMM_BFC
                : op.cfg == CFG_BFC_DENSE ? K_GEMM_BFC_DENSE : op.cfg == CFG_BLSTM ? K_GEMM_BLSTM
-               : op.cfg == CFG_BLSTM_DENSE ? K_GEMM_BLSTM_DENSE : K_GEMM_CONV_WIDE;
+               : op.cfg == CFG_BLSTM_DENSE ? K_GEMM_BLSTM_DENSE : op.cfg == CFG_LSTM_T ? K_GEMM_LSTM_T
+               : op.cfg == CFG_LSTM_T_DENSE ? K_GEMM_LSTM_T_DENSE : op.cfg == CFG_BLSTM_T ? K_GEMM_BLSTM_T
+               : op.cfg == CFG_BLSTM_T_DENSE ? K_GEMM_BLSTM_T_DENSE : K_GEMM_CONV_WIDE;
     case OP_FUSED:
         if (op.fa.cin == 128) return op.tm == 1 ? K_FUSEDB1 : op.tm == 2 ? K_FUSEDB2 : K_FUSEDB3;   // bf16 rows: pitch in units
         return op.tm == 1 ? K_FUSED1 : op.tm == 2 ? K_FUSED2 : K_FUSED3;
@@ -997,6 +1014,11 @@ int ds_create(const ds_config* cfg, ds_handle** out)
     h->J = (h->is_rnn ? 2 * HID : 0) + (h->is_cnn ? h->SF : 0);     // layers.py:248-255
     h->bf16 = cfg->precision == DS_PRECISION_BF16 || cfg->precision == DS_PRECISION_BF16_ALL;
     h->lstm_bf16 = cfg->precision == DS_PRECISION_BF16_ALL && h->is_rnn;
+    // narrow LSTM tiles pay when the 128 x 128 tiling cannot fill the GPU (a full diagonal has 6 * (B/128) * 8 workgroups)
+    // (DS_LSTM_T = 0 / 1 overrides the choice; diagnostic)
+    // Measured (MI355X): fp32 cells gain 2.5 % end to end at 512 sites per forward (+10 % when the convolutions run in
+    // bf16) and 36 % at 128, lose 3 % at >= 1024 (4x the activation traffic); bf16 cells are a wash, so they stay wide.
+    h->lstm_t = h->is_rnn && (getenv("DS_LSTM_T") ? atoi(getenv("DS_LSTM_T")) != 0 : (h->B <= 512 && !h->lstm_bf16));
     h->JP = (h->J + 31) / 32 * 32;
     h->debug = cfg->reserved[0] != 0;
 #define CK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { fail(nullptr, DS_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); ds_destroy(h); return DS_ERR_HIP; } } while (0)

@@ -74,7 +74,9 @@ struct GemmLaunch {
 
 enum GemmCfg { CFG_CONV = 0, CFG_FC = 1, CFG_LSTM = 2, CFG_CONV_WIDE = 3, CFG_CONV_POOL = 4, CFG_FC_DENSE = 5, CFG_LSTM_DENSE = 6,
                // bf16-operand variants (mixed-precision mode)
-               CFG_BCONV = 7, CFG_BCONV_POOL = 8, CFG_BFC = 9, CFG_BFC_DENSE = 10, CFG_BLSTM = 11, CFG_BLSTM_DENSE = 12 };
+               CFG_BCONV = 7, CFG_BCONV_POOL = 8, CFG_BFC = 9, CFG_BFC_DENSE = 10, CFG_BLSTM = 11, CFG_BLSTM_DENSE = 12,
+               // fp32 LSTM cell on 128 x 32 tiles (transposed MFMA, [gate][8 units] column order inside a tile)
+               CFG_LSTM_T = 13, CFG_LSTM_T_DENSE = 14, CFG_BLSTM_T = 15, CFG_BLSTM_T_DENSE = 16 };
 
 // tile geometry per config (host needs it for grid sizing)
 struct TileGeom { int bm, bn, threads, ksplit; };

@@ -87,7 +87,7 @@ __device__ __forceinline__ float bf2f(unsigned short b) { return __uint_as_float
 // accumulators are exchanged through LDS at the end. It doubles the waves per SIMD for grids that
 // only have ~one workgroup per CU and halves the serial chunk chain of short-K problems.
 template <int MT, int NT, int WM, int WN, int EPI, int AMODE, int BD, int KS, bool BF = false>
-__global__ __launch_bounds__(64 * WM * WN * KS, (EPI == 1 && KS == 1) ? 2 : 1) void gemm_kernel(const GemmLaunch* __restrict__ L)
+__global__ __launch_bounds__(64 * WM * WN * KS, EPI == 2 ? 3 : (EPI == 1 && KS == 1) ? 2 : 1) void gemm_kernel(const GemmLaunch* __restrict__ L)
 {
     constexpr int BM = WM * MT * 32;
     constexpr int LDA = KC + 4;
@@ -271,8 +271,19 @@ __global__ __launch_bounds__(64 * WM * WN * KS, (EPI == 1 && KS == 1) ? 2 : 1) v
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 if (BF) {
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[X][rs][mt]),
-                                                                          __builtin_bit_cast(bf16x8, bq[J][nt][rs]), acc[mt][nt], 0, 0, 0);
+                    if (EPI == 2)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bq[J][nt][rs]),
+                                                                              __builtin_bit_cast(bf16x8, af[X][rs][mt]), acc[mt][nt], 0, 0, 0);
+                    else
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[X][rs][mt]),
+                                                                              __builtin_bit_cast(bf16x8, bq[J][nt][rs]), acc[mt][nt], 0, 0, 0);
+                    continue;
+                }
+                if (EPI == 2) {      // transposed product (X W)^T: a lane holds one row and 16 of the tile's columns
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(bq[J][nt][rs].x, af[X][rs][mt].x, acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(bq[J][nt][rs].y, af[X][rs][mt].y, acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(bq[J][nt][rs].z, af[X][rs][mt].z, acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(bq[J][nt][rs].w, af[X][rs][mt].w, acc[mt][nt], 0, 0, 0);
                     continue;
                 }
                 acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[X][rs][mt].x, bq[J][nt][rs].x, acc[mt][nt], 0, 0, 0);
@@ -497,6 +508,64 @@ __global__ __launch_bounds__(64 * WM * WN * KS, (EPI == 1 && KS == 1) ? 2 : 1) v
                     }
                 }
         }
+    } else if (EPI == 2) {
+        // LSTM cell on 128 x 32 tiles (MT = NT = 1): the 32 columns of n-tile p are [gate 0..3][8 units] of units
+        // 8p .. 8p+7 (weights packed so) and the product is transposed, so register 4g+e of a lane is gate g of unit
+        // 8p + 4*(lane >> 5) + e for ONE site (lane & 31): all four gates of four neighbouring units sit in one lane,
+        // and c / h / bias / table rows move as float4. Same arithmetic (and rounding) as the 128 x 128 variant; the
+        // point of the narrow tile is occupancy: 768 workgroups per full diagonal at 512 sites, three per CU.
+        const LstmEp E = P.lstm;
+        const int p8 = (tn * WN + wn) * 8 + 4 * (lane >> 5);            // first of this lane's four units
+        const int row = m0 + wm * 32 + (lane & 31);
+        if (nvalid[0] && (AMODE == 2 || row < M)) {
+            const bool has_table = E.table != nullptr, has_feat = E.use_feat != 0;
+            float4 z[4];                                                 // z[g] = pre-activations of gate g, units p8..p8+3
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float4 b = gload4(P.bias + g * 256 + p8);
+                if (g == 2) { b.x += 1.0f; b.y += 1.0f; b.z += 1.0f; b.w += 1.0f; }     // forget_bias folded into the bias, as in EPI 1
+                z[g] = make_float4(acc[0][0][4 * g] + b.x, acc[0][0][4 * g + 1] + b.y, acc[0][0][4 * g + 2] + b.z, acc[0][0][4 * g + 3] + b.w);
+            }
+            if (has_feat) {
+                const unsigned it = (unsigned)row * E.T + E.t;
+                const float f0 = gload(E.means + it), f1 = gload(E.stds + it), f2 = gload(E.lens + it);
+                const int code = has_table ? *(const __attribute__((address_space(1))) int*)(E.codes + it) : 0;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float4 w0 = gload4(E.wfeat + g * 256 + p8), w1 = gload4(E.wfeat + 1024 + g * 256 + p8),
+                                 w2 = gload4(E.wfeat + 2048 + g * 256 + p8);
+                    float4 x = make_float4(fmaf(f2, w2.x, fmaf(f1, w1.x, f0 * w0.x)), fmaf(f2, w2.y, fmaf(f1, w1.y, f0 * w0.y)),
+                                           fmaf(f2, w2.z, fmaf(f1, w1.z, f0 * w0.z)), fmaf(f2, w2.w, fmaf(f1, w1.w, f0 * w0.w)));
+                    if (has_table) {
+                        const float4 tb = gload4(E.table + (size_t)code * 1024 + g * 256 + p8);
+                        x.x += tb.x; x.y += tb.y; x.z += tb.z; x.w += tb.w;
+                    }
+                    z[g].x += x.x; z[g].y += x.y; z[g].z += x.z; z[g].w += x.w;
+                }
+            }
+            const size_t off = (size_t)row * 256 + p8;
+            float4 cp = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (!E.c_zero) cp = gload4(E.c + off);
+            float4 cn, hn;
+            cn.x = fmaf(fast_sigmoid(z[2].x), cp.x, fast_sigmoid(z[0].x) * fast_tanh(z[1].x));
+            cn.y = fmaf(fast_sigmoid(z[2].y), cp.y, fast_sigmoid(z[0].y) * fast_tanh(z[1].y));
+            cn.z = fmaf(fast_sigmoid(z[2].z), cp.z, fast_sigmoid(z[0].z) * fast_tanh(z[1].z));
+            cn.w = fmaf(fast_sigmoid(z[2].w), cp.w, fast_sigmoid(z[0].w) * fast_tanh(z[1].w));
+            hn.x = fast_sigmoid(z[3].x) * fast_tanh(cn.x);
+            hn.y = fast_sigmoid(z[3].y) * fast_tanh(cn.y);
+            hn.z = fast_sigmoid(z[3].z) * fast_tanh(cn.z);
+            hn.w = fast_sigmoid(z[3].w) * fast_tanh(cn.w);
+            v4f co = {cn.x, cn.y, cn.z, cn.w};
+            *(__attribute__((address_space(1))) v4f*)(E.c + off) = co;
+            if (BF) {
+                typedef unsigned int u2v __attribute__((ext_vector_type(2)));
+                const u2v ho = {(unsigned)f2bf(hn.x) | ((unsigned)f2bf(hn.y) << 16), (unsigned)f2bf(hn.z) | ((unsigned)f2bf(hn.w) << 16)};
+                *(__attribute__((address_space(1))) u2v*)(reinterpret_cast<unsigned short*>(E.h_out) + off) = ho;
+            } else {
+                v4f ho = {hn.x, hn.y, hn.z, hn.w};
+                *(__attribute__((address_space(1))) v4f*)(E.h_out + off) = ho;
+            }
+        }
     } else {
         // NT == 4: the wave's four n-tiles are gates i,j,f,o of unit group ug (weights packed so).
         // Uniform (SGPR) base pointers + 32-bit per-lane offsets keep the address math off the VALU;
@@ -597,6 +666,10 @@ TileGeom gemm_geom(GemmCfg cfg)
     case CFG_BFC_DENSE: return {128, 256, 256, 1};  // weight fragment is loaded by exactly one wave of the workgroup
     case CFG_BLSTM: return {128, 128, 256, 1};      // CFG_LSTM with bf16 h / weight operands (fp32 accumulate, gates, cell state)
     case CFG_BLSTM_DENSE: return {128, 128, 256, 1};
+    case CFG_LSTM_T: return {128, 32, 256, 1};      // transposed, unit-major LSTM cell: MT1 NT1 WM4 WN1
+    case CFG_LSTM_T_DENSE: return {128, 32, 256, 1};
+    case CFG_BLSTM_T: return {128, 32, 256, 1};     // the same with bf16 h / weight operands
+    case CFG_BLSTM_T_DENSE: return {128, 32, 256, 1};
     }
     return {0, 0, 0, 1};
 }
@@ -618,6 +691,10 @@ hipError_t launch_gemm(GemmCfg cfg, const GemmLaunch* d_launch, int total_tiles,
     case CFG_BFC_DENSE: hipLaunchKernelGGL((gemm_kernel<4, 2, 1, 4, 0, 2, 2, 1, true>), dim3(total_tiles), dim3(256), 0, s, d_launch); break;
     case CFG_BLSTM: hipLaunchKernelGGL((gemm_kernel<1, 4, 4, 1, 1, 0, 3, 1, true>), dim3(total_tiles), dim3(256), 0, s, d_launch); break;
     case CFG_BLSTM_DENSE: hipLaunchKernelGGL((gemm_kernel<1, 4, 4, 1, 1, 2, 3, 1, true>), dim3(total_tiles), dim3(256), 0, s, d_launch); break;
+    case CFG_LSTM_T: hipLaunchKernelGGL((gemm_kernel<1, 1, 4, 1, 2, 0, 1, 1>), dim3(total_tiles), dim3(256), 0, s, d_launch); break;
+    case CFG_LSTM_T_DENSE: hipLaunchKernelGGL((gemm_kernel<1, 1, 4, 1, 2, 2, 1, 1>), dim3(total_tiles), dim3(256), 0, s, d_launch); break;
+    case CFG_BLSTM_T: hipLaunchKernelGGL((gemm_kernel<1, 1, 4, 1, 2, 0, 3, 1, true>), dim3(total_tiles), dim3(256), 0, s, d_launch); break;
+    case CFG_BLSTM_T_DENSE: hipLaunchKernelGGL((gemm_kernel<1, 1, 4, 1, 2, 2, 3, 1, true>), dim3(total_tiles), dim3(256), 0, s, d_launch); break;
     }
     return hipGetLastError();
 }
