@@ -603,13 +603,16 @@ int build_plan(ds_handle* h, int n, Plan* plan)
         float* y = h->cur->modout[m];
         static const bool no_fused = getenv("DS_NO_FUSED") != nullptr;
         if (!no_fused && W <= 96) {
-            // one fused launch per module; tile = spt whole sites (<= 96 rows). Pick the spt that
-            // minimises padded rows while keeping >= 256 workgroups when the batch allows it.
+            // one fused launch per module; tile = spt whole sites (<= 96 rows). Pick the spt that minimises padded
+            // rows (= matrix-pipe time) while keeping >= 128 workgroups when the batch allows it: with several
+            // forwards in flight the CUs a short grid leaves idle are taken by other kernels, so fewer, fuller
+            // tiles win (W = 23 at 512 sites: 128 tiles of 92/96 rows instead of 512 tiles of 23/32 rows, +2 %).
             int best_spt = 1; long best_rows = -1;
             static const int max_spt = getenv("DS_FUSE_MAX_SPT") ? atoi(getenv("DS_FUSE_MAX_SPT")) : 8;   // tuning knob
             for (int spt = 1; spt * W <= 96 && spt <= max_spt; ++spt) {
                 const int tiles = (n + spt - 1) / spt;
-                if (spt > 1 && tiles < std::min(256, n)) break;
+                static const int min_tiles = getenv("DS_FUSE_MIN_TILES") ? atoi(getenv("DS_FUSE_MIN_TILES")) : 128;   // tuning knob
+                if (spt > 1 && tiles < std::min(min_tiles, n)) break;
                 const long rows = (long)tiles * ((spt * W + 31) / 32) * 32;
                 if (best_rows < 0 || rows < best_rows) { best_rows = rows; best_spt = spt; }
             }
