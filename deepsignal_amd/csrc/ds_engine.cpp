@@ -141,7 +141,7 @@ struct ds_handle {
     int B = 512;
     bool is_cnn = true, is_rnn = true, is_base = true;   // model.py:28-29,59-75,89-95
     bool bf16 = false;    // DS_PRECISION_BF16: bf16 conv + FC operands (fp32 accumulate), fp32 BiLSTM
-    bool lstm_t = false;      // fp32 LSTM cells on 128 x 32 tiles (CFG_LSTM_T): weights packed [gate][8 units] per n-tile
+    int lstm_t = -1;          // LSTM cell tiling: 1 = always 128 x 32 (CFG_*LSTM_T), 0 = always 128 x 128, -1 = by forward size
     bool lstm_bf16 = false;   // DS_PRECISION_BF16_ALL: additionally bf16 h / weight operands in the LSTM matmuls (fp32 accumulate,
                               // gates and cell state; the layer-0 input projection stays an fp32 table lookup)
     int JP = 0;           // J rounded up to a whole K chunk (32 bf16)
@@ -159,6 +159,7 @@ struct ds_handle {
     PackedGemm m_f1[NMOD];   // fused-module stage 1: [b5s|b2|b3a|b4a|b5a|b1]
     PackedGemm m_s1[NMOD], m_b1[NMOD], m_b3b[NMOD], m_b4b[NMOD], m_b5b[NMOD], m_b5c[NMOD];
     PackedGemm lstm[2][NLAYER];
+    PackedGemm lstm_n[2][NLAYER];   // the same cells packed for the 128 x 32 tiling ([gate][8 units] columns per n-tile)
     float* lstm_table[2] = {nullptr, nullptr};
     float* lstm_wfeat[2] = {nullptr, nullptr};
     PackedGemm fc1;
@@ -407,12 +408,17 @@ int finalize_weights(ds_handle* h)
                 const int p = pc / 32, i = pc % 32;
                 return kd[(size_t)(row0 + k) * 4 * HID + (i >> 3) * HID + p * 8 + (i & 7)];
             };
-            std::function<float(int, int)> wfun = wfun_wide;
-            if (h->lstm_t) wfun = wfun_t;
-            std::vector<float> packed = h->lstm_bf16 ? pack_b_bf16(K, 4 * HID, wfun) : pack_b(K, 4 * HID, wfun);
-            h->lstm[d][l].K = h->lstm_bf16 ? K / 2 : K; h->lstm[d][l].N = 4 * HID;
-            if ((rc = upload(h, &h->lstm[d][l].Bp, packed))) return rc;
-            if ((rc = upload(h, &h->lstm[d][l].bias, bias->data))) return rc;
+            // both layouts are kept (2 x 11.6 MB fp32): the planner picks the tiling per forward size
+            for (int layout = 0; layout < 2; ++layout) {
+                PackedGemm& pg = layout == 0 ? h->lstm[d][l] : h->lstm_n[d][l];
+                std::function<float(int, int)> wfun = wfun_wide;
+                if (layout == 1) wfun = wfun_t;
+                std::vector<float> packed = h->lstm_bf16 ? pack_b_bf16(K, 4 * HID, wfun) : pack_b(K, 4 * HID, wfun);
+                pg.K = h->lstm_bf16 ? K / 2 : K; pg.N = 4 * HID;
+                if ((rc = upload(h, &pg.Bp, packed))) return rc;
+                if (layout == 0) { if ((rc = upload(h, &pg.bias, bias->data))) return rc; }
+                else pg.bias = h->lstm[d][l].bias;
+            }
             if (l == 0) {
                 if (h->is_base) {
                     // embedding folded into W_x: table[v] = emb[v] @ kernel[0:128]   (model.py:61-69)
@@ -712,8 +718,12 @@ int build_plan(ds_handle* h, int n, Plan* plan)
     // dense variants skip the per-row validity selects; legal when every tile row is a real site
     const bool lbf = h->lstm_bf16;
     const bool dense = n % 128 == 0;
-    const GemmCfg lstm_cfg = lbf ? (h->lstm_t ? (dense ? CFG_BLSTM_T_DENSE : CFG_BLSTM_T) : (dense ? CFG_BLSTM_DENSE : CFG_BLSTM))
-                                 : (h->lstm_t ? (dense ? CFG_LSTM_T_DENSE : CFG_LSTM_T) : (dense ? CFG_LSTM_DENSE : CFG_LSTM));
+    // Narrow (128 x 32) LSTM tiles pay when the 128 x 128 tiling cannot fill the GPU: measured on MI355X, fp32 cells
+    // gain 2.5 % end to end at 512 sites per forward (+10 % when the convolutions run in bf16) and 36 % at 128, lose
+    // 3 % at >= 1024 (4x the activation traffic); bf16 cells are a wash, so they stay wide. DS_LSTM_T=0/1 forces one.
+    const bool narrow = h->lstm_t >= 0 ? h->lstm_t != 0 : (n <= 512 && !lbf);
+    const GemmCfg lstm_cfg = lbf ? (narrow ? (dense ? CFG_BLSTM_T_DENSE : CFG_BLSTM_T) : (dense ? CFG_BLSTM_DENSE : CFG_BLSTM))
+                                 : (narrow ? (dense ? CFG_LSTM_T_DENSE : CFG_LSTM_T) : (dense ? CFG_LSTM_DENSE : CFG_LSTM));
     const int HU = lbf ? HID / 2 : HID;                 // row pitch / K of an h operand in 4-byte units
     auto hptr = [&](int dir, int l, int t) {            // h(dir, l, t): [n][256] fp32, or bf16 when lbf
         return h->cur->H[dir][l] + (size_t)t * h->B * HU;
@@ -727,7 +737,7 @@ int build_plan(ds_handle* h, int n, Plan* plan)
                 if (s < 0 || s >= T) continue;
                 const int t = dir == 0 ? s : T - 1 - s;
                 const int tprev = dir == 0 ? t - 1 : t + 1;
-                GemmProblem P = base_problem(n, 4 * HID, n, h->lstm[dir][l]);
+                GemmProblem P = base_problem(n, 4 * HID, n, narrow ? h->lstm_n[dir][l] : h->lstm[dir][l]);
                 if (l > 0) add_seg(P, hptr(dir, l - 1, t), HU, 0, HU);
                 if (s > 0) add_seg(P, hptr(dir, l, tprev), HU, 0, HU);
                 P.lstm.table = l == 0 ? h->lstm_table[dir] : nullptr;
@@ -1017,11 +1027,7 @@ int ds_create(const ds_config* cfg, ds_handle** out)
     h->J = (h->is_rnn ? 2 * HID : 0) + (h->is_cnn ? h->SF : 0);     // layers.py:248-255
     h->bf16 = cfg->precision == DS_PRECISION_BF16 || cfg->precision == DS_PRECISION_BF16_ALL;
     h->lstm_bf16 = cfg->precision == DS_PRECISION_BF16_ALL && h->is_rnn;
-    // narrow LSTM tiles pay when the 128 x 128 tiling cannot fill the GPU (a full diagonal has 6 * (B/128) * 8 workgroups)
-    // (DS_LSTM_T = 0 / 1 overrides the choice; diagnostic)
-    // Measured (MI355X): fp32 cells gain 2.5 % end to end at 512 sites per forward (+10 % when the convolutions run in
-    // bf16) and 36 % at 128, lose 3 % at >= 1024 (4x the activation traffic); bf16 cells are a wash, so they stay wide.
-    h->lstm_t = h->is_rnn && (getenv("DS_LSTM_T") ? atoi(getenv("DS_LSTM_T")) != 0 : (h->B <= 512 && !h->lstm_bf16));
+    h->lstm_t = getenv("DS_LSTM_T") ? (atoi(getenv("DS_LSTM_T")) != 0 ? 1 : 0) : -1;     // diagnostic override of the LSTM tiling
     h->JP = (h->J + 31) / 32 * 32;
     h->debug = cfg->reserved[0] != 0;
 #define CK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { fail(nullptr, DS_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); ds_destroy(h); return DS_ERR_HIP; } } while (0)

@@ -282,8 +282,8 @@ def test_config2_full_size_with_sampled_oracle_check():
 
 
 def test_narrow_and_wide_lstm_tilings_give_the_same_bits(small_weights, monkeypatch):
-    """The BiLSTM cells run on 128 x 32 tiles (transposed MFMA, [gate][8 units] column order) for max_batch <= 512 and
-    on 128 x 128 tiles otherwise; both accumulate K in the same order and round the gate math identically."""
+    """The BiLSTM cells run on 128 x 32 tiles (transposed MFMA, [gate][8 units] column order) for forwards of <= 512
+    sites and on 128 x 128 tiles otherwise; both accumulate K in the same order and round the gate math identically."""
     feats = synth.synthetic_features(200, seed=44)
     keys = ("kmer", "means", "stds", "sanums", "signals")
     outs = {}
