@@ -1184,6 +1184,37 @@ int ds_forward(ds_handle* h, int32_t n, const int32_t* kmer, const float* means,
     if (n == 0) return DS_OK;
     if (!kmer || !means || !stds || !sanums || !signals || !act || !pred) return fail(h, DS_ERR_INVALID, "null buffer");
     HIPCHK(h, hipSetDevice(h->cfg.device));
+    if (n > h->B && !h->profiling && h->slots.size() > 1) {
+        // more than one device pass: keep up to `slots` passes in flight through the asynchronous boundary
+        // (pinned staging per slot), results copied out in order
+        for (Slot& sl : h->slots)
+            if (sl.submitted_n >= 0) return fail(h, DS_ERR_INVALID, "ds_forward: ds_submit tickets are still in flight");
+        const int nslots = (int)h->slots.size();
+        std::vector<int32_t> tickets;
+        size_t tail = 0;
+        int off_wait = 0;
+        for (int off = 0; off < n; off += h->B) {
+            const int m = std::min(h->B, n - off);
+            if ((int)(tickets.size() - tail) == nslots) {
+                const int mw = std::min(h->B, n - off_wait);
+                int rc = ds_wait(h, tickets[tail++], act + (size_t)off_wait * h->C, pred + off_wait);
+                if (rc) return rc;
+                off_wait += mw;
+            }
+            int32_t t = -1;
+            int rc = ds_submit(h, m, kmer + (size_t)off * h->T, means + (size_t)off * h->T, stds + (size_t)off * h->T,
+                               sanums + (size_t)off * h->T, signals + (size_t)off * h->S, &t);
+            if (rc) return rc;
+            tickets.push_back(t);
+        }
+        while (tail < tickets.size()) {
+            const int mw = std::min(h->B, n - off_wait);
+            int rc = ds_wait(h, tickets[tail++], act + (size_t)off_wait * h->C, pred + off_wait);
+            if (rc) return rc;
+            off_wait += mw;
+        }
+        return DS_OK;
+    }
     for (int off = 0; off < n; off += h->B) {
         const int m = std::min(h->B, n - off);
         h->cur = &h->slots[0];
