@@ -101,6 +101,8 @@ struct Plan {
     GemmLaunch* d_launches = nullptr;
     std::vector<Op> ops;                  // merged issue order
     hipGraphExec_t graph = nullptr;
+    int64_t uses = 0, last_use = 0;       // ragged tails produce many one-off sizes: graphs are captured for sizes that
+                                          // recur, and the per-slot plan cache is bounded (get_plan)
 };
 
 }  // namespace
@@ -939,16 +941,47 @@ int collect_stage_times(ds_handle* h)
     return DS_OK;
 }
 
+void destroy_plan(ds_handle* h, Plan& p)
+{
+    if (p.graph) hipGraphExecDestroy(p.graph);
+    for (Op& op : p.ops) { if (op.ev0) hipEventDestroy(op.ev0); if (op.ev1) hipEventDestroy(op.ev1); }
+    if (p.d_launches) {
+        hipFree(p.d_launches);
+        auto it = std::find(h->allocs.begin(), h->allocs.end(), (void*)p.d_launches);
+        if (it != h->allocs.end()) h->allocs.erase(it);
+    }
+    p.graph = nullptr; p.d_launches = nullptr; p.ops.clear();
+}
+
+constexpr size_t MAX_PLANS_PER_SLOT = 24;
+
 int get_plan(ds_handle* h, int n, Plan** out)
 {
-    auto it = h->cur->plans.find(n);
-    if (it == h->cur->plans.end()) {
+    static int64_t tick = 0;
+    auto& plans = h->cur->plans;
+    auto it = plans.find(n);
+    if (it == plans.end()) {
+        if (plans.size() >= MAX_PLANS_PER_SLOT && !h->profiling) {
+            // a long run over ragged queue items sees up to max_batch distinct tail sizes: drop the least recently
+            // used plan of this slot (its work must have drained before its graph / descriptors are freed)
+            auto victim = plans.end();
+            for (auto jt = plans.begin(); jt != plans.end(); ++jt)
+                if (jt->first != h->B && (victim == plans.end() || jt->second.last_use < victim->second.last_use)) victim = jt;
+            if (victim != plans.end()) {
+                HIPCHK(h, hipStreamSynchronize(h->cur->s0));
+                HIPCHK(h, hipStreamSynchronize(h->cur->s1));
+                destroy_plan(h, victim->second);
+                plans.erase(victim);
+            }
+        }
         Plan p;
         int rc = build_plan(h, n, &p);
         if (rc) return rc;
-        it = h->cur->plans.emplace(n, std::move(p)).first;
+        it = plans.emplace(n, std::move(p)).first;
         h->stages_done = true;
     }
+    it->second.uses += 1;
+    it->second.last_use = ++tick;
     *out = &it->second;
     return DS_OK;
 }
@@ -968,7 +1001,8 @@ int run_resident(ds_handle* h, int n)
         for (Stage& S : h->stages) S.calls += 1;
         return DS_OK;
     }
-    if (h->use_graph) {
+    // a graph is worth its capture (~ms) only for sizes that come back: the full batch, or any size seen twice
+    if (h->use_graph && (plan->graph || n == h->B || plan->uses >= 2)) {
         if (!plan->graph) {
             hipGraph_t g = nullptr;
             HIPCHK(h, hipStreamBeginCapture(h->cur->s0, hipStreamCaptureModeThreadLocal));

@@ -295,3 +295,17 @@ def test_narrow_and_wide_lstm_tilings_give_the_same_bits(small_weights, monkeypa
         eng.close()
     for a, b in zip(outs["wide"], outs["narrow"]):
         assert np.array_equal(a, b)
+
+
+def test_many_ragged_sizes_bounded_plan_cache(small_weights):
+    """A long run over queue items sees many distinct tail sizes; the per-slot plan cache is bounded (least recently
+    used sizes are dropped) and graphs are only captured for recurring sizes -- results must not depend on any of it."""
+    feats = synth.synthetic_features(64, seed=61)
+    keys = ("kmer", "means", "stds", "sanums", "signals")
+    eng = _engine(small_weights, max_batch=64, slots=2)
+    ref_act, ref_pred = eng.run(*(feats[k] for k in keys))
+    for rep in range(2):
+        for n in list(range(1, 41)) + [64, 17, 3, 64]:          # 40+ sizes > the cache bound, some recurring
+            a, p = eng.run(*(feats[k][:n] for k in keys))
+            assert np.array_equal(a, ref_act[:n]) and np.array_equal(p, ref_pred[:n]), (rep, n)
+    eng.close()
