@@ -316,10 +316,30 @@ def call_mods(input_path, model_path, result_file, kmer_len, cent_signals_len,
         with open(result_file, "wb") as wf:
             def drain(limit):
                 while len(inflight) > limit:
-                    ticket, it_, s_, e_ = inflight.popleft()
+                    ticket, segs_ = inflight.popleft()
                     act_, pred_ = engine.wait(ticket)
-                    wf.write(fastio.format_rows(it_.info, it_.info_off[s_:e_ + 1], act_, pred_, it_.kmer[s_:e_]))
+                    o = 0
+                    for it_, s_, e_ in segs_:
+                        m_ = e_ - s_
+                        wf.write(fastio.format_rows(it_.info, it_.info_off[s_:e_ + 1], act_[o:o + m_], pred_[o:o + m_],
+                                                    it_.kmer[s_:e_]))
+                        o += m_
 
+            def submit(segs_):
+                # asynchronous boundary: up to `slots` batches in flight; rows leave in submission order
+                drain(engine.slots - 1)
+                if len(segs_) == 1:
+                    it_, s_, e_ = segs_[0]
+                    arrs = (it_.kmer[s_:e_], it_.means[s_:e_], it_.stds[s_:e_], it_.lens[s_:e_], it_.signals[s_:e_])
+                else:
+                    arrs = tuple(np.concatenate([getattr(it_, k)[s_:e_] for it_, s_, e_ in segs_])
+                                 for k in ("kmer", "means", "stds", "lens", "signals"))
+                inflight.append((engine.submit(*arrs), segs_))
+
+            # Pipelined route: batches are filled ACROSS queue items (a site's result does not depend on its batch
+            # mates), so the engine sees full batch_size forwards instead of one ragged tail per item; rows are still
+            # written in file order, a read's rows together.
+            segs, count = [], 0
             while True:
                 item = q.get()
                 if item is None:
@@ -327,18 +347,25 @@ def call_mods(input_path, model_path, result_file, kmer_len, cent_signals_len,
                 if isinstance(item, BaseException):
                     raise item
                 n = len(item.labels)
-                for s in range(0, n, batch_size):
-                    e = min(n, s + batch_size)
-                    if pipelined:
-                        # asynchronous boundary: up to `slots` batches in flight; rows leave in submission order
-                        drain(engine.slots - 1)
-                        inflight.append((engine.submit(item.kmer[s:e], item.means[s:e], item.stds[s:e], item.lens[s:e],
-                                                       item.signals[s:e]), item, s, e))
-                    else:
+                if pipelined:
+                    s = 0
+                    while s < n:
+                        take = min(n - s, batch_size - count)
+                        segs.append((item, s, s + take))
+                        count += take
+                        s += take
+                        if count == batch_size:
+                            submit(segs)
+                            segs, count = [], 0
+                else:
+                    for s in range(0, n, batch_size):
+                        e = min(n, s + batch_size)
                         act, pred = engine.run(item.kmer[s:e], item.means[s:e], item.stds[s:e], item.lens[s:e],
                                                item.signals[s:e])
                         wf.write(fastio.format_rows(item.info, item.info_off[s:e + 1], act, pred, item.kmer[s:e]))
                 nsites += n
+            if count:
+                submit(segs)
             drain(0)
             wf.flush()
         th.join()
