@@ -52,8 +52,9 @@ typedef struct ds_config {
     int32_t precision;    /* DS_PRECISION_FP32 | DS_PRECISION_BF16 | DS_PRECISION_BF16_ALL */
     int32_t max_batch;    /* largest n per device pass (workspaces are sized for it); larger n is looped */
     int32_t reserved[7];  /* reserved[0] != 0: debug mode — keep every module output for ds_get_intermediate;
-                             reserved[1]: forwards in flight for ds_forward_device (pipeline slots; default 8 for
-                             max_batch <= 1024, else 4; max 8) */
+                             reserved[1]: forwards in flight for ds_forward_device / ds_submit (pipeline slots, each
+                             with its own workspace, stream pair and captured graphs; default 8 for
+                             max_batch <= 1024, else 4; max 16) */
 } ds_config;
 
 /* Replaces Model(...) + tf.Session(): call_modifications.py:203-209. */
