@@ -1226,28 +1226,35 @@ int ds_forward(ds_handle* h, int32_t n, const int32_t* kmer, const float* means,
         const int nslots = (int)h->slots.size();
         std::vector<int32_t> tickets;
         size_t tail = 0;
-        int off_wait = 0;
-        for (int off = 0; off < n; off += h->B) {
+        int off_wait = 0, rc = DS_OK;
+        for (int off = 0; off < n && !rc; off += h->B) {
             const int m = std::min(h->B, n - off);
             if ((int)(tickets.size() - tail) == nslots) {
                 const int mw = std::min(h->B, n - off_wait);
-                int rc = ds_wait(h, tickets[tail++], act + (size_t)off_wait * h->C, pred + off_wait);
-                if (rc) return rc;
+                rc = ds_wait(h, tickets[tail++], act + (size_t)off_wait * h->C, pred + off_wait);
+                if (rc) break;
                 off_wait += mw;
             }
             int32_t t = -1;
-            int rc = ds_submit(h, m, kmer + (size_t)off * h->T, means + (size_t)off * h->T, stds + (size_t)off * h->T,
-                               sanums + (size_t)off * h->T, signals + (size_t)off * h->S, &t);
-            if (rc) return rc;
-            tickets.push_back(t);
+            rc = ds_submit(h, m, kmer + (size_t)off * h->T, means + (size_t)off * h->T, stds + (size_t)off * h->T,
+                           sanums + (size_t)off * h->T, signals + (size_t)off * h->S, &t);
+            if (!rc) tickets.push_back(t);
         }
-        while (tail < tickets.size()) {
+        while (tail < tickets.size() && !rc) {
             const int mw = std::min(h->B, n - off_wait);
-            int rc = ds_wait(h, tickets[tail++], act + (size_t)off_wait * h->C, pred + off_wait);
-            if (rc) return rc;
+            rc = ds_wait(h, tickets[tail++], act + (size_t)off_wait * h->C, pred + off_wait);
             off_wait += mw;
         }
-        return DS_OK;
+        if (rc) {       // leave no pass in flight behind a failed call (the error message of the failing step is kept)
+            const std::string msg = h->err;
+            for (Slot& sl : h->slots) {
+                if (sl.s0) hipStreamSynchronize(sl.s0);
+                if (sl.s1) hipStreamSynchronize(sl.s1);
+                sl.submitted_n = -1;
+            }
+            h->err = msg;
+        }
+        return rc;
     }
     for (int off = 0; off < n; off += h->B) {
         const int m = std::min(h->B, n - off);
