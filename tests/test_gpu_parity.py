@@ -309,3 +309,19 @@ def test_many_ragged_sizes_bounded_plan_cache(small_weights):
             a, p = eng.run(*(feats[k][:n] for k in keys))
             assert np.array_equal(a, ref_act[:n]) and np.array_equal(p, ref_pred[:n]), (rep, n)
     eng.close()
+
+
+def test_class_num_three():
+    """--class_num is a CLI parameter of the reference (deepsignal.py:266-267); the head handles any class count."""
+    from deepsignal_amd import weights as W
+    from oracle import oracle
+    w = W.random_weights(seed=8, lstm_bias_std=0.1, class_num=3)
+    feats = synth.synthetic_features(50, seed=19)
+    eng = _engine(w, max_batch=64, class_num=3)
+    act, pred = eng.run(feats["kmer"], feats["means"], feats["stds"], feats["sanums"], feats["signals"])
+    o_act, o_pred = oracle.forward(w, feats, "f32", class_num=3)
+    assert act.shape == (50, 3) and np.abs(act - o_act).max() <= ACT_ATOL
+    srt = np.sort(o_act, axis=1)
+    decided = srt[:, -1] - srt[:, -2] > 1e-3
+    assert (pred[decided] == o_pred[decided]).all()
+    eng.close()
