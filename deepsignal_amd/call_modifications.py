@@ -396,20 +396,8 @@ def _call_mods_from_fast5s(fast5_dir, model_path, result_file, kmer_len, cent_si
     fast5s = ef.get_fast5s(fast5_dir, is_recursive)
     print("{} fast5 files in total..".format(len(fast5s)))
     motif_seqs = ef.get_motif_seqs(motifs, is_dna)
-    chrom2len = None
-    if reference_path is not None:
-        chrom2len, name = {}, None
-        with open(reference_path) as rf:                     # contig lengths (reference utils/ref_reader.py:7-13)
-            for line in rf:
-                if line.startswith(">"):
-                    name = line.strip()[1:].split(" ")[0]
-                    chrom2len[name] = 0
-                elif name is not None:
-                    chrom2len[name] += len(line.strip())
-    positions = None
-    if position_file is not None:
-        with open(position_file) as pf:
-            positions = set(ef.key_sep.join(l.strip().split("\t")[:3]) for l in pf)
+    chrom2len = ef.read_reference_lengths(reference_path)       # contig lengths (reference utils/ref_reader.py:7-13)
+    positions = ef.read_position_file(position_file)
     own = engine is None
     if own:
         engine = make_engine(model_path, kmer_len, cent_signals_len, class_num, batch_size,

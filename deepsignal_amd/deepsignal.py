@@ -1,5 +1,6 @@
 """`deepsignal call_mods` command line — the reference's flag surface for this sub-command
-(reference deepsignal/deepsignal.py:236-326, defaults included), driving the MI355X engine.
+(reference deepsignal/deepsignal.py:236-326, defaults included), driving the MI355X engine — plus `extract`, the
+host-side step that produces call_mods' feature-TSV input (deepsignal.py:155-234).
 
 Multi-GPU: one process per GPU, e.g.
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
@@ -25,9 +26,42 @@ def main_call_mods(args):
               precision=args.precision)
 
 
+def main_extraction(args):
+    from .extract_features import extract_features
+    display_args(args)
+    extract_features(args.fast5_dir, str2bool(args.recursively), args.reference_path, str2bool(args.is_dna),
+                     args.f5_batch_num, args.write_path, args.nproc, args.corrected_group, args.basecall_subgroup,
+                     args.normalize_method, args.motifs, args.mod_loc, args.kmer_len, args.cent_signals_len,
+                     args.methy_label, args.positions, str2bool(args.w_is_dir), args.w_batch_num)
+
+
 def build_parser():
     parser = argparse.ArgumentParser(prog="deepsignal", description="call_mods on MI355X (gfx950)")
     sub = parser.add_subparsers(title="modules", dest="module")
+    # `extract`: the step before the path -- fast5 -> feature TSV (reference deepsignal/deepsignal.py:155-234, same flags)
+    e = sub.add_parser("extract", description="extract features from fast5 files (host side, needs h5py)")
+    g = e.add_argument_group("INPUT")
+    g.add_argument("--fast5_dir", "-i", required=True)
+    g.add_argument("--recursively", "-r", default="yes")
+    g.add_argument("--corrected_group", default="RawGenomeCorrected_000")
+    g.add_argument("--basecall_subgroup", default="BaseCalled_template")
+    g.add_argument("--is_dna", default="yes")
+    g.add_argument("--reference_path", default=None)
+    g = e.add_argument_group("EXTRACTION")
+    g.add_argument("--normalize_method", default="mad", choices=["mad", "zscore"])
+    g.add_argument("--methy_label", type=int, default=1, choices=[1, 0])
+    g.add_argument("--kmer_len", type=int, default=17)
+    g.add_argument("--cent_signals_len", type=int, default=360)
+    g.add_argument("--motifs", default="CG")
+    g.add_argument("--mod_loc", type=int, default=0)
+    g.add_argument("--positions", default=None)
+    g = e.add_argument_group("OUTPUT")
+    g.add_argument("--write_path", "-o", required=True)
+    g.add_argument("--w_is_dir", default="no")
+    g.add_argument("--w_batch_num", type=int, default=200)
+    e.add_argument("--nproc", "-p", type=int, default=1)
+    e.add_argument("--f5_batch_num", type=int, default=50)
+    e.set_defaults(func=main_extraction)
     p = sub.add_parser("call_mods", description="call modifications")
     g = p.add_argument_group("INPUT")
     g.add_argument("--input_path", "-i", required=True,

@@ -188,3 +188,102 @@ def get_fast5s(fast5_dir: str, is_recursive: bool = True) -> List[str]:
     if is_recursive:
         return [os.path.join(r, f) for r, _, fs in os.walk(fast5_dir) for f in fs if f.endswith(".fast5")]
     return ["/".join([fast5_dir, f]) for f in os.listdir(fast5_dir) if f.endswith(".fast5")]
+
+
+def read_reference_lengths(reference_path: Optional[str]):
+    """Contig name -> length of a FASTA file, or None (reference utils/ref_reader.py:7-13 role)."""
+    if reference_path is None:
+        return None
+    chrom2len, name = {}, None
+    with open(reference_path) as rf:
+        for line in rf:
+            if line.startswith(">"):
+                name = line.strip()[1:].split(" ")[0]
+                chrom2len[name] = 0
+            elif name is not None:
+                chrom2len[name] += len(line.strip())
+    return chrom2len
+
+
+def read_position_file(position_file: Optional[str]):
+    """chromosome \t position \t strand rows -> set of keys, or None (extract_features.py:388-394 role)."""
+    if position_file is None:
+        return None
+    with open(position_file) as pf:
+        return set(key_sep.join(line.strip().split("\t")[:3]) for line in pf)
+
+
+def _extract_batch(task):
+    (fast5s, corrected_group, basecall_subgroup, normalize_method, motif_seqs, methyloc, chrom2len, kmer_len,
+     raw_signals_len, methy_label, positions) = task
+    feats, err = _extract_features(fast5s, corrected_group, basecall_subgroup, normalize_method, motif_seqs, methyloc,
+                                   chrom2len, kmer_len, raw_signals_len, methy_label, positions)
+    return [_features_to_str(f) for f in feats], err
+
+
+class _FeatureWriter:
+    """One file, or a directory of <n>.tsv files holding w_batch_num batches each (extract_features.py:336-385 role)."""
+
+    def __init__(self, write_fp: str, is_dir: bool, w_batch_num: int):
+        self.is_dir, self.w_batch_num, self.dir = is_dir, max(1, w_batch_num), write_fp
+        self.file_count = self.batch_count = 0
+        if is_dir:
+            if os.path.isfile(write_fp):
+                raise FileExistsError("{} already exists as a file, please use another write_dir".format(write_fp))
+            os.makedirs(write_fp, exist_ok=True)
+            self.wf = open("/".join([write_fp, "0.tsv"]), "w")
+        else:
+            self.wf = open(write_fp, "w")
+
+    def write_batch(self, rows):
+        if self.is_dir and self.batch_count >= self.w_batch_num:
+            self.wf.close()
+            self.file_count += 1
+            self.batch_count = 0
+            self.wf = open("/".join([self.dir, str(self.file_count) + ".tsv"]), "w")
+        for row in rows:
+            self.wf.write(row + "\n")
+        self.wf.flush()
+        self.batch_count += 1
+
+    def close(self):
+        self.wf.close()
+
+
+def extract_features(fast5_dir, is_recursive, reference_path, is_dna, batch_size, write_fp, nproc,
+                     corrected_group, basecall_subgroup, normalize_method, motifs, methyloc, kmer_len, raw_signals_len,
+                     methy_label, position_file, w_is_dir, w_batch_num):
+    """`deepsignal extract`: fast5 directory -> feature TSV (same arguments as the reference's
+    extract_features.py:424-428). Files are taken in batches of `batch_size`; `nproc` > 1 spreads the batches over a
+    process pool (rows of a batch stay together; batches are written in completion order, as in the reference)."""
+    import time
+    start = time.time()
+    fast5s = get_fast5s(fast5_dir, is_recursive)
+    print("{} fast5 files in total..".format(len(fast5s)))
+    motif_seqs = get_motif_seqs(motifs, is_dna)
+    chrom2len = read_reference_lengths(reference_path)
+    positions = read_position_file(position_file)
+    tasks = [(fast5s[i:i + batch_size], corrected_group, basecall_subgroup, normalize_method, motif_seqs, methyloc,
+              chrom2len, kmer_len, raw_signals_len, methy_label, positions) for i in range(0, len(fast5s), batch_size)]
+    writer = _FeatureWriter(write_fp, w_is_dir, w_batch_num)
+    errors = nrows = 0
+    try:
+        if nproc > 1 and len(tasks) > 1:
+            import multiprocessing as mp
+            with mp.get_context("spawn").Pool(min(nproc, len(tasks))) as pool:
+                for rows, err in pool.imap_unordered(_extract_batch, tasks):
+                    writer.write_batch(rows)
+                    errors += err
+                    nrows += len(rows)
+        else:
+            for task in tasks:
+                rows, err = _extract_batch(task)
+                writer.write_batch(rows)
+                errors += err
+                nrows += len(rows)
+    finally:
+        writer.close()
+    print("%d of %d fast5 files failed.." % (errors, len(fast5s)))
+    print("[extract] finished, cost {:.1f}s ({} feature rows)".format(time.time() - start, nrows))
+    return nrows, errors
+

@@ -65,3 +65,59 @@ def test_helpers():
     assert list(c) == [0, 1, 2, 0, 1, 2, 3, 0, 0, 0]
     with pytest.raises(ValueError):
         ef.extract_read_features([0], [0], [1], "A", 1.0, 0.0, "r", "t", "+", "c", 0, None, ["CG"], 0, 16, 360, 1)
+
+
+def _fake_reader(gold):
+    def read(path, corrected_group, basecall_subgroup):
+        r = gold["reads"][os.path.basename(path)[:-len(".fast5")]]
+        return (np.asarray(r["signal"], np.int16), r["starts"], r["lengths"], r["bases"], r["range"] / r["digitisation"],
+                r["offset"], (r["read_id"], r["strand"], r["alignstrand"], r["chrom"], r["chrom_start"]))
+    return read
+
+
+def test_extract_entry_point_and_cli(gold, tmp_path, monkeypatch):
+    """`deepsignal extract` (extract_features.py:424-428 signature): fast5 directory -> feature TSV. HDF5 access is
+    replaced by the committed raw arrays (no h5py in this image); the rows must be the reference extractor's rows, in one
+    file or in a directory of <n>.tsv files, and a broken file is counted, not fatal."""
+    from deepsignal_amd.deepsignal import main
+    case = gold["cases"][0]
+    d = tmp_path / "f5"
+    d.mkdir()
+    for name in gold["read_order"]:
+        (d / (name + ".fast5")).write_bytes(b"")
+    (d / "zzz_broken.fast5").write_bytes(b"")                  # unknown read -> the fake reader raises KeyError
+    monkeypatch.setattr(ef, "_read_fast5", _fake_reader(gold))
+    # files in the order the golden run processed them (its seeded `random.sample` draws depend on it), broken file last
+    order = list(gold["read_order"])
+    monkeypatch.setattr(ef, "get_fast5s", lambda fast5_dir, rec=True: [os.path.join(fast5_dir, n + ".fast5")
+                                                                       for n in order + ["zzz_broken"]])
+    want = list(case["features_str"])
+    ref_fa = None
+    if case["chrom2len"] is not None:                          # the golden run had a reference: contigs of these lengths
+        ref_fa = str(tmp_path / "ref.fa")
+        with open(ref_fa, "w") as f:
+            for name, ln in case["chrom2len"].items():
+                f.write(">%s some description\n" % name)
+                for i in range(0, ln, 80):
+                    f.write("A" * min(80, ln - i) + "\n")
+        assert ef.read_reference_lengths(ref_fa) == case["chrom2len"]
+    out = str(tmp_path / "features.tsv")
+    random.seed(case["seed"])
+    nrows, errors = ef.extract_features(str(d), True, ref_fa, True, 2, out, 1, "RawGenomeCorrected_000", "BaseCalled_template",
+                                        case["normalize_method"], case["motifs"], 0, case["kmer_len"], case["signal_len"], 1,
+                                        None, False, 200)
+    got = open(out).read().splitlines()
+    assert errors == 1 and nrows == len(got) == len(want)
+    assert got == want                            # the reference extractor's rows, byte for byte, in order
+    # directory output through the CLI: ceil(batches / w_batch_num) files
+    outdir = str(tmp_path / "feat_dir")
+    random.seed(case["seed"])
+    assert main(["extract", "-i", str(d), "-o", outdir, "--w_is_dir", "yes", "--w_batch_num", "1", "--f5_batch_num", "2",
+                 "--motifs", case["motifs"], "--normalize_method", case["normalize_method"],
+                 "--kmer_len", str(case["kmer_len"]), "--cent_signals_len", str(case["signal_len"])]
+                + (["--reference_path", ref_fa] if ref_fa else [])) == 0
+    files = sorted(os.listdir(outdir), key=lambda f: int(f.split(".")[0]))
+    nbatches = (len(order) + 1 + 1) // 2
+    assert files == ["%d.tsv" % i for i in range(nbatches)]
+    rows = [l for f in files for l in open(os.path.join(outdir, f)).read().splitlines()]
+    assert rows == want
