@@ -121,3 +121,16 @@ def test_extract_entry_point_and_cli(gold, tmp_path, monkeypatch):
     assert files == ["%d.tsv" % i for i in range(nbatches)]
     rows = [l for f in files for l in open(os.path.join(outdir, f)).read().splitlines()]
     assert rows == want
+
+
+def test_extract_worker_pool_counts_failed_files(tmp_path):
+    """--nproc > 1 spreads file batches over spawned workers; unreadable files (empty here, and no h5py in this image)
+    are counted as failures, as the reference does (extract_features.py:225,281-283)."""
+    d = tmp_path / "f5"
+    d.mkdir()
+    for i in range(5):
+        (d / ("r%d.fast5" % i)).write_bytes(b"")
+    out = str(tmp_path / "o.tsv")
+    nrows, errors = ef.extract_features(str(d), True, None, True, 2, out, 2, "RawGenomeCorrected_000", "BaseCalled_template",
+                                        "mad", "CG", 0, 17, 360, 1, None, False, 200)
+    assert (nrows, errors) == (0, 5) and open(out).read() == ""
