@@ -269,7 +269,7 @@ def call_mods(input_path, model_path, result_file, kmer_len, cent_signals_len,
     start = time.time()
     if os.path.isdir(input_path):
         return _call_mods_from_fast5s(input_path, model_path, result_file, kmer_len, cent_signals_len, batch_size,
-                                      class_num, is_rnn, is_base, is_cnn, f5_args, engine)
+                                      class_num, is_rnn, is_base, is_cnn, f5_args, engine, nproc=nproc)
     if f5_batch_num is None:
         f5_batch_num = f5_args[0] if f5_args else 50
     dist, rank, world, local = _distributed_context(dist)
@@ -385,8 +385,13 @@ def call_mods(input_path, model_path, result_file, kmer_len, cent_signals_len,
     return nsites
 
 
+def _fast5_task(task):
+    """Worker of the fast5 route: one batch of files -> one queue item (picklable wrapper)."""
+    return _read_features_from_fast5s(*task)
+
+
 def _call_mods_from_fast5s(fast5_dir, model_path, result_file, kmer_len, cent_signals_len, batch_size, class_num,
-                           is_rnn, is_base, is_cnn, f5_args, engine=None):
+                           is_rnn, is_base, is_cnn, f5_args, engine=None, nproc=1):
     """fast5-directory mode (reference call_modifications.py:431-448 + :300-414, single process):
     batches of f5_batch_num files -> features on the host -> engine -> rows. Needs h5py for the HDF5 files."""
     from . import extract_features as ef
@@ -403,11 +408,19 @@ def _call_mods_from_fast5s(fast5_dir, model_path, result_file, kmer_len, cent_si
         engine = make_engine(model_path, kmer_len, cent_signals_len, class_num, batch_size,
                              is_cnn=is_cnn, is_rnn=is_rnn, is_base=is_base)
     errors = nsites = 0
+    tasks = [(fast5s[i:i + f5_batch_num], corrected_group, basecall_subgroup, normalize_method, motif_seqs, mod_loc,
+              chrom2len, kmer_len, cent_signals_len, methy_label, positions) for i in range(0, len(fast5s), f5_batch_num)]
+    pool = None
+    if nproc > 2 and len(tasks) > 1:
+        # the reference runs nproc - 1 extraction processes next to the GPU process (call_modifications.py:431-448);
+        # here nproc - 1 workers extract file batches (in order) while this process drives the engine
+        import multiprocessing as mp
+        pool = mp.get_context("spawn").Pool(min(nproc - 1, len(tasks)))
+        results = pool.imap(_fast5_task, tasks)
+    else:
+        results = (_fast5_task(t) for t in tasks)
     with open(result_file, "w") as wf:
-        for i in range(0, len(fast5s), f5_batch_num):
-            batches, err = _read_features_from_fast5s(fast5s[i:i + f5_batch_num], corrected_group, basecall_subgroup,
-                                                      normalize_method, motif_seqs, mod_loc, chrom2len, kmer_len,
-                                                      cent_signals_len, methy_label, positions)
+        for batches, err in results:
             errors += err
             for fb in batches:
                 pred_str, _, _ = _call_mods(fb, engine, batch_size)
@@ -415,6 +428,9 @@ def _call_mods_from_fast5s(fast5_dir, model_path, result_file, kmer_len, cent_si
                     wf.write(row + "\n")
                 nsites += len(pred_str)
             wf.flush()
+    if pool is not None:
+        pool.close()
+        pool.join()
     if own:
         engine.close()
     print("%d of %d fast5 files failed.." % (errors, len(fast5s)))

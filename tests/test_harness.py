@@ -146,3 +146,22 @@ def test_fast5_directory_mode(tmp_path, monkeypatch):
     assert n == len(rows) == len(case["features_str"])
     expect = sorted("\t".join(r.split("\t")[:7]) for r in case["features_str"])
     assert sorted("\t".join(r[:6] + [r[9]]) for r in rows) == expect
+
+
+def test_fast5_directory_mode_with_extraction_workers(tmp_path, capsys):
+    """nproc > 2: file batches are extracted by spawned workers while this process drives the engine (the reference's
+    nproc - 1 extraction processes, call_modifications.py:431-448). Unreadable files are counted, not fatal."""
+    d = tmp_path / "f5"
+    d.mkdir()
+    for i in range(7):
+        (d / ("r%d.fast5" % i)).write_bytes(b"")                 # empty files (and no h5py here): every read fails
+
+    class Eng:
+        def run(self, *a):
+            raise AssertionError("no site should reach the engine")
+
+    out = str(tmp_path / "r.tsv")
+    f5_args = (2, True, "RawGenomeCorrected_000", "BaseCalled_template", True, "mad", "CG", 0, 1, None, None)
+    n = cm.call_mods(str(d), "unused", out, 17, 360, 16, 0.001, 2, 4, False, True, True, True, f5_args, engine=Eng())
+    assert n == 0 and open(out).read() == ""
+    assert "7 of 7 fast5 files failed" in capsys.readouterr().out
