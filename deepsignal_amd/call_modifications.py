@@ -201,6 +201,30 @@ def _distributed_context(dist):
     return tdist, tdist.get_rank(), tdist.get_world_size(), local
 
 
+def _run_item(engine, item, batch_size):
+    """All rows of one queue item through the engine in batch_size chunks; the chunks are kept in flight through the
+    asynchronous boundary when the engine has one."""
+    n = len(item.labels)
+    spans = [(s, min(n, s + batch_size)) for s in range(0, n, batch_size)]
+    args = lambda s, e: (item.kmer[s:e], item.means[s:e], item.stds[s:e], item.lens[s:e], item.signals[s:e])
+    acts, preds = [], []
+    if hasattr(engine, "submit") and hasattr(engine, "wait") and batch_size <= getattr(engine, "max_batch", 0):
+        pending = []
+        for s, e in spans:
+            if len(pending) == engine.slots:
+                ai, pi = engine.wait(pending.pop(0))
+                acts.append(ai); preds.append(pi)
+            pending.append(engine.submit(*args(s, e)))
+        for t in pending:
+            ai, pi = engine.wait(t)
+            acts.append(ai); preds.append(pi)
+    else:
+        for s, e in spans:
+            ai, pi = engine.run(*args(s, e))
+            acts.append(ai); preds.append(pi)
+    return np.concatenate(acts), np.concatenate(preds)
+
+
 def _call_mods_sharded(reader_items, engine, batch_size, result_file, dist, rank, world, device=None):
     """One process per GPU: queue items hold whole reads, item k is run by rank k % world on its own
     weight replica; after every round of `world` items the 12 B/site results are gathered to rank 0 (the only
@@ -238,14 +262,7 @@ def _call_mods_sharded(reader_items, engine, batch_size, result_file, dist, rank
     for k, item in enumerate(reader_items):
         a = p = None
         if k % world == rank:
-            n = len(item.labels)
-            acts, preds = [], []
-            for s in range(0, n, batch_size):
-                e = min(n, s + batch_size)
-                ai, pi = engine.run(item.kmer[s:e], item.means[s:e], item.stds[s:e], item.lens[s:e], item.signals[s:e])
-                acts.append(ai)
-                preds.append(pi)
-            a, p = np.concatenate(acts), np.concatenate(preds)
+            a, p = _run_item(engine, item, batch_size)
         round_items.append((k, item, a, p))
         if len(round_items) == world:
             flush()

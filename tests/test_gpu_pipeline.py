@@ -125,3 +125,20 @@ def test_cli_accepts_a_tf_checkpoint_prefix_and_precision(small_weights, tmp_pat
     p32 = np.array([[float(x) for x in l.split("\t")[6:8]] for l in open(outs["dsw"])])
     p16 = np.array([[float(x) for x in l.split("\t")[6:8]] for l in open(outs["bf16"])])
     assert np.abs(p32 - p16).max() <= 5e-3 and np.abs(p16.sum(axis=1) - 1.0).max() <= 1e-6
+
+
+def test_run_item_pipelines_chunks_with_identical_bits(small_weights):
+    """The per-item helper of the multi-GPU harness keeps an item's chunks in flight (ds_submit / ds_wait)."""
+    from types import SimpleNamespace
+    from deepsignal_amd import call_modifications as cm
+    from deepsignal_amd.engine import Engine
+    n = 1000
+    feats = synth.synthetic_features(n, seed=3)
+    item = SimpleNamespace(labels=np.zeros(n, np.int32), kmer=feats["kmer"], means=feats["means"], stds=feats["stds"],
+                           lens=feats["sanums"], signals=feats["signals"])
+    eng = Engine(max_batch=128, slots=3)
+    eng.load_weights(small_weights)
+    a, p = cm._run_item(eng, item, 128)
+    ra, rp = eng.run(feats["kmer"], feats["means"], feats["stds"], feats["sanums"], feats["signals"])
+    eng.close()
+    assert np.array_equal(a, ra) and np.array_equal(p, rp)
