@@ -144,6 +144,11 @@ struct ds_handle {
     bool is_cnn = true, is_rnn = true, is_base = true;   // model.py:28-29,59-75,89-95
     bool bf16 = false;    // DS_PRECISION_BF16: bf16 conv + FC operands (fp32 accumulate), fp32 BiLSTM
     int lstm_t = -1;          // LSTM cell tiling: 1 = always 128 x 32 (CFG_*LSTM_T), 0 = always 128 x 128, -1 = by forward size
+    // per-handle tuning / diagnostic knobs, all from ds_config.reserved[2..5] (include/deepsignal_hip.h)
+    bool no_fused = false;    // DS_TUNE_NO_FUSED: layer-granular inception modules instead of the fused kernel
+    bool serial = false;      // DS_TUNE_SERIAL: every launch of a forward on ONE stream (stand-alone kernel times)
+    int fuse_max_spt = 8;     // sites per fused-module tile, upper bound
+    int fuse_min_tiles = 128; // fused-module grids keep at least this many workgroups when the batch allows it
     bool lstm_bf16 = false;   // DS_PRECISION_BF16_ALL: additionally bf16 h / weight operands in the LSTM matmuls (fp32 accumulate,
                               // gates and cell state; the layer-0 input projection stays an fp32 table lookup)
     int JP = 0;           // J rounded up to a whole K chunk (32 bf16)
@@ -169,7 +174,7 @@ struct ds_handle {
 
     bool debug_keep_pool = false;   // keep the stand-alone maxpool kernels (diagnostic)
     const float* zero_seg = nullptr;
-    unsigned long long* dbg_stamps = nullptr;   // [NMOD][1024 wgs][2 waves][8] when DS_DEBUG_STAMPS is set
+    unsigned long long* dbg_stamps = nullptr;   // [NMOD][1024 wgs][2 waves][8] when DS_TUNE_DEBUG_STAMPS is set
     std::vector<Stage> stages;
     KernelStat kstat[K_COUNT];
     // pipelining: consecutive forwards rotate over independent slots (own workspace, streams, graphs), so the
@@ -177,6 +182,7 @@ struct ds_handle {
     std::vector<Slot> slots;
     Slot* cur = nullptr;
     unsigned next_slot = 0;
+    int64_t plan_tick = 0;    // LRU clock of the per-slot plan caches
     bool stages_done = false;
 };
 
@@ -289,8 +295,9 @@ int fold_conv(ds_handle* h, const std::string& scope, const std::string& conv, c
     const HostTensor* var = find(h, scope + "/" + bn + "/moving_variance");
     if (!ker || !beta || !gamma || !mean || !var)
         return fail(h, DS_ERR_INVALID, "missing tensor(s) under " + scope + "/" + conv);
-    if ((int64_t)ker->data.size() != (int64_t)k * cin * cout || (int)beta->data.size() != cout)
-        return fail(h, DS_ERR_INVALID, "bad shape for " + scope + "/" + conv);
+    if ((int64_t)ker->data.size() != (int64_t)k * cin * cout || (int)beta->data.size() != cout ||
+        (int)gamma->data.size() != cout || (int)mean->data.size() != cout || (int)var->data.size() != cout)
+        return fail(h, DS_ERR_INVALID, "bad shape for " + scope + "/" + conv + " (kernel or one of beta/gamma/moving_mean/moving_variance)");
     out->k = k; out->cin = cin; out->cout = cout;
     out->w.resize((size_t)k * cin * cout);
     out->b.resize(cout);
@@ -609,18 +616,15 @@ int build_plan(ds_handle* h, int n, Plan* plan)
         st = stage_id(h, nm, 0);
         const int W = module_width(h, m), M = n * W;
         float* y = h->cur->modout[m];
-        static const bool no_fused = getenv("DS_NO_FUSED") != nullptr;
-        if (!no_fused && W <= 96) {
+        if (!h->no_fused && W <= 96) {
             // one fused launch per module; tile = spt whole sites (<= 96 rows). Pick the spt that minimises padded
             // rows (= matrix-pipe time) while keeping >= 128 workgroups when the batch allows it: with several
             // forwards in flight the CUs a short grid leaves idle are taken by other kernels, so fewer, fuller
             // tiles win (W = 23 at 512 sites: 128 tiles of 92/96 rows instead of 512 tiles of 23/32 rows, +2 %).
             int best_spt = 1; long best_rows = -1;
-            static const int max_spt = getenv("DS_FUSE_MAX_SPT") ? atoi(getenv("DS_FUSE_MAX_SPT")) : 8;   // tuning knob
-            for (int spt = 1; spt * W <= 96 && spt <= max_spt; ++spt) {
+            for (int spt = 1; spt * W <= 96 && spt <= h->fuse_max_spt; ++spt) {
                 const int tiles = (n + spt - 1) / spt;
-                static const int min_tiles = getenv("DS_FUSE_MIN_TILES") ? atoi(getenv("DS_FUSE_MIN_TILES")) : 128;   // tuning knob
-                if (spt > 1 && tiles < std::min(min_tiles, n)) break;
+                if (spt > 1 && tiles < std::min(h->fuse_min_tiles, n)) break;
                 const long rows = (long)tiles * ((spt * W + 31) / 32) * 32;
                 if (best_rows < 0 || rows < best_rows) { best_rows = rows; best_spt = spt; }
             }
@@ -691,8 +695,7 @@ int build_plan(ds_handle* h, int n, Plan* plan)
         x = y; cin = INC_OUT;
         if (m == 2 || m == 7) {   // maxpool_layer2/3                            layers.py:211-213,224-226
             const int wout = m == 2 ? h->wb : h->wc, pad = m == 2 ? h->pl_pool2 : h->pl_pool3;
-            static const bool no_fused2 = getenv("DS_NO_FUSED") != nullptr;
-            if (!no_fused2 && wout <= 96 && !h->debug_keep_pool) {
+            if (!h->no_fused && wout <= 96 && !h->debug_keep_pool) {
                 pend_pool_win = W; pend_pool_pad = pad;      // folded into module m+2's staging: no launch, no buffer
             } else {
                 Op op{};
@@ -722,7 +725,7 @@ int build_plan(ds_handle* h, int n, Plan* plan)
     const bool dense = n % 128 == 0;
     // Narrow (128 x 32) LSTM tiles pay when the 128 x 128 tiling cannot fill the GPU: measured on MI355X, fp32 cells
     // gain 2.5 % end to end at 512 sites per forward (+10 % when the convolutions run in bf16) and 36 % at 128, lose
-    // 3 % at >= 1024 (4x the activation traffic); bf16 cells are a wash, so they stay wide. DS_LSTM_T=0/1 forces one.
+    // 3 % at >= 1024 (4x the activation traffic); bf16 cells are a wash, so they stay wide. ds_config.reserved[3] forces one.
     const bool narrow = h->lstm_t >= 0 ? h->lstm_t != 0 : (n <= 512 && !lbf);
     const GemmCfg lstm_cfg = lbf ? (narrow ? (dense ? CFG_BLSTM_T_DENSE : CFG_BLSTM_T) : (dense ? CFG_BLSTM_DENSE : CFG_BLSTM))
                                  : (narrow ? (dense ? CFG_LSTM_T_DENSE : CFG_LSTM_T) : (dense ? CFG_LSTM_DENSE : CFG_LSTM));
@@ -845,8 +848,7 @@ int enqueue_forward(ds_handle* h, Plan& plan, int timed)
     HIPCHK(h, hipEventRecord(h->cur->ev_fork, h->cur->s0));
     HIPCHK(h, hipStreamWaitEvent(h->cur->s1, h->cur->ev_fork, 0));
     bool joined = false;
-    static const bool serial_env = getenv("DS_SERIAL") != nullptr;   // diagnostic: one stream, no overlap
-    const bool serial = serial_env || timed == 3;
+    const bool serial = h->serial || timed == 3;   // diagnostic: one stream, no overlap
     if (timed == 3) timed = 1;
     Op* head[2] = {nullptr, nullptr};       // open run per stream (timed == 1)
     auto close_run = [&](int si) -> int {
@@ -957,7 +959,6 @@ constexpr size_t MAX_PLANS_PER_SLOT = 24;
 
 int get_plan(ds_handle* h, int n, Plan** out)
 {
-    static int64_t tick = 0;
     auto& plans = h->cur->plans;
     auto it = plans.find(n);
     if (it == plans.end()) {
@@ -981,7 +982,7 @@ int get_plan(ds_handle* h, int n, Plan** out)
         h->stages_done = true;
     }
     it->second.uses += 1;
-    it->second.last_use = ++tick;
+    it->second.last_use = ++h->plan_tick;
     *out = &it->second;
     return DS_OK;
 }
@@ -1022,6 +1023,24 @@ int run_resident(ds_handle* h, int n)
 
 }  // namespace
 
+// ---- exception firewall: nothing may unwind across the C ABI (std::bad_alloc from an oversized tensor, length_error
+// from a corrupt header, ...): every allocating entry point runs behind this guard and reports a DS_ERR_* code instead.
+namespace {
+template <class F>
+int guarded(ds_handle* h, F&& body)
+{
+    try {
+        return body();
+    } catch (const std::bad_alloc&) {
+        return fail(h, DS_ERR_NOMEM, "out of host memory");
+    } catch (const std::exception& e) {
+        return fail(h, DS_ERR_INVALID, std::string("internal error: ") + e.what());
+    } catch (...) {
+        return fail(h, DS_ERR_INVALID, "internal error");
+    }
+}
+}  // namespace
+
 // ======================================= C ABI =======================================
 extern "C" {
 
@@ -1029,7 +1048,7 @@ const char* ds_version(void) { return "deepsignal_amd 0.2 (gfx950, fp32 MFMA; op
 
 const char* ds_last_error(const ds_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
 
-int ds_create(const ds_config* cfg, ds_handle** out)
+static int ds_create_impl(const ds_config* cfg, ds_handle** out)
 {
     if (!cfg || !out) return fail(nullptr, DS_ERR_INVALID, "ds_create: null argument");
     *out = nullptr;
@@ -1061,14 +1080,21 @@ int ds_create(const ds_config* cfg, ds_handle** out)
     h->J = (h->is_rnn ? 2 * HID : 0) + (h->is_cnn ? h->SF : 0);     // layers.py:248-255
     h->bf16 = cfg->precision == DS_PRECISION_BF16 || cfg->precision == DS_PRECISION_BF16_ALL;
     h->lstm_bf16 = cfg->precision == DS_PRECISION_BF16_ALL && h->is_rnn;
-    h->lstm_t = getenv("DS_LSTM_T") ? (atoi(getenv("DS_LSTM_T")) != 0 ? 1 : 0) : -1;     // diagnostic override of the LSTM tiling
+    // tuning / diagnostic knobs live in the handle's own config (no process-global state): reserved[2] = flags,
+    // reserved[3] = LSTM tiling override, reserved[4] / [5] = fused-module tile bounds
+    const int32_t flags = cfg->reserved[2];
+    h->no_fused = (flags & DS_TUNE_NO_FUSED) != 0;
+    h->serial = (flags & DS_TUNE_SERIAL) != 0;
+    h->lstm_t = cfg->reserved[3] == DS_LSTM_TILING_NARROW ? 1 : cfg->reserved[3] == DS_LSTM_TILING_WIDE ? 0 : -1;
+    if (cfg->reserved[4] > 0) h->fuse_max_spt = cfg->reserved[4];
+    if (cfg->reserved[5] > 0) h->fuse_min_tiles = cfg->reserved[5];
     h->JP = (h->J + 31) / 32 * 32;
     h->debug = cfg->reserved[0] != 0;
 #define CK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { fail(nullptr, DS_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); ds_destroy(h); return DS_ERR_HIP; } } while (0)
     CK(hipSetDevice(cfg->device));
     CK(configure_fused_kernels());
     // reserved[1] = forwards in flight (pipeline slots); 0 -> default
-    int nslots = cfg->reserved[1] > 0 ? cfg->reserved[1] : (getenv("DS_SLOTS") ? atoi(getenv("DS_SLOTS")) : (h->B <= 1024 ? 8 : 4));
+    int nslots = cfg->reserved[1] > 0 ? cfg->reserved[1] : (h->B <= 1024 ? 8 : 4);
     nslots = std::max(1, std::min(nslots, 16));
     h->slots.resize(nslots);
     int rc = DS_OK;
@@ -1087,7 +1113,7 @@ int ds_create(const ds_config* cfg, ds_handle** out)
         rc = dalloc(h, &z, 64);
         if (!rc && hipMemset(z, 0, 256) != hipSuccess) rc = fail(h, DS_ERR_HIP, "hipMemset");
         h->zero_seg = z;
-        if (!rc && getenv("DS_DEBUG_STAMPS")) {
+        if (!rc && (flags & DS_TUNE_DEBUG_STAMPS)) {
             rc = dalloc(h, &h->dbg_stamps, (size_t)NMOD * 1024 * 16);
             if (!rc) hipMemset(h->dbg_stamps, 0, (size_t)NMOD * 1024 * 16 * 8);
         }
@@ -1120,7 +1146,7 @@ void ds_destroy(ds_handle* h)
     delete h;
 }
 
-int ds_set_tensor(ds_handle* h, const char* name, const float* data, const int64_t* shape, int32_t ndim)
+static int ds_set_tensor_impl(ds_handle* h, const char* name, const float* data, const int64_t* shape, int32_t ndim)
 {
     if (!h || !name || !data || !shape || ndim < 1 || ndim > 8) return fail(h, DS_ERR_INVALID, "ds_set_tensor: bad argument");
     if (h->finalized) return fail(h, DS_ERR_INVALID, "weights already finalized");
@@ -1133,7 +1159,7 @@ int ds_set_tensor(ds_handle* h, const char* name, const float* data, const int64
     return DS_OK;
 }
 
-int ds_finalize_weights(ds_handle* h)
+static int ds_finalize_weights_impl(ds_handle* h)
 {
     if (!h) return DS_ERR_INVALID;
     if (h->finalized) return fail(h, DS_ERR_INVALID, "weights already finalized");
@@ -1141,7 +1167,7 @@ int ds_finalize_weights(ds_handle* h)
     return finalize_weights(h);
 }
 
-int ds_load_weights(ds_handle* h, const char* path)
+static int ds_load_weights_impl(ds_handle* h, const char* path)
 {
     if (!h || !path) return fail(h, DS_ERR_INVALID, "ds_load_weights: bad argument");
     FILE* f = fopen(path, "rb");
@@ -1153,6 +1179,10 @@ int ds_load_weights(ds_handle* h, const char* path)
     if (fread(&nt, 4, 1, f) != 1 || nt > 100000) return bad("bad tensor count");
     struct Meta { std::string name; std::vector<int64_t> shape; uint64_t off, nbytes; };
     std::vector<Meta> metas(nt);
+    if (fseek(f, 0, SEEK_END) != 0) return bad("cannot seek");
+    const long fsize_l = ftell(f);
+    if (fsize_l < 12 || fseek(f, 12, SEEK_SET) != 0) return bad("cannot seek");
+    const uint64_t fsize = (uint64_t)fsize_l;
     for (auto& m : metas) {
         uint16_t ln = 0; uint8_t nd = 0;
         if (fread(&ln, 2, 1, f) != 1) return bad("truncated header");
@@ -1161,6 +1191,11 @@ int ds_load_weights(ds_handle* h, const char* path)
         if (fread(&nd, 1, 1, f) != 1 || nd > 8) return bad("truncated header");
         for (int i = 0; i < nd; ++i) { uint32_t d = 0; if (fread(&d, 4, 1, f) != 1) return bad("truncated header"); m.shape.push_back(d); }
         if (fread(&m.off, 8, 1, f) != 1 || fread(&m.nbytes, 8, 1, f) != 1) return bad("truncated header");
+        // the header is untrusted: the payload must be exactly prod(shape) floats and lie inside the file
+        uint64_t cnt = 1;
+        for (int64_t d : m.shape) { if (d <= 0 || cnt > (uint64_t)1 << 40) return bad("bad tensor shape"); cnt *= (uint64_t)d; }
+        if (cnt > ((uint64_t)1 << 32) || m.nbytes != cnt * 4) return bad("tensor byte count does not match its shape");
+        if (m.off > fsize || m.nbytes > fsize - m.off) return bad("tensor payload lies outside the file");
     }
     for (auto& m : metas) {
         HostTensor t;
@@ -1173,7 +1208,7 @@ int ds_load_weights(ds_handle* h, const char* path)
     return ds_finalize_weights(h);
 }
 
-int ds_forward_device(ds_handle* h, int32_t n, const int32_t* d_kmer, const float* d_means, const float* d_stds,
+static int ds_forward_device_impl(ds_handle* h, int32_t n, const int32_t* d_kmer, const float* d_means, const float* d_stds,
                       const float* d_sanums, const float* d_signals, float* d_act, int32_t* d_pred)
 {
     if (!h) return DS_ERR_INVALID;
@@ -1209,7 +1244,7 @@ int ds_sync(ds_handle* h)
     return DS_OK;
 }
 
-int ds_forward(ds_handle* h, int32_t n, const int32_t* kmer, const float* means, const float* stds, const float* sanums,
+static int ds_forward_impl(ds_handle* h, int32_t n, const int32_t* kmer, const float* means, const float* stds, const float* sanums,
                const float* signals, float* act, int32_t* pred)
 {
     if (!h) return DS_ERR_INVALID;
@@ -1279,7 +1314,7 @@ int ds_forward(ds_handle* h, int32_t n, const int32_t* kmer, const float* means,
 // enqueues H2D + forward + D2H on that slot's streams; ds_wait(ticket) blocks until that forward is done and hands
 // the results out. Up to `slots` forwards are in flight, so PCIe copies, the 19-launch LSTM chain of one batch and
 // the host's own work (parsing, formatting) overlap.
-int ds_submit(ds_handle* h, int32_t n, const int32_t* kmer, const float* means, const float* stds, const float* sanums,
+static int ds_submit_impl(ds_handle* h, int32_t n, const int32_t* kmer, const float* means, const float* stds, const float* sanums,
               const float* signals, int32_t* ticket)
 {
     if (!h || !ticket) return DS_ERR_INVALID;
@@ -1318,7 +1353,7 @@ int ds_submit(ds_handle* h, int32_t n, const int32_t* kmer, const float* means, 
     return DS_OK;
 }
 
-int ds_wait(ds_handle* h, int32_t ticket, float* act, int32_t* pred)
+static int ds_wait_impl(ds_handle* h, int32_t ticket, float* act, int32_t* pred)
 {
     if (!h || !act || !pred) return DS_ERR_INVALID;
     if (ticket < 0 || ticket >= (int)h->slots.size() || h->slots[ticket].submitted_n < 0)
@@ -1415,7 +1450,7 @@ int64_t ds_get_intermediate(ds_handle* h, const char* name, float* out, int64_t 
         return count;
     }
     if (s.rfind("stamps", 0) == 0) {   // "stampsN": phase stamp deltas (cycles) of fused module N, wave 0 and wave 7, averaged over workgroups
-        if (!h->dbg_stamps) return fail(h, DS_ERR_INVALID, "set DS_DEBUG_STAMPS=1");
+        if (!h->dbg_stamps) return fail(h, DS_ERR_INVALID, "create the handle with DS_TUNE_DEBUG_STAMPS in ds_config.reserved[2]");
         const int m = atoi(s.c_str() + 6) - 1;
         if (m < 0 || m >= NMOD || capacity < 16) return fail(h, DS_ERR_INVALID, "bad stamps request");
         std::vector<unsigned long long> st(1024 * 16);
@@ -1503,4 +1538,13 @@ int ds_set_graph(ds_handle* h, int32_t enable)
     return DS_OK;
 }
 
+
+int ds_create(const ds_config* cfg, ds_handle** out) { return guarded(nullptr, [&] { return ds_create_impl(cfg, out); }); }
+int ds_set_tensor(ds_handle* h, const char* name, const float* data, const int64_t* shape, int32_t ndim) { return guarded(h, [&] { return ds_set_tensor_impl(h, name, data, shape, ndim); }); }
+int ds_finalize_weights(ds_handle* h) { return guarded(h, [&] { return ds_finalize_weights_impl(h); }); }
+int ds_load_weights(ds_handle* h, const char* path) { return guarded(h, [&] { return ds_load_weights_impl(h, path); }); }
+int ds_forward_device(ds_handle* h, int32_t n, const int32_t* d_kmer, const float* d_means, const float* d_stds, const float* d_sanums, const float* d_signals, float* d_act, int32_t* d_pred) { return guarded(h, [&] { return ds_forward_device_impl(h, n, d_kmer, d_means, d_stds, d_sanums, d_signals, d_act, d_pred); }); }
+int ds_forward(ds_handle* h, int32_t n, const int32_t* kmer, const float* means, const float* stds, const float* sanums, const float* signals, float* act, int32_t* pred) { return guarded(h, [&] { return ds_forward_impl(h, n, kmer, means, stds, sanums, signals, act, pred); }); }
+int ds_submit(ds_handle* h, int32_t n, const int32_t* kmer, const float* means, const float* stds, const float* sanums, const float* signals, int32_t* ticket) { return guarded(h, [&] { return ds_submit_impl(h, n, kmer, means, stds, sanums, signals, ticket); }); }
+int ds_wait(ds_handle* h, int32_t ticket, float* act, int32_t* pred) { return guarded(h, [&] { return ds_wait_impl(h, ticket, act, pred); }); }
 }  // extern "C"

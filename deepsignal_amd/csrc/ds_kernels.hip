@@ -529,7 +529,8 @@ __global__ __launch_bounds__(64 * WM * WN * KS, EPI == 2 ? 3 : (EPI == 1 && KS =
             if (has_feat) {
                 const unsigned it = (unsigned)row * E.T + E.t;
                 const float f0 = gload(E.means + it), f1 = gload(E.stds + it), f2 = gload(E.lens + it);
-                const int code = has_table ? *(const __attribute__((address_space(1))) int*)(E.codes + it) : 0;
+                // codes index the folded [vocab = 1024][1024] table; a non-Python client may pass anything: clamp
+                const int code = has_table ? min(max(*(const __attribute__((address_space(1))) int*)(E.codes + it), 0), 1023) : 0;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const float4 w0 = gload4(E.wfeat + g * 256 + p8), w1 = gload4(E.wfeat + 1024 + g * 256 + p8),
@@ -625,7 +626,7 @@ __global__ __launch_bounds__(64 * WM * WN * KS, EPI == 2 ? 3 : (EPI == 1 && KS =
                             xf[k] = fmaf(f2, wf[2], fmaf(f1, wf[1], f0 * wf[0]));
                             xo[k] = fmaf(f2, wo[2], fmaf(f1, wo[1], f0 * wo[0]));
                             if (has_table) {
-                                const unsigned tb = (unsigned)codeg[it] * 1024u + u;
+                                const unsigned tb = (unsigned)min(max(codeg[it], 0), 1023) * 1024u + u;
                                 xi[k] += tabg[tb];
                                 xj[k] += tabg[tb + 256];
                                 xf[k] += tabg[tb + 512];

@@ -54,8 +54,25 @@ typedef struct ds_config {
     int32_t reserved[7];  /* reserved[0] != 0: debug mode — keep every module output for ds_get_intermediate;
                              reserved[1]: forwards in flight for ds_forward_device / ds_submit (pipeline slots, each
                              with its own workspace, stream pair and captured graphs; default 8 for
-                             max_batch <= 1024, else 4; max 16) */
+                             max_batch <= 1024, else 4; max 16);
+                             reserved[2]: DS_TUNE_* flag bits (diagnostics, below);
+                             reserved[3]: DS_LSTM_TILING_* override of the planner's BiLSTM tile choice;
+                             reserved[4]: fused inception module, most sites per tile (0 = default 8);
+                             reserved[5]: fused inception module, fewest workgroups a grid is shrunk to when the
+                                          batch allows more (0 = default 128);
+                             reserved[6]: must be 0.
+                             Every knob is per handle: the library reads no environment variable and keeps no
+                             process-global tuning state, so two handles in one process never influence each other. */
 } ds_config;
+
+/* ds_config.reserved[2] bits — diagnostics, results are unchanged (same bits out) */
+#define DS_TUNE_NO_FUSED 1       /* layer-granular GEMM launches for the inception modules instead of the fused kernel */
+#define DS_TUNE_SERIAL 2         /* every launch of a forward on ONE stream (stand-alone kernel durations)            */
+#define DS_TUNE_DEBUG_STAMPS 4   /* attach the s_memtime stamp buffer of the fused kernels (tools/stamps.py)          */
+/* ds_config.reserved[3] */
+#define DS_LSTM_TILING_AUTO 0    /* by forward size */
+#define DS_LSTM_TILING_NARROW 1
+#define DS_LSTM_TILING_WIDE 2
 
 /* Replaces Model(...) + tf.Session(): call_modifications.py:203-209. */
 int ds_create(const ds_config *cfg, ds_handle **out);

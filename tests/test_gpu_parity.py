@@ -281,15 +281,14 @@ def test_config2_full_size_with_sampled_oracle_check():
     eng.close()
 
 
-def test_narrow_and_wide_lstm_tilings_give_the_same_bits(small_weights, monkeypatch):
+def test_narrow_and_wide_lstm_tilings_give_the_same_bits(small_weights):
     """The BiLSTM cells run on 128 x 32 tiles (transposed MFMA, [gate][8 units] column order) for forwards of <= 512
     sites and on 128 x 128 tiles otherwise; both accumulate K in the same order and round the gate math identically."""
     feats = synth.synthetic_features(200, seed=44)
     keys = ("kmer", "means", "stds", "sanums", "signals")
     outs = {}
-    for tag, val in (("wide", "0"), ("narrow", "1")):
-        monkeypatch.setenv("DS_LSTM_T", val)
-        eng = _engine(small_weights, max_batch=256, debug=True)
+    for tag in ("wide", "narrow"):
+        eng = _engine(small_weights, max_batch=256, debug=True, lstm_tiling=tag)
         act, pred = eng.run(*(feats[k] for k in keys))
         outs[tag] = (act, pred, eng.intermediate("lstm_fw_l0", (200, 17, 256)), eng.intermediate("lstm_bw_l2", (200, 17, 256)))
         eng.close()

@@ -1,12 +1,11 @@
-"""Stand-alone per-kernel efficiency at a given batch size (DS_SERIAL=1, profiling mode 2)."""
+"""Stand-alone per-kernel efficiency at a given batch size (serial=True: one stream; profiling mode 2)."""
 import os, sys
-os.environ["DS_SERIAL"] = "1"
 sys.path.insert(0, os.getcwd())
 import numpy as np
 from deepsignal_amd import synth, weights as W
 from deepsignal_amd.engine import Engine
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
-e = Engine(max_batch=B, slots=1); e.load_weights(W.random_weights(seed=1))
+e = Engine(max_batch=B, slots=1, serial=True); e.load_weights(W.random_weights(seed=1))
 f = synth.synthetic_features(B, seed=2)
 args = [f[k] for k in ("kmer", "means", "stds", "sanums", "signals")]
 e.run(*args)

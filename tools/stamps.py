@@ -1,11 +1,10 @@
 import os, sys
-os.environ["DS_DEBUG_STAMPS"] = "1"; os.environ["DS_SERIAL"] = "1"
 sys.path.insert(0, os.getcwd())
 import numpy as np
 from deepsignal_amd import synth, weights as W
 from deepsignal_amd.engine import Engine
 w = W.random_weights(seed=1)
-e = Engine(max_batch=512); e.load_weights(w)
+e = Engine(max_batch=512, serial=True, debug_stamps=True); e.load_weights(w)
 f = synth.synthetic_features(512, seed=2)
 args = [f[k] for k in ("kmer", "means", "stds", "sanums", "signals")]
 for _ in range(3): e.run(*args)

@@ -1,12 +1,11 @@
 import os, sys
-os.environ["DS_DEBUG_STAMPS"] = "1"; os.environ["DS_SERIAL"] = "1"
 sys.path.insert(0, os.getcwd())
 import numpy as np
 from deepsignal_amd import synth, weights as W
 from deepsignal_amd.engine import Engine
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024     # stamp buffer holds 1024 workgroups per module
 w = W.random_weights(seed=1)
-e = Engine(max_batch=B, precision="bf16_all", slots=1); e.load_weights(w)
+e = Engine(max_batch=B, precision="bf16_all", slots=1, serial=True, debug_stamps=True); e.load_weights(w)
 f = synth.synthetic_features(B, seed=2)
 args = [f[k] for k in ("kmer", "means", "stds", "sanums", "signals")]
 for _ in range(3): e.run(*args)
