@@ -13,7 +13,7 @@ from __future__ import absolute_import
 import os
 import sys
 import time
-from typing import Iterator, List, Optional, Sequence, Tuple
+from typing import Iterator, List, NamedTuple, Optional, Sequence, Tuple
 
 import numpy as np
 
@@ -201,205 +201,274 @@ def _distributed_context(dist):
     return tdist, tdist.get_rank(), tdist.get_world_size(), local
 
 
-def _run_item(engine, item, batch_size):
-    """All rows of one queue item through the engine in batch_size chunks; the chunks are kept in flight through the
-    asynchronous boundary when the engine has one."""
-    n = len(item.labels)
-    spans = [(s, min(n, s + batch_size)) for s in range(0, n, batch_size)]
-    args = lambda s, e: (item.kmer[s:e], item.means[s:e], item.stds[s:e], item.lens[s:e], item.signals[s:e])
-    acts, preds = [], []
-    if hasattr(engine, "submit") and hasattr(engine, "wait") and batch_size <= getattr(engine, "max_batch", 0):
-        pending = []
-        for s, e in spans:
-            if len(pending) == engine.slots:
-                ai, pi = engine.wait(pending.pop(0))
-                acts.append(ai); preds.append(pi)
-            pending.append(engine.submit(*args(s, e)))
-        for t in pending:
-            ai, pi = engine.wait(t)
-            acts.append(ai); preds.append(pi)
-    else:
-        for s, e in spans:
-            ai, pi = engine.run(*args(s, e))
-            acts.append(ai); preds.append(pi)
-    return np.concatenate(acts), np.concatenate(preds)
+class _RowPipeline:
+    """Rows of queue items through the engine, results formatted and handed to `sink(tag, row_bytes)` in feed order.
 
+    With an engine that has the asynchronous boundary (submit / wait) batches are filled ACROSS queue items (a site's
+    result does not depend on its batch mates), so the engine sees full batch_size forwards instead of one ragged tail
+    per item, and up to `engine.slots` batches are in flight while the caller parses the next item. Rows still leave in
+    file order, a read's rows together. `tag` travels with every row (the sharded path uses it to know which work unit
+    a row belongs to)."""
 
-def _call_mods_sharded(reader_items, engine, batch_size, result_file, dist, rank, world, device=None):
-    """One process per GPU: queue items hold whole reads, item k is run by rank k % world on its own
-    weight replica; after every round of `world` items the 12 B/site results are gathered to rank 0 (the only
-    collective), which formats and writes the rows in file order -- reads stay contiguous (README.rst:15)."""
-    from . import fastio, sharding
-    nsites = 0
-    wf = open(result_file, "wb") if rank == 0 else None
-    round_items = []
+    def __init__(self, engine, batch_size, sink):
+        import collections
+        from . import fastio
+        self.engine, self.batch_size, self.sink, self.fastio = engine, batch_size, sink, fastio
+        self.pipelined = hasattr(engine, "submit") and hasattr(engine, "wait") and \
+            batch_size <= getattr(engine, "max_batch", 0)
+        self.inflight = collections.deque()
+        self.segs, self.count = [], 0
+        self.nsites = 0
 
-    def flush():
-        nonlocal nsites
-        if not round_items:
+    def _emit(self, seg, act, pred):
+        tag, it, s, e = seg
+        self.sink(tag, self.fastio.format_rows(it.info, it.info_off[s:e + 1], act, pred, it.kmer[s:e]))
+
+    def _drain(self, limit):
+        while len(self.inflight) > limit:
+            ticket, segs = self.inflight.popleft()
+            act, pred = self.engine.wait(ticket)
+            o = 0
+            for seg in segs:
+                m = seg[3] - seg[2]
+                self._emit(seg, act[o:o + m], pred[o:o + m])
+                o += m
+
+    def _submit(self):
+        segs, self.segs, self.count = self.segs, [], 0
+        self._drain(self.engine.slots - 1)
+        if len(segs) == 1:
+            _, it, s, e = segs[0]
+            arrs = (it.kmer[s:e], it.means[s:e], it.stds[s:e], it.lens[s:e], it.signals[s:e])
+        else:
+            arrs = tuple(np.concatenate([getattr(it, k)[s:e] for _, it, s, e in segs])
+                         for k in ("kmer", "means", "stds", "lens", "signals"))
+        self.inflight.append((self.engine.submit(*arrs), segs))
+
+    def feed(self, item, tag=None):
+        n = len(item.labels)
+        self.nsites += n
+        if not self.pipelined:
+            for s in range(0, n, self.batch_size):
+                e = min(n, s + self.batch_size)
+                act, pred = self.engine.run(item.kmer[s:e], item.means[s:e], item.stds[s:e], item.lens[s:e],
+                                            item.signals[s:e])
+                self._emit((tag, item, s, e), act, pred)
             return
-        base = 0
-        act = np.zeros((0, engine.class_num), np.float32)
-        pred = np.zeros((0,), np.int32)
-        index = np.zeros((0,), np.int64)
-        for k, item, a, p in round_items:
-            n = len(item.labels)
-            if a is not None:
-                act, pred, index = a, p, np.arange(base, base + n, dtype=np.int64)
-            base += n
-        g_act, g_pred = sharding.gather_results(act, pred, index, dist, dst=0, device=device)
-        if rank == 0:
-            base = 0
-            for k, item, _, _ in round_items:
-                n = len(item.labels)
-                wf.write(fastio.format_rows(item.info, item.info_off, g_act[base:base + n], g_pred[base:base + n],
-                                            item.kmer))
-                base += n
-            wf.flush()
-        nsites += base
-        round_items.clear()
+        s = 0
+        while s < n:
+            take = min(n - s, self.batch_size - self.count)
+            self.segs.append((tag, item, s, s + take))
+            self.count += take
+            s += take
+            if self.count == self.batch_size:
+                self._submit()
 
-    for k, item in enumerate(reader_items):
-        a = p = None
-        if k % world == rank:
-            a, p = _run_item(engine, item, batch_size)
-        round_items.append((k, item, a, p))
-        if len(round_items) == world:
-            flush()
-    flush()
-    if wf is not None:
-        wf.close()
-    return nsites
+    def flush(self):
+        """Everything fed so far has reached the sink when this returns."""
+        if self.pipelined:
+            if self.count:
+                self._submit()
+            self._drain(0)
+
+
+def _prefetch(iterable, depth=3):
+    """Run `iterable` on a helper thread (the native parser releases the GIL), a bounded queue ahead of the consumer."""
+    import queue
+    import threading
+    q = queue.Queue(maxsize=depth)
+    done = object()
+
+    def produce():
+        try:
+            for x in iterable:
+                q.put(x)
+            q.put(done)
+        except BaseException as exc:          # surfaced on the consumer side
+            q.put(exc)
+
+    th = threading.Thread(target=produce, daemon=True)
+    th.start()
+    while True:
+        x = q.get()
+        if x is done:
+            break
+        if isinstance(x, BaseException):
+            raise x
+        yield x
+    th.join()
+
+
+# Sharded feature-file mode: the file is cut into byte ranges of whole reads of about this many bytes; range k belongs
+# to rank k % world (about 9 k sites of 3.5 kB text per 32 MB: tens of milliseconds of GPU work per range)
+SHARD_CHUNK_BYTES = 32 << 20
+
+
+def _local_world(world):
+    return max(1, min(world, int(os.environ.get("LOCAL_WORLD_SIZE", world))))
+
+
+def _call_mods_sharded(input_path, engine, batch_size, result_file, kmer_len, cent_signals_len, f5_batch_num,
+                       dist, rank, world, device=None):
+    """One process per GPU. Each rank parses ONLY its own byte ranges of the feature file (cut at read
+    boundaries by ds_tsv_align, which every rank computes alike -- per-rank parsing cost is 1/world of the file),
+    runs them on its own weight replica and formats its own rows; the rows go to rank 0 through
+    sharding.OrderedRowGather, whose communication thread keeps the collectives off this thread, and rank 0 writes
+    them in file order -- reads stay contiguous (README.rst:15). Returns the job-wide site count on every rank."""
+    from . import fastio, sharding
+    threads = max(1, fastio.usable_cpus() // _local_world(world))
+    reader = fastio.FeatureReader(input_path, kmer_len, cent_signals_len, nthreads=threads)
+    per_rank = max(1, min(4096, reader.size // max(1, world * SHARD_CHUNK_BYTES)))
+    nchunks = world * per_rank
+    cuts = reader.cut_points(nchunks)
+    gather = sharding.OrderedRowGather(dist, rank, world, result_file, nrounds=per_rank, device=device)
+    mine = list(range(rank, nchunks, world))
+    bufs = {c: [] for c in mine}
+    fed_all = set()                        # chunks whose last row has been fed to the pipeline
+    next_out = [0]                         # index into `mine` of the next chunk to hand over
+
+    def sink(tag, data):
+        bufs[tag].append(data)
+
+    pipe = _RowPipeline(engine, batch_size, sink)
+    # rows of chunk c are complete once everything fed up to the chunk's end has drained; with batches filled across
+    # chunk borders that is known when a LATER batch drains, so hand chunks over lazily and flush at the very end
+
+    def hand_over(upto_complete):
+        while next_out[0] < len(mine) and mine[next_out[0]] in upto_complete:
+            c = mine[next_out[0]]
+            gather.put(b"".join(bufs.pop(c)))
+            upto_complete.discard(c)
+            next_out[0] += 1
+
+    def rows():
+        for c in mine:
+            reader.set_range(cuts[c], cuts[c + 1])
+            for item in reader.items(f5_batch_num):
+                yield c, item
+            yield c, None
+
+    failed = False
+    try:
+        pending_done = []                  # chunks fully fed, waiting for their rows to drain
+        for c, item in _prefetch(rows()):
+            if item is not None:
+                pipe.feed(item, c)
+                continue
+            pending_done.append(c)
+            # a chunk's rows have all drained when nothing of it is buffered in the pipeline any more
+            live = {seg[0] for seg in pipe.segs} | {seg[0] for _, segs in pipe.inflight for seg in segs}
+            fed_all.update(x for x in pending_done if x not in live)
+            pending_done = [x for x in pending_done if x in live]
+            hand_over(fed_all)
+        pipe.flush()
+        fed_all.update(pending_done)
+        hand_over(fed_all)
+    except BaseException:
+        failed = True
+        raise
+    finally:
+        try:
+            total, _ = gather.close(pipe.nsites, 0, failed=failed)
+        finally:
+            reader.close()
+    return total
 
 
 def call_mods(input_path, model_path, result_file, kmer_len, cent_signals_len,
               batch_size, learning_rate, class_num, nproc, is_gpu, is_rnn, is_base, is_cnn,
               f5_args, engine=None, f5_batch_num=None, native_io=True, precision="fp32", dist=None):
-    """Feature-file mode of the reference's call_mods (call_modifications.py:417-495).
+    """The reference's call_mods (call_modifications.py:417-495), same signature and argument meaning.
 
-    learning_rate / nproc / is_gpu are accepted for signature compatibility: inference ignores the
-    learning rate and the engine always runs on the GPU. `f5_args` is the reference's
-    tuple (its first element is f5_batch_num); a directory as input_path takes the fast5 route
-    (features extracted on the host, deepsignal_amd/extract_features.py). With the native reader the engine is
-    driven through its asynchronous boundary (submit / wait, several batches in flight) and, when launched by
-    torch.distributed.run with WORLD_SIZE > 1, one process per GPU shares the reads."""
+    learning_rate / is_gpu are accepted for signature compatibility: inference ignores the learning rate
+     and the engine always runs on the GPU. `f5_args` is the reference's 11-tuple
+    (call_modifications.py:428-429): (is_recursive, corrected_group, basecall_subgroup, reference_path, is_dna,
+    normalize_method, motifs, mod_loc, methy_label, f5_batch_num, position_file); the keyword `f5_batch_num`
+    overrides its entry. A directory as input_path takes the fast5 route (features extracted on the host,
+    deepsignal_amd/extract_features.py). With the native reader the engine is driven through its asynchronous boundary
+    (submit / wait, several batches in flight) and, when launched by torch.distributed.run with WORLD_SIZE > 1, one
+    process per GPU takes its share of the reads."""
     start = time.time()
-    if os.path.isdir(input_path):
-        return _call_mods_from_fast5s(input_path, model_path, result_file, kmer_len, cent_signals_len, batch_size,
-                                      class_num, is_rnn, is_base, is_cnn, f5_args, engine, nproc=nproc)
-    if f5_batch_num is None:
-        f5_batch_num = f5_args[0] if f5_args else 50
+    f5 = _unpack_f5_args(f5_args, f5_batch_num)
     dist, rank, world, local = _distributed_context(dist)
+    device = None
+    if world > 1 and dist.get_backend() == "nccl":
+        import torch
+        device = torch.device("cuda", local)
     own = engine is None
     if own:
         engine = make_engine(model_path, kmer_len, cent_signals_len, class_num, batch_size,
                              is_cnn=is_cnn, is_rnn=is_rnn, is_base=is_base, device=local, precision=precision)
-    nsites = 0
-    if world > 1:
-        # launched as `python -m torch.distributed.run --nproc-per-node N -m deepsignal_amd.deepsignal call_mods ...`
-        if not native_io:
-            raise ValueError("multi-GPU call_mods uses the native feature reader (native_io=True)")
-        from . import fastio
-        reader = fastio.FeatureReader(input_path, kmer_len, cent_signals_len)
-        device = None
-        if dist.get_backend() == "nccl":
-            import torch
-            device = torch.device("cuda", local)
-        nsites = _call_mods_sharded(reader.items(f5_batch_num), engine, batch_size, result_file, dist, rank, world, device)
-        reader.close()
-    elif native_io:
-        # row f1: native reader (host threads) + native row formatter; same items, same row text
-        from . import fastio
-        reader = fastio.FeatureReader(input_path, kmer_len, cent_signals_len)
-        # parse the next item on a helper thread while the engine works on the current one
-        # (the native calls release the GIL); a bounded queue keeps memory flat
-        import queue
-        import threading
-        q = queue.Queue(maxsize=3)
-
-        def _produce():
-            try:
-                for it in reader.items(f5_batch_num):
-                    q.put(it)
-                q.put(None)
-            except BaseException as exc:          # surfaced on the consumer side
-                q.put(exc)
-
-        th = threading.Thread(target=_produce, daemon=True)
-        th.start()
-        import collections
-        inflight = collections.deque()
-        pipelined = hasattr(engine, "submit") and hasattr(engine, "wait") and batch_size <= getattr(engine, "max_batch", 0)
-        with open(result_file, "wb") as wf:
-            def drain(limit):
-                while len(inflight) > limit:
-                    ticket, segs_ = inflight.popleft()
-                    act_, pred_ = engine.wait(ticket)
-                    o = 0
-                    for it_, s_, e_ in segs_:
-                        m_ = e_ - s_
-                        wf.write(fastio.format_rows(it_.info, it_.info_off[s_:e_ + 1], act_[o:o + m_], pred_[o:o + m_],
-                                                    it_.kmer[s_:e_]))
-                        o += m_
-
-            def submit(segs_):
-                # asynchronous boundary: up to `slots` batches in flight; rows leave in submission order
-                drain(engine.slots - 1)
-                if len(segs_) == 1:
-                    it_, s_, e_ = segs_[0]
-                    arrs = (it_.kmer[s_:e_], it_.means[s_:e_], it_.stds[s_:e_], it_.lens[s_:e_], it_.signals[s_:e_])
-                else:
-                    arrs = tuple(np.concatenate([getattr(it_, k)[s_:e_] for it_, s_, e_ in segs_])
-                                 for k in ("kmer", "means", "stds", "lens", "signals"))
-                inflight.append((engine.submit(*arrs), segs_))
-
-            # Pipelined route: batches are filled ACROSS queue items (a site's result does not depend on its batch
-            # mates), so the engine sees full batch_size forwards instead of one ragged tail per item; rows are still
-            # written in file order, a read's rows together.
-            segs, count = [], 0
-            while True:
-                item = q.get()
-                if item is None:
-                    break
-                if isinstance(item, BaseException):
-                    raise item
-                n = len(item.labels)
-                if pipelined:
-                    s = 0
-                    while s < n:
-                        take = min(n - s, batch_size - count)
-                        segs.append((item, s, s + take))
-                        count += take
-                        s += take
-                        if count == batch_size:
-                            submit(segs)
-                            segs, count = [], 0
-                else:
-                    for s in range(0, n, batch_size):
-                        e = min(n, s + batch_size)
-                        act, pred = engine.run(item.kmer[s:e], item.means[s:e], item.stds[s:e], item.lens[s:e],
-                                               item.signals[s:e])
-                        wf.write(fastio.format_rows(item.info, item.info_off[s:e + 1], act, pred, item.kmer[s:e]))
-                nsites += n
-            if count:
-                submit(segs)
-            drain(0)
-            wf.flush()
-        th.join()
-        reader.close()
-    else:
-        with open(result_file, "w") as wf:
-            for item in iter_features_batches(input_path, f5_batch_num):
-                pred_str, _, _ = _call_mods(item, engine, batch_size)
-                for row in pred_str:
-                    wf.write(row + "\n")
+    try:
+        if os.path.isdir(input_path):
+            nsites = _call_mods_from_fast5s(input_path, result_file, kmer_len, cent_signals_len, batch_size, f5, engine,
+                                            nproc=nproc, dist=dist, rank=rank, world=world, device=device)
+        elif world > 1:
+            # launched as `python -m torch.distributed.run --nproc-per-node N -m deepsignal_amd.deepsignal call_mods ...`
+            if not native_io:
+                raise ValueError("multi-GPU call_mods uses the native feature reader (native_io=True)")
+            nsites = _call_mods_sharded(input_path, engine, batch_size, result_file, kmer_len, cent_signals_len,
+                                        f5.f5_batch_num, dist, rank, world, device)
+        elif native_io:
+            # row f1: native reader (host threads, one item ahead on a helper thread) + native row formatter;
+            # same items, same row text
+            from . import fastio
+            reader = fastio.FeatureReader(input_path, kmer_len, cent_signals_len)
+            with open(result_file, "wb") as wf:
+                pipe = _RowPipeline(engine, batch_size, lambda tag, data: wf.write(data))
+                for item in _prefetch(reader.items(f5.f5_batch_num)):
+                    pipe.feed(item)
+                pipe.flush()
                 wf.flush()
-                nsites += len(pred_str)
-    if own:
-        engine.close()
+            nsites = pipe.nsites
+            reader.close()
+        else:
+            nsites = 0
+            with open(result_file, "w") as wf:
+                for item in iter_features_batches(input_path, f5.f5_batch_num):
+                    pred_str, _, _ = _call_mods(item, engine, batch_size)
+                    for row in pred_str:
+                        wf.write(row + "\n")
+                    wf.flush()
+                    nsites += len(pred_str)
+    finally:
+        if own:
+            engine.close()
     if rank == 0:
         print("call_mods costs %.2f seconds.. (%d sites)" % (time.time() - start, nsites))
     return nsites
+
+
+class _F5Args(NamedTuple):
+    """The reference's f5_args, by name (deepsignal.py:83-84, call_modifications.py:428-429)."""
+    is_recursive: bool = True
+    corrected_group: str = "RawGenomeCorrected_000"
+    basecall_subgroup: str = "BaseCalled_template"
+    reference_path: Optional[str] = None
+    is_dna: bool = True
+    normalize_method: str = "mad"
+    motifs: str = "CG"
+    mod_loc: int = 0
+    methy_label: int = 1
+    f5_batch_num: int = 50
+    position_file: Optional[str] = None
+
+
+def _unpack_f5_args(f5_args, f5_batch_num=None) -> "_F5Args":
+    """f5_args in the reference's order; None / () take the CLI defaults. Anything else is an error: a tuple in another
+    layout would silently mis-assign every field."""
+    if f5_args is None or len(f5_args) == 0:
+        f5 = _F5Args()
+    elif len(f5_args) == len(_F5Args._fields):
+        f5 = _F5Args(*f5_args)
+    else:
+        raise ValueError("f5_args must be the reference's 11-tuple %s" % (_F5Args._fields,))
+    if not isinstance(f5.f5_batch_num, (int, np.integer)) or isinstance(f5.f5_batch_num, bool) or f5.f5_batch_num < 1:
+        raise ValueError("f5_args[9] (f5_batch_num) must be a positive int, got %r -- is the tuple in the reference's "
+                         "order %s?" % (f5.f5_batch_num, _F5Args._fields))
+    if f5_batch_num is not None:
+        f5 = f5._replace(f5_batch_num=int(f5_batch_num))
+    return f5
 
 
 def _fast5_task(task):
@@ -407,49 +476,65 @@ def _fast5_task(task):
     return _read_features_from_fast5s(*task)
 
 
-def _call_mods_from_fast5s(fast5_dir, model_path, result_file, kmer_len, cent_signals_len, batch_size, class_num,
-                           is_rnn, is_base, is_cnn, f5_args, engine=None, nproc=1):
-    """fast5-directory mode (reference call_modifications.py:431-448 + :300-414, single process):
-    batches of f5_batch_num files -> features on the host -> engine -> rows. Needs h5py for the HDF5 files."""
+def _call_mods_from_fast5s(fast5_dir, result_file, kmer_len, cent_signals_len, batch_size, f5, engine, nproc=1,
+                           dist=None, rank=0, world=1, device=None):
+    """fast5-directory mode (reference call_modifications.py:431-448 + :300-414): batches of f5_batch_num files ->
+    features on the host -> engine -> rows. Needs h5py for the HDF5 files. With world > 1 (one process per GPU) file
+    batch k belongs to rank k % world -- extraction, the forward and row formatting all happen on the owning rank -- and
+    rank 0 writes the batches' rows in batch order through sharding.OrderedRowGather."""
     from . import extract_features as ef
-    (f5_batch_num, is_recursive, corrected_group, basecall_subgroup, is_dna, normalize_method, motifs, mod_loc,
-     methy_label, position_file, reference_path) = f5_args
-    start = time.time()
-    fast5s = ef.get_fast5s(fast5_dir, is_recursive)
-    print("{} fast5 files in total..".format(len(fast5s)))
-    motif_seqs = ef.get_motif_seqs(motifs, is_dna)
-    chrom2len = ef.read_reference_lengths(reference_path)       # contig lengths (reference utils/ref_reader.py:7-13)
-    positions = ef.read_position_file(position_file)
-    own = engine is None
-    if own:
-        engine = make_engine(model_path, kmer_len, cent_signals_len, class_num, batch_size,
-                             is_cnn=is_cnn, is_rnn=is_rnn, is_base=is_base)
+    fast5s = ef.get_fast5s(fast5_dir, f5.is_recursive)
+    if rank == 0:
+        print("{} fast5 files in total..".format(len(fast5s)))
+    motif_seqs = ef.get_motif_seqs(f5.motifs, f5.is_dna)
+    chrom2len = ef.read_reference_lengths(f5.reference_path)    # contig lengths (reference utils/ref_reader.py:7-13)
+    positions = ef.read_position_file(f5.position_file)
     errors = nsites = 0
-    tasks = [(fast5s[i:i + f5_batch_num], corrected_group, basecall_subgroup, normalize_method, motif_seqs, mod_loc,
-              chrom2len, kmer_len, cent_signals_len, methy_label, positions) for i in range(0, len(fast5s), f5_batch_num)]
+    tasks = [(fast5s[i:i + f5.f5_batch_num], f5.corrected_group, f5.basecall_subgroup, f5.normalize_method, motif_seqs,
+              f5.mod_loc, chrom2len, kmer_len, cent_signals_len, f5.methy_label, positions)
+             for i in range(0, len(fast5s), f5.f5_batch_num)]
+    mine = tasks[rank::world]
     pool = None
-    if nproc > 2 and len(tasks) > 1:
+    if nproc > 2 and len(mine) > 1:
         # the reference runs nproc - 1 extraction processes next to the GPU process (call_modifications.py:431-448);
         # here nproc - 1 workers extract file batches (in order) while this process drives the engine
         import multiprocessing as mp
-        pool = mp.get_context("spawn").Pool(min(nproc - 1, len(tasks)))
-        results = pool.imap(_fast5_task, tasks)
+        pool = mp.get_context("spawn").Pool(min(nproc - 1, len(mine)))
+        results = pool.imap(_fast5_task, mine)
     else:
-        results = (_fast5_task(t) for t in tasks)
-    with open(result_file, "w") as wf:
+        results = (_fast5_task(t) for t in mine)
+    gather = None
+    failed = False
+    if world > 1:
+        from . import sharding
+        gather = sharding.OrderedRowGather(dist, rank, world, result_file, nrounds=(len(tasks) + world - 1) // world,
+                                           device=device)
+    wf = open(result_file, "w") if gather is None else None
+    try:
         for batches, err in results:
             errors += err
+            rows = []
             for fb in batches:
                 pred_str, _, _ = _call_mods(fb, engine, batch_size)
-                for row in pred_str:
-                    wf.write(row + "\n")
-                nsites += len(pred_str)
-            wf.flush()
-    if pool is not None:
-        pool.close()
-        pool.join()
-    if own:
-        engine.close()
-    print("%d of %d fast5 files failed.." % (errors, len(fast5s)))
-    print("call_mods costs %.2f seconds.. (%d sites)" % (time.time() - start, nsites))
+                rows.extend(pred_str)
+            nsites += len(rows)
+            text = "".join(r + "\n" for r in rows)
+            if gather is None:
+                wf.write(text)
+                wf.flush()
+            else:
+                gather.put(text.encode())
+    except BaseException:
+        failed = True
+        raise
+    finally:
+        if pool is not None:
+            pool.close()
+            pool.join()
+        if wf is not None:
+            wf.close()
+        if gather is not None:
+            nsites, errors = gather.close(nsites, errors, failed=failed)
+    if rank == 0:
+        print("%d of %d fast5 files failed.." % (errors, len(fast5s)))
     return nsites

@@ -32,6 +32,7 @@ struct ds_tsv {
     int fd = -1;
     const char* data = nullptr;
     size_t size = 0, pos = 0;
+    size_t limit = 0;          // rows are read from [pos, limit): the whole file, or one rank's byte range (ds_tsv_set_range)
     int kmer_len = 17, signal_len = 360, nthreads = 1;
     int64_t line_no = 0;
     std::string err;
@@ -211,6 +212,7 @@ int ds_tsv_open(const char* path, int32_t kmer_len, int32_t signal_len, int32_t 
         madvise(m, t->size, MADV_SEQUENTIAL);
         t->data = (const char*)m;
     }
+    t->limit = t->size;
     *out = t;
     return DS_OK;
 }
@@ -231,8 +233,8 @@ int64_t ds_tsv_next(ds_tsv* t, int32_t max_reads)
 {
     if (!t || max_reads < 1) return DS_ERR_INVALID;
     t->lines.clear();
-    const char* end = t->data + t->size;
-    const char* p = t->data + t->pos;
+    const char* end = t->data + t->limit;
+    const char* p = t->data + std::min(t->pos, t->limit);
     const char* prev_id = nullptr;
     size_t prev_len = 0;
     int reads = 0;
@@ -299,6 +301,72 @@ int64_t ds_tsv_next(ds_tsv* t, int32_t max_reads)
     for (size_t i = 0; i < n; ++i) memcpy(t->info.data() + t->info_off[i], t->lines[i].first, (size_t)ilen[i]);
     t->line_no += (int64_t)n;
     return (int64_t)n;
+}
+
+int64_t ds_tsv_size(const ds_tsv* t) { return t ? (int64_t)t->size : DS_ERR_INVALID; }
+
+namespace {
+// [begin, end) of column 5 (the read id) of the line starting at p; false when the line has fewer than 5 columns
+bool line_read_id(const char* p, const char* le, const char** ib, const char** ie)
+{
+    const char* c = p;
+    int tabs = 0;
+    while (tabs < 4 && c < le) { c = find_tab(c, le); if (c < le) { ++c; ++tabs; } }
+    if (tabs < 4) return false;
+    *ib = c; *ie = find_tab(c, le);
+    return true;
+}
+}  // namespace
+
+// First read boundary at or after byte `pos`: the start of the first line that begins at or after `pos` and whose
+// read id (column 5) differs from the line before it -- so [align(a), align(b)) always holds whole reads, and the
+// ranges of consecutive nominal offsets tile the file exactly. 0 stays 0; returns the file size when no boundary
+// follows. A function of the file alone: every rank computes the same cut points without talking to the others.
+int64_t ds_tsv_align(const ds_tsv* t, int64_t pos)
+{
+    if (!t || pos < 0) return DS_ERR_INVALID;
+    if (pos == 0) return 0;
+    if ((size_t)pos >= t->size) return (int64_t)t->size;
+    const char* data = t->data;
+    const char* end = data + t->size;
+    // start of the last non-blank line that begins before pos (the "previous" line of the first candidate)
+    auto line_start = [&](const char* x) { const char* r = x - 1; while (r > data && r[-1] != '\n') --r; return r; };   // x > data
+    auto is_blank = [&](const char* b) { const char* e = b; while (e < end && *e != '\n') { if (*e != '\r') return false; ++e; } return true; };
+    const char* q = line_start(data + pos);
+    while (q > data && is_blank(q)) q = line_start(q);
+    const char* prev_b = nullptr; const char* prev_e = nullptr;
+    bool have_prev = false;
+    const char* p = q;
+    bool first = true;
+    while (p < end) {
+        const char* nl = (const char*)memchr(p, '\n', (size_t)(end - p));
+        const char* le = nl ? nl : end;
+        const char* ltrim = le;
+        while (ltrim > p && ltrim[-1] == '\r') --ltrim;
+        if (ltrim > p) {                                    // blank lines neither start nor end a read
+            const char *ib, *ie;
+            if (!line_read_id(p, ltrim, &ib, &ie)) return (int64_t)(p - data);      // malformed: the parser reports it
+            if (!first && p >= data + pos) {
+                if (!have_prev || (size_t)(ie - ib) != (size_t)(prev_e - prev_b) || memcmp(ib, prev_b, (size_t)(ie - ib)) != 0)
+                    return (int64_t)(p - data);
+            }
+            prev_b = ib; prev_e = ie; have_prev = true;
+            first = false;
+        }
+        p = nl ? nl + 1 : end;
+    }
+    return (int64_t)t->size;
+}
+
+// Restrict the reader to the byte range [begin, end) (both from ds_tsv_align) and rewind to its start.
+int ds_tsv_set_range(ds_tsv* t, int64_t begin, int64_t end)
+{
+    if (!t || begin < 0 || end < begin || (size_t)end > t->size) return DS_ERR_INVALID;
+    t->pos = (size_t)begin;
+    t->limit = (size_t)end;
+    t->line_no = 0;
+    t->err.clear();
+    return DS_OK;
 }
 
 const int32_t* ds_tsv_kmer(const ds_tsv* t) { return t->kmer.data(); }

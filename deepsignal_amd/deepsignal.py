@@ -17,9 +17,10 @@ from .utils.process_utils import display_args, str2bool
 def main_call_mods(args):
     from .call_modifications import call_mods
     display_args(args)
-    f5_args = (args.f5_batch_num, str2bool(args.recursively), args.corrected_group, args.basecall_subgroup,
-               str2bool(args.is_dna), args.normalize_method, args.motifs, args.mod_loc, 1, args.positions,
-               args.reference_path)
+    # the reference's tuple, in the reference's order (deepsignal.py:83-84); methy_label is fixed to 1 there (:78-79)
+    f5_args = (str2bool(args.recursively), args.corrected_group, args.basecall_subgroup, args.reference_path,
+               str2bool(args.is_dna), args.normalize_method, args.motifs, args.mod_loc, 1, args.f5_batch_num,
+               args.positions)
     call_mods(args.input_path, args.model_path, args.result_file, args.kmer_len, args.cent_signals_len,
               args.batch_size, args.learning_rate, args.class_num, args.nproc, str2bool(args.is_gpu),
               str2bool(args.is_rnn), str2bool(args.is_base), str2bool(args.is_cnn), f5_args,

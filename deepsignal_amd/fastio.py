@@ -14,6 +14,24 @@ import numpy as np
 from .engine import load_library
 
 
+def usable_cpus() -> int:
+    """Host CPUs this process may use: affinity mask and cgroup-v2 quota both count (the GPU boxes expose 256 logical
+    CPUs under a 16-CPU quota; a thread team wider than the quota only thrashes)."""
+    import os
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, -(-int(quota) // int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
 class FeatureItem(NamedTuple):
     """One queue item (all rows of f5_batch_num reads)."""
     info: np.ndarray          # uint8 buffer: the first six columns of every row, concatenated
@@ -51,6 +69,11 @@ def _bind():
         f = getattr(lib, "ds_tsv_" + name)
         f.argtypes = [vp]
         f.restype = vp
+    lib.ds_tsv_size.argtypes = [vp]
+    lib.ds_tsv_size.restype = i64
+    lib.ds_tsv_align.argtypes = [vp, i64]
+    lib.ds_tsv_align.restype = i64
+    lib.ds_tsv_set_range.argtypes = [vp, i64, i64]
     lib.ds_format_rows.argtypes = [i64, vp, vp, vp, i32, vp, vp, i32, vp, i64]
     lib.ds_format_rows.restype = i64
     lib._io_bound = True
@@ -84,6 +107,30 @@ class FeatureReader:
             self.close()
         except Exception:
             pass
+
+    @property
+    def size(self) -> int:
+        return int(self._lib.ds_tsv_size(self._h))
+
+    def align(self, pos: int) -> int:
+        """First read boundary at or after byte `pos` (ds_tsv_align): cut points every rank computes alike."""
+        got = int(self._lib.ds_tsv_align(self._h, int(pos)))
+        if got < 0:
+            raise ValueError("ds_tsv_align(%d) failed (%d)" % (pos, got))
+        return got
+
+    def set_range(self, begin: int, end: int) -> None:
+        """Read rows of the byte range [begin, end) only (both ends from align())."""
+        if self._lib.ds_tsv_set_range(self._h, int(begin), int(end)) != 0:
+            raise ValueError("bad byte range [%d, %d)" % (begin, end))
+
+    def cut_points(self, nchunks: int) -> list:
+        """nchunks + 1 byte offsets that tile the file into chunks of whole reads, near-equal in bytes."""
+        size = self.size
+        pts = [self.align(size * k // nchunks) for k in range(nchunks)] + [size]
+        for k in range(1, len(pts)):                     # monotone by construction; keep it so explicitly
+            pts[k] = max(pts[k], pts[k - 1])
+        return pts
 
     def items(self, f5_batch_num: int = 50) -> Iterator[FeatureItem]:
         lib, h, K, S = self._lib, self._h, self.kmer_len, self.signal_len

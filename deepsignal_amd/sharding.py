@@ -78,3 +78,95 @@ def gather_results(act, pred, index, dist=None, dst: int = 0, device=None, as_nu
         out_act[gi] = blk[:, :C].astype(np.float32)
         out_pred[gi] = blk[:, C].astype(np.int32)
     return out_act, out_pred
+
+
+class OrderedRowGather:
+    """The product path's only exchange: result rows travel to the writer rank, which writes them in
+    work-unit order. Work unit k (a byte range of whole reads, or a batch of fast5 files) belongs to rank k % world;
+    round r = units r*world .. r*world + world - 1. Every rank hands its finished unit of round r to put(); a
+    COMMUNICATION THREAD per rank runs the collectives (lengths, then the padded byte payload, gathered to rank 0
+    over RCCL/xGMI with backend "nccl", or gloo on CPU), so the rank's main thread never blocks on a collective: it
+    parses and drives its GPU for round r+1 while round r is on the wire and being written. `depth` bounds the
+    finished-but-unsent rounds a rank may hold (back-pressure).
+
+    The rows are gathered as formatted text (the 12 B/site of results plus the six verbatim sampleinfo columns and
+    the k-mer that only the owning rank has parsed): rank 0 never touches the other ranks' input bytes.
+    Only the communication thread calls into torch.distributed, so the collective order is the same on every rank."""
+
+    def __init__(self, dist, rank: int, world: int, result_file: str, nrounds: int, device=None, depth: int = 4):
+        import queue
+        import threading
+        self.dist, self.rank, self.world, self.nrounds, self.device = dist, rank, world, nrounds, device
+        self._q = queue.Queue(maxsize=max(1, depth))
+        self._exc = None
+        self._put = 0
+        self.total_sites = 0
+        self.total_errors = 0
+        self.failed_ranks = 0
+        self.bytes_gathered = 0
+        self._wf = open(result_file, "wb") if rank == 0 else None
+        self._th = threading.Thread(target=self._run, name="ds-row-gather", daemon=True)
+        self._th.start()
+
+    def put(self, data: bytes) -> None:
+        """This rank's rows of its next round (b"" when it owns no unit in that round)."""
+        if self._exc is not None:
+            raise self._exc
+        self._put += 1
+        self._q.put(bytes(data))
+
+    def close(self, nsites: int = 0, nerrors: int = 0, failed: bool = False):
+        """All rounds handed over: wait for the exchange to finish; returns the job-wide (sites, errors) on every rank.
+        failed=True (this rank hit an error): its remaining rounds are sent empty so no rank hangs in a collective,
+        and EVERY rank's close() raises."""
+        while self._put < self.nrounds:
+            self.put(b"")
+        self._q.put((int(nsites), int(nerrors), 1 if failed else 0))
+        self._th.join()
+        if self._wf is not None:
+            self._wf.close()
+        if self._exc is not None:
+            raise self._exc
+        if self.failed_ranks:
+            raise RuntimeError("call_mods failed on %d rank(s); %s is incomplete" % (self.failed_ranks, "the result file"))
+        return self.total_sites, self.total_errors
+
+    def _run(self):
+        import torch
+        try:
+            dist, world, rank = self.dist, self.world, self.rank
+            dev = self.device if self.device is not None else torch.device("cpu")
+            if dev.type == "cuda":
+                torch.cuda.set_device(dev)
+            for _ in range(self.nrounds):
+                data = self._q.get()
+                n_local = torch.tensor([len(data)], dtype=torch.int64, device=dev)
+                lens = [torch.zeros_like(n_local) for _ in range(world)]
+                dist.all_gather(lens, n_local)
+                lens = [int(x.item()) for x in lens]
+                nmax = max(lens)
+                if nmax == 0:
+                    continue
+                buf = torch.zeros(nmax, dtype=torch.uint8)
+                if data:
+                    buf[:len(data)] = torch.frombuffer(bytearray(data), dtype=torch.uint8)
+                buf = buf.to(dev)
+                gl = [torch.empty_like(buf) for _ in range(world)] if rank == 0 else None
+                dist.gather(buf, gl, dst=0)
+                if rank == 0:
+                    for r in range(world):
+                        if lens[r]:
+                            self._wf.write(gl[r][:lens[r]].cpu().numpy().tobytes())
+                            self.bytes_gathered += lens[r] if r else 0
+                    self._wf.flush()
+            counts = self._q.get()
+            t = torch.tensor(list(counts), dtype=torch.int64, device=dev)
+            dist.all_reduce(t)
+            self.total_sites, self.total_errors, self.failed_ranks = int(t[0].item()), int(t[1].item()), int(t[2].item())
+        except BaseException as exc:      # surfaced by put() / close() on the main thread
+            self._exc = exc
+            try:
+                while True:
+                    self._q.get_nowait()
+            except Exception:
+                pass

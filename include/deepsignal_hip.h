@@ -162,6 +162,15 @@ int ds_tsv_open(const char *path, int32_t kmer_len, int32_t signal_len, int32_t 
 void ds_tsv_close(ds_tsv *t);
 const char *ds_tsv_error(const ds_tsv *t);
 int64_t ds_tsv_next(ds_tsv *t, int32_t max_reads);
+/* Multi-GPU call_mods (sites sharded BY READ): each rank parses only its own byte ranges of the file.
+ * ds_tsv_align(t, pos) = the first read boundary at or after byte pos (start of the first line beginning at or after
+ * pos whose read id differs from the line before it; 0 -> 0; file size when none follows), a function of the file
+ * alone, so all ranks agree on the cut points without communicating; ds_tsv_set_range(t, begin, end) restricts
+ * ds_tsv_next to [begin, end) and rewinds. The reference has no counterpart (single reader process,
+ * call_modifications.py:453). */
+int64_t ds_tsv_size(const ds_tsv *t);
+int64_t ds_tsv_align(const ds_tsv *t, int64_t pos);
+int ds_tsv_set_range(ds_tsv *t, int64_t begin, int64_t end);
 const int32_t *ds_tsv_kmer(const ds_tsv *t);
 const float *ds_tsv_means(const ds_tsv *t);
 const float *ds_tsv_stds(const ds_tsv *t);

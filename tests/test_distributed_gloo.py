@@ -97,45 +97,159 @@ class _OracleEngine:
         return oracle.forward(self.w, feats, "f32", nthreads=2)
 
 
-def _call_mods_worker(rank, world, port, tmp):
+def _call_mods_worker(rank, world, port, tmp, chunk_bytes):
     sys.path.insert(0, ROOT)
     import torch.distributed as dist
     from deepsignal_amd import call_modifications as cm, weights
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    cm.SHARD_CHUNK_BYTES = chunk_bytes            # small ranges: several rounds of the row gather even on a test-sized file
     w = weights.random_weights(seed=11, lstm_bias_std=0.1)
     log = []
     n = cm.call_mods(os.path.join(tmp, "features.tsv"), "unused", os.path.join(tmp, "sharded.tsv"), 17, 360, 8, 0.001, 2,
-                     1, True, True, True, True, (2,), engine=_OracleEngine(w, log), dist=dist)
+                     1, True, True, True, True, None, engine=_OracleEngine(w, log), dist=dist, f5_batch_num=2)
     with open(os.path.join(tmp, "rank%d.log" % rank), "w") as f:
         f.write("%d %d\n" % (n, sum(log)))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_call_mods_two_ranks_writes_the_single_process_file(tmp_path):
-    """5 queue items (2 reads each, ragged last one) over 2 ranks: rank 0's file must equal the single-process file
-    byte for byte, and every rank must have run only its own items."""
-    sys.path.insert(0, ROOT)
-    lib = os.path.join(ROOT, "deepsignal_amd", "libdeepsignal_hip.so")
-    if not os.path.exists(lib):
+def _need_native():
+    if not os.path.exists(os.path.join(ROOT, "deepsignal_amd", "libdeepsignal_hip.so")):
         import pytest
         pytest.skip("native library not built (the sharded harness uses the native reader)")
+
+
+def _run_sharded_vs_single(tmp, world, reads, chunk_bytes, seed=5):
     from deepsignal_amd import call_modifications as cm, synth, weights
-    n = 27
-    feats = synth.synthetic_features(n, seed=5)
-    reads = ["read%d" % (i // 3) for i in range(n)]               # 9 reads, 3 sites each -> items of 2 reads: 6,6,6,6,3
-    tmp = str(tmp_path)
+    n = len(reads)
+    feats = synth.synthetic_features(n, seed=seed)
     _write_feature_tsv(os.path.join(tmp, "features.tsv"), feats, reads)
-    mp.spawn(_call_mods_worker, args=(2, _free_port(), tmp), nprocs=2, join=True)
+    mp.spawn(_call_mods_worker, args=(world, _free_port(), tmp, chunk_bytes), nprocs=world, join=True)
     w = weights.random_weights(seed=11, lstm_bias_std=0.1)
     log = []
     cm.call_mods(os.path.join(tmp, "features.tsv"), "unused", os.path.join(tmp, "single.tsv"), 17, 360, 8, 0.001, 2, 1,
-                 True, True, True, True, (2,), engine=_OracleEngine(w, log))
+                 True, True, True, True, None, engine=_OracleEngine(w, log), f5_batch_num=2)
     assert open(os.path.join(tmp, "sharded.tsv"), "rb").read() == open(os.path.join(tmp, "single.tsv"), "rb").read()
-    r0 = [int(x) for x in open(os.path.join(tmp, "rank0.log")).read().split()]
-    r1 = [int(x) for x in open(os.path.join(tmp, "rank1.log")).read().split()]
-    assert r0[0] == r1[0] == n                   # both saw all the rows go by
-    assert r0[1] == 6 + 6 + 3 and r1[1] == 6 + 6  # items 0,2,4 on rank 0; items 1,3 on rank 1
-    assert not os.path.exists(os.path.join(tmp, "sharded.tsv.rank1"))
+    logs = [[int(x) for x in open(os.path.join(tmp, "rank%d.log" % r)).read().split()] for r in range(world)]
+    assert all(l[0] == n for l in logs)              # every rank returns the job-wide site count
+    assert sum(l[1] for l in logs) == n              # and together they ran every site exactly once
+    return [l[1] for l in logs]
+
+
+def test_call_mods_two_ranks_writes_the_single_process_file(tmp_path):
+    """9 reads of 3 sites over 2 ranks, byte ranges cut at read boundaries: rank 0's file must equal the single-process
+    file byte for byte, and each rank parses and runs only the reads of its own ranges."""
+    sys.path.insert(0, ROOT)
+    _need_native()
+    reads = ["read%d" % (i // 3) for i in range(27)]
+    own = _run_sharded_vs_single(str(tmp_path), 2, reads, chunk_bytes=1 << 30)       # one range per rank
+    assert all(x % 3 == 0 and x > 0 for x in own)                                    # whole reads only
+    assert not os.path.exists(os.path.join(str(tmp_path), "sharded.tsv.rank1"))
+
+
+def test_call_mods_four_ranks_uneven_reads_several_rounds(tmp_path):
+    """World 4, reads of very different lengths (1 .. 13 sites), ranges of ~12 kB so that every rank owns several and
+    the row gather runs several rounds: still the single-process file, byte for byte."""
+    sys.path.insert(0, ROOT)
+    _need_native()
+    lens = [1, 7, 2, 13, 1, 1, 5, 3, 9, 2, 4, 6]
+    reads = [("r%02d" % k) for k, m in enumerate(lens) for _ in range(m)]
+    own = _run_sharded_vs_single(str(tmp_path), 4, reads, chunk_bytes=12000, seed=6)
+    assert sum(own) == sum(lens)
+
+
+def test_call_mods_four_ranks_with_empty_shards(tmp_path):
+    """Two reads for four ranks: at least two ranks own no read at all and still take part in every collective."""
+    sys.path.insert(0, ROOT)
+    _need_native()
+    reads = ["a"] * 5 + ["b"] * 2
+    own = _run_sharded_vs_single(str(tmp_path), 4, reads, chunk_bytes=1 << 30, seed=7)
+    assert sorted(own) == [0, 0, 2, 5]
+
+
+def test_cut_points_tile_the_file_in_whole_reads(tmp_path):
+    """ds_tsv_align: the cut points every rank computes on its own tile the file exactly, and no read straddles one."""
+    sys.path.insert(0, ROOT)
+    _need_native()
+    from deepsignal_amd import fastio, synth
+    lens = [3, 1, 8, 2, 2, 11, 1, 4]
+    reads = [("q%d" % k) for k, m in enumerate(lens) for _ in range(m)]
+    path = os.path.join(str(tmp_path), "f.tsv")
+    _write_feature_tsv(path, synth.synthetic_features(len(reads), seed=8), reads)
+    rd = fastio.FeatureReader(path, nthreads=1)
+    whole = [it for it in rd.items(1)]
+    for nchunks in (1, 2, 3, 5, 16, 64):
+        cuts = rd.cut_points(nchunks)
+        assert cuts[0] == 0 and cuts[-1] == rd.size and cuts == sorted(cuts)
+        got = []
+        for c in range(nchunks):
+            rd.set_range(cuts[c], cuts[c + 1])
+            got.extend(rd.items(1))                  # items of ONE read each
+        assert [bytes(g.info) for g in got] == [bytes(w_.info) for w_ in whole]
+        assert all(np.array_equal(g.signals, w_.signals) for g, w_ in zip(got, whole))
+    rd.close()
+
+
+# ---- the fast5-directory route under WORLD_SIZE > 1: file batch k belongs to rank k % world ----
+def _fast5_worker(rank, world, port, tmp, golden):
+    sys.path.insert(0, ROOT)
+    import json
+    import torch.distributed as dist
+    from deepsignal_amd import call_modifications as cm, extract_features as ef
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = json.load(open(golden))
+
+    def fake_read(path, corrected_group, basecall_subgroup):
+        r = g["reads"][os.path.basename(path)[:-6]]
+        return (np.asarray(r["signal"], np.int16), r["starts"], r["lengths"], r["bases"], r["range"] / r["digitisation"],
+                r["offset"], (r["read_id"], r["strand"], r["alignstrand"], r["chrom"], r["chrom_start"]))
+
+    ef._read_fast5 = fake_read
+    f5_args = (True, "RawGenomeCorrected_000", "BaseCalled_template", None, True, "mad", "CG", 0, 1, 1, None)
+    n = cm.call_mods(os.path.join(tmp, "f5"), "unused", os.path.join(tmp, "sharded.tsv"), 17, 360, 16, 0.001, 2, 1, False,
+                     True, True, True, f5_args, engine=_SignalEngine(), dist=dist)
+    open(os.path.join(tmp, "f5rank%d.log" % rank), "w").write(str(n))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+class _SignalEngine:
+    """Deterministic stand-in: outputs depend on the site's own features only (not on the 360 central samples: one
+    golden read takes the reference's random.sample branch, extract_features.py:165-168)."""
+    class_num = 2
+
+    def run(self, kmer, means, stds, sanums, signals):
+        x = np.stack([np.asarray(means, np.float32)[:, 0], np.asarray(stds, np.float32)[:, 1]], axis=1)
+        act = np.stack([1 / (1 + np.exp(-x[:, 0])), 1 / (1 + np.exp(x[:, 1]))], axis=1).astype(np.float32)
+        return act, np.argmax(act, axis=1)
+
+
+def test_fast5_directory_two_ranks_writes_the_single_process_file(tmp_path, monkeypatch):
+    """Directory input under torch.distributed: batches of files are dealt to the ranks, rank 0 writes the rows in batch
+    order (the single-process file), the other ranks write nothing."""
+    sys.path.insert(0, ROOT)
+    import json
+    from deepsignal_amd import call_modifications as cm, extract_features as ef
+    golden = os.path.join(ROOT, "tests", "golden", "extract_golden.json")
+    g = json.load(open(golden))
+    tmp = str(tmp_path)
+    os.mkdir(os.path.join(tmp, "f5"))
+    for name in g["read_order"]:
+        open(os.path.join(tmp, "f5", name + ".fast5"), "wb").close()
+    mp.spawn(_fast5_worker, args=(2, _free_port(), tmp, golden), nprocs=2, join=True)
+
+    def fake_read(path, corrected_group, basecall_subgroup):
+        r = g["reads"][os.path.basename(path)[:-6]]
+        return (np.asarray(r["signal"], np.int16), r["starts"], r["lengths"], r["bases"], r["range"] / r["digitisation"],
+                r["offset"], (r["read_id"], r["strand"], r["alignstrand"], r["chrom"], r["chrom_start"]))
+
+    monkeypatch.setattr(ef, "_read_fast5", fake_read)
+    f5_args = (True, "RawGenomeCorrected_000", "BaseCalled_template", None, True, "mad", "CG", 0, 1, 1, None)
+    n = cm.call_mods(os.path.join(tmp, "f5"), "unused", os.path.join(tmp, "single.tsv"), 17, 360, 16, 0.001, 2, 1, False,
+                     True, True, True, f5_args, engine=_SignalEngine())
+    assert n > 0 and open(os.path.join(tmp, "f5rank0.log")).read() == open(os.path.join(tmp, "f5rank1.log")).read() == str(n)
+    assert open(os.path.join(tmp, "sharded.tsv"), "rb").read() == open(os.path.join(tmp, "single.tsv"), "rb").read()

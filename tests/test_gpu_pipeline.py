@@ -48,8 +48,8 @@ def test_call_mods_cli_1k_rows_batch32(small_weights, tmp_path):
     _write_feature_tsv(tsv, feats, reads)
     W.save_weights(wfile, small_weights)
     assert main(["call_mods", "-i", tsv, "-m", wfile, "-o", out_gpu, "-b", "32", "--nproc", "1", "--is_gpu", "yes"]) == 0
-    cm.call_mods(tsv, wfile, out_cpu, 17, 360, 32, 0.001, 2, 1, False, True, True, True, (50,),
-                 engine=OracleEngine(small_weights))
+    cm.call_mods(tsv, wfile, out_cpu, 17, 360, 32, 0.001, 2, 1, False, True, True, True, None,
+                 engine=OracleEngine(small_weights), f5_batch_num=50)
     g = [l.rstrip("\n").split("\t") for l in open(out_gpu)]
     c = [l.rstrip("\n").split("\t") for l in open(out_cpu)]
     assert len(g) == len(c) == n

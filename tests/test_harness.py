@@ -77,7 +77,7 @@ def test_call_mods_end_to_end_file(cases, tmp_path):
         f.write("\n".join(case["tsv_rows"]) + "\n")
     eng = ReplayEngine(case["session_calls"])
     n = cm.call_mods(path, "unused", out, 17, 360, case["batch_size"], 0.001, 2, 1, False, True, True, True,
-                     (case["f5_batch_num"],), engine=eng)
+                     None, engine=eng, f5_batch_num=case["f5_batch_num"])
     expect = [r for o in case["outputs"] for r in o["pred_str"]]
     assert n == len(expect)
     assert open(out).read().splitlines() == expect
@@ -139,7 +139,9 @@ def test_fast5_directory_mode(tmp_path, monkeypatch):
             return act, np.argmax(act, axis=1)
 
     out = str(tmp_path / "r.tsv")
-    f5_args = (2, True, "RawGenomeCorrected_000", "BaseCalled_template", True, "mad", "CG", 0, 1, None, None)
+    # the reference's layout (deepsignal.py:83-84): (is_recursive, corrected_group, basecall_subgroup, reference_path,
+    # is_dna, normalize_method, motifs, mod_loc, methy_label, f5_batch_num, position_file)
+    f5_args = (True, "RawGenomeCorrected_000", "BaseCalled_template", None, True, "mad", "CG", 0, 1, 2, None)
     n = cm.call_mods(str(d), "unused", out, 17, 360, 16, 0.001, 2, 1, False, True, True, True, f5_args, engine=Eng())
     rows = [l.split("\t") for l in open(out).read().splitlines()]
     case = g["cases"][1]                                      # same settings, no reference genome -> pos_in_strand = -1
@@ -161,7 +163,36 @@ def test_fast5_directory_mode_with_extraction_workers(tmp_path, capsys):
             raise AssertionError("no site should reach the engine")
 
     out = str(tmp_path / "r.tsv")
-    f5_args = (2, True, "RawGenomeCorrected_000", "BaseCalled_template", True, "mad", "CG", 0, 1, None, None)
+    # the reference's layout (deepsignal.py:83-84): (is_recursive, corrected_group, basecall_subgroup, reference_path,
+    # is_dna, normalize_method, motifs, mod_loc, methy_label, f5_batch_num, position_file)
+    f5_args = (True, "RawGenomeCorrected_000", "BaseCalled_template", None, True, "mad", "CG", 0, 1, 2, None)
     n = cm.call_mods(str(d), "unused", out, 17, 360, 16, 0.001, 2, 4, False, True, True, True, f5_args, engine=Eng())
     assert n == 0 and open(out).read() == ""
     assert "7 of 7 fast5 files failed" in capsys.readouterr().out
+
+
+def test_f5_args_is_the_references_tuple():
+    """call_mods takes f5_args in the reference's order (deepsignal.py:83-84, call_modifications.py:428-429); a tuple in
+    any other layout must fail loudly instead of mis-assigning fields."""
+    import pytest
+    ref = (True, "RawGenomeCorrected_000", "BaseCalled_template", "/ref.fa", True, "zscore", "CG,CHG", 1, 1, 7, "/pos.txt")
+    f5 = cm._unpack_f5_args(ref)
+    assert (f5.is_recursive, f5.reference_path, f5.normalize_method, f5.motifs, f5.mod_loc, f5.f5_batch_num,
+            f5.position_file) == (True, "/ref.fa", "zscore", "CG,CHG", 1, 7, "/pos.txt")
+    assert cm._unpack_f5_args(ref, f5_batch_num=3).f5_batch_num == 3
+    assert cm._unpack_f5_args(None).f5_batch_num == 50                    # CLI default, deepsignal.py:243
+    with pytest.raises(ValueError):
+        cm._unpack_f5_args((50,))
+    with pytest.raises(ValueError):                                        # round 1's layout: f5_batch_num first
+        cm._unpack_f5_args((2, True, "RawGenomeCorrected_000", "BaseCalled_template", True, "mad", "CG", 0, 1, None, None))
+
+
+def test_cli_builds_the_references_f5_args(monkeypatch):
+    from deepsignal_amd import deepsignal as cli
+    seen = {}
+    monkeypatch.setattr(cm, "call_mods", lambda *a, **k: seen.update(args=a, kw=k))
+    cli.main(["call_mods", "-i", "x", "-m", "w", "-o", "o", "--f5_batch_num", "9", "--reference_path", "ref.fa",
+              "--positions", "p.txt", "--normalize_method", "zscore"])
+    f5 = cm._unpack_f5_args(seen["args"][13])
+    assert (f5.f5_batch_num, f5.reference_path, f5.position_file, f5.normalize_method, f5.methy_label) == \
+        (9, "ref.fa", "p.txt", "zscore", 1)

@@ -21,7 +21,7 @@ for prec in precisions:
     for native in ((False, True) if prec == "fp32" and n <= 40000 else (True,)):
         for f5 in (50, 400):
             t0 = time.perf_counter()
-            cm.call_mods(path, "x", path + ".out%d" % native, 17, 360, 512, 0.001, 2, 1, True, True, True, True, (f5,), engine=eng, native_io=native)
+            cm.call_mods(path, "x", path + ".out%d" % native, 17, 360, 512, 0.001, 2, 1, True, True, True, True, None, engine=eng, native_io=native, f5_batch_num=f5)
             dt = time.perf_counter() - t0
             print("%s native_io=%s f5_batch_num=%d: %.2f s, %.0f sites/s end to end (usable cores 16 of %d)" % (prec, native, f5, dt, n / dt, os.cpu_count()))
     if prec == "fp32" and n <= 40000:

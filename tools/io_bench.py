@@ -23,8 +23,8 @@ class NullEngine:
         act = np.full((k, 2), 0.25, np.float32); act[:, 1] = 0.6
         return act, np.ones(k, np.int32)
 
-t0 = time.perf_counter(); cm.call_mods(path, "x", path + ".py.out", 17, 360, 512, 0.001, 2, 1, False, True, True, True, (50,), engine=NullEngine(), native_io=False); tp = time.perf_counter() - t0
-t0 = time.perf_counter(); cm.call_mods(path, "x", path + ".nat.out", 17, 360, 512, 0.001, 2, 1, False, True, True, True, (50,), engine=NullEngine(), native_io=True); tn = time.perf_counter() - t0
+t0 = time.perf_counter(); cm.call_mods(path, "x", path + ".py.out", 17, 360, 512, 0.001, 2, 1, False, True, True, True, None, engine=NullEngine(), native_io=False); tp = time.perf_counter() - t0
+t0 = time.perf_counter(); cm.call_mods(path, "x", path + ".nat.out", 17, 360, 512, 0.001, 2, 1, False, True, True, True, None, engine=NullEngine(), native_io=True); tn = time.perf_counter() - t0
 assert open(path + ".py.out").read() == open(path + ".nat.out").read()
 print("file %.1f MB, %d rows, cores %d" % (mb, n, os.cpu_count()))
 print("python reader+formatter: %.2f s = %.0f sites/s (%.1f MB/s)" % (tp, n / tp, mb / tp))
