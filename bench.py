@@ -6,10 +6,22 @@ One "step" = one pass of the hot path (ds_forward_device) over one batch of 512 
 (torch.distributed / RCCL), sites sharded by read with a full weight replica per rank (weak
 scaling, no data-path collective); the only collective is the final result gather to rank 0.
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
-  roofline      the dominant kernel's achieved TFLOP/s (algorithmic 2*M*N*K per launch / HIP-event
-                duration per launch) against the fp32 MFMA peak
-  cpu_baseline  the CPU oracle (oracle/ds_oracle.c, "port") timed on this box's host cores
+`python bench.py --gpus N` with N > 1 and no launcher environment starts its own ranks: the parent spawns
+`python -m torch.distributed.run --nproc-per-node N ... bench.py` as a CHILD process before it has imported torch or
+touched the GPU, and exits with the child's code (a process that has initialised the GPU is never re-exec'ed).
+`--dry-run` replaces the engine by a stub and RCCL by gloo: the launcher / barrier / gather / JSON plumbing runs on a
+CPU-only box (tests/test_bench_launcher.py); its line carries "dry_run": true and is not a measurement.
+
+The timed region is repeated `--windows` times (default 5), each window = EXACTLY K steps bracketed by barrier +
+synchronize on both sides, max over ranks; `value` / `ms_per_step` are the MEDIAN window, `windows` lists them all.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with these extra objects:
+  roofline        the dominant kernel's achieved TFLOP/s (algorithmic 2*M*N*K per launch / HIP-event
+                  duration per launch) against the fp32 MFMA peak
+  cpu_baseline    the CPU oracle (oracle/ds_oracle.c, "port") timed on this box's host cores
+  pcie_inclusive  the same 512-site batches from HOST memory through ds_submit / ds_wait (H2D + kernels + D2H,
+                  SURVEY.md 8d's definition of the metric) -- reported beside `value`, never as it
+  e2e_tsv         feature TSV -> result TSV through call_mods (native reader + formatter + the engine)
 """
 import argparse
 import json
@@ -101,7 +113,9 @@ def pmc_traffic(kernel_name):
     """HBM bytes per launch of `kernel_name` from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE are
     collected in separate runs of this same command and corrected as MI355X_MICROARCH.md prescribes; see
     tools/pmc_traffic.py). Counters cannot be read from inside the process, so this is the recorded figure."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    import glob
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_traffic.json")))
+    path = cands[-1] if cands else os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
     norm = lambda s: s.replace(" ", "").replace(",false>", ">").replace(",true>", ",bf16>")
     try:
         rec = json.load(open(path))
@@ -109,10 +123,104 @@ def pmc_traffic(kernel_name):
             if norm(name) == norm(kernel_name):
                 return {"traffic": round(v["hbm_bytes_per_launch"]), "traffic_unit": "B/launch",
                         "traffic_fetch": round(v["fetch_bytes_per_launch"]), "traffic_write": round(v["write_bytes_per_launch"]),
-                        "traffic_source": "profiles/r01_pmc_traffic.json (" + rec["source"] + ")"}
+                        "traffic_source": "profiles/" + os.path.basename(path) + " (" + rec["source"] + ")"}
     except (OSError, ValueError, KeyError):
         pass
     return {"traffic": None}
+
+
+class _DryRunEngine:
+    """--dry-run only: no forward is executed; outputs are filled with a constant so the gather has something to move."""
+    slots = 8
+
+    def __init__(self, torch):
+        self.torch = torch
+
+    def run_device(self, n, dk, dm, ds_, dn, dg, d_act, d_pred):
+        pass
+
+    def sync(self):
+        pass
+
+    def close(self):
+        pass
+
+
+def self_launch(args):
+    """--gpus N without a launcher environment: start N fresh ranks as a CHILD process tree. Nothing in this (parent)
+    process has imported torch or made a HIP call at this point, and the parent never execs: it waits for the child
+    and returns its exit code."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: required for RCCL across processes on this pool
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def pcie_inclusive(eng, feats, steps, batch):
+    """SURVEY.md 8d's metric boundary: the same batches from HOST memory through the asynchronous host boundary
+    (ds_submit stages into pinned memory and enqueues H2D + forward + D2H; ds_wait hands the 12 B/site back), as many
+    batches in flight as the engine has slots. Median of 3 windows of `steps` batches."""
+    keys = ("kmer", "means", "stds", "sanums", "signals")
+    npool = feats["kmer"].shape[0] // batch
+    pool = [tuple(feats[k][b * batch:(b + 1) * batch] for k in keys) for b in range(npool)]
+    rates = []
+    for rep in range(4):                      # rep 0 = warm-up (pinned staging is allocated on first use)
+        pending = []
+        t0 = time.perf_counter()
+        for i in range(steps):
+            if len(pending) == eng.slots:
+                eng.wait(pending.pop(0))
+            pending.append(eng.submit(*pool[i % npool]))
+        for t in pending:
+            eng.wait(t)
+        if rep:
+            rates.append(steps * batch / (time.perf_counter() - t0))
+    rates.sort()
+    return {"value": round(rates[len(rates) // 2], 1), "unit": "sites/s", "min": round(rates[0], 1), "max": round(rates[-1], 1),
+            "boundary": "ds_submit / ds_wait from host buffers: pinned staging + H2D (1,712 B/site) + forward + D2H "
+                        "(12 B/site), %d batches of %d sites per window, %d in flight" % (steps, batch, eng.slots)}
+
+
+def e2e_tsv(eng, feats, rows, batch):
+    """Feature TSV -> result TSV through the product's call_mods (native reader on the usable host cores, engine through
+    submit / wait, native row formatter): what a user's `deepsignal call_mods -i features.tsv` sustains on this box."""
+    import tempfile
+    from deepsignal_amd import call_modifications as cm
+    from deepsignal_amd.utils.process_utils import code2base_dna
+    nuniq = min(rows, feats["kmer"].shape[0])
+    tmpdir = tempfile.mkdtemp(prefix="ds_bench_")
+    path = os.path.join(tmpdir, "features.tsv")
+    tails = []
+    for i in range(nuniq):          # columns 7..12 of a row; the first six are cheap and written per copy below
+        tails.append("\t".join(["".join(code2base_dna[int(c)] for c in feats["kmer"][i]),
+                                ",".join("%.6f" % x for x in feats["means"][i]), ",".join("%.6f" % x for x in feats["stds"][i]),
+                                ",".join(str(int(x)) for x in feats["sanums"][i]),
+                                ",".join("%.6f" % x for x in feats["signals"][i]), "1"]))
+    with open(path, "w") as f:
+        for i in range(rows):
+            f.write("chr1\t%d\t+\t%d\tread_%06d\tt\t%s\n" % (1000 + i, i, i // 20, tails[i % nuniq]))
+    try:
+        out = os.path.join(tmpdir, "calls.tsv")
+        cm.call_mods(path, "unused", out, 17, 360, batch, 0.001, 2, 1, True, True, True, True, None, engine=eng)   # warm
+        t0 = time.perf_counter()
+        n = cm.call_mods(path, "unused", out, 17, 360, batch, 0.001, 2, 1, True, True, True, True, None, engine=eng)
+        dt = time.perf_counter() - t0
+        assert n == rows and sum(1 for _ in open(out)) == rows
+        size = os.path.getsize(path)
+    finally:
+        import shutil
+        shutil.rmtree(tmpdir, ignore_errors=True)
+    return {"value": round(rows / dt, 1), "unit": "sites/s", "rows": rows, "input_MB": round(size / 1e6, 1),
+            "host_cores": effective_cores(),
+            "path": "call_mods(feature TSV -> result TSV): native reader + ds_submit / ds_wait + native formatter, "
+                    "20 sites per read, f5_batch_num 50"}
 
 
 def main():
@@ -120,12 +228,19 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=400)
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--windows", type=int, default=5, help="repetitions of the timed K-step window (median reported)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile-pass", action="store_true")
     ap.add_argument("--no-standalone-pass", action="store_true",
                     help="skip pass C (every launch on one stream); used for the rocprofv3 cross-check, whose per-kernel "
                          "averages would otherwise blend co-resident and stand-alone launches")
+    ap.add_argument("--no-host-path", action="store_true", help="skip the pcie_inclusive and e2e_tsv legs")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launcher / collective / JSON plumbing only (stub engine, gloo, CPU): NOT a measurement")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))            # fresh child ranks; this parent never touched the GPU
 
     import numpy as np
     import torch
@@ -133,24 +248,31 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ..."
-                             % (args.gpus, args.gpus))
+        raise SystemExit("bench.py --gpus %d was started under a launcher with WORLD_SIZE=%d" % (args.gpus, world))
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    dev = torch.device("cuda", local_rank)
-    torch.cuda.set_device(dev)
+        if args.dry_run:
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cpu") if args.dry_run else torch.device("cuda", local_rank)
+    if not args.dry_run:
+        torch.cuda.set_device(dev)
+    dev_sync = (lambda: None) if args.dry_run else torch.cuda.synchronize
 
     from deepsignal_amd import spec, synth, weights as W
-    from deepsignal_amd.engine import Engine
 
-    w = W.random_weights(seed=W.WEIGHT_SEED)          # TF-initializer style, randomised BN
-    eng = Engine(device=local_rank, max_batch=BATCH)
-    eng.load_weights(w)
+    if args.dry_run:
+        w = None
+        eng = _DryRunEngine(torch)
+    else:
+        from deepsignal_amd.engine import Engine
+        w = W.random_weights(seed=W.WEIGHT_SEED)          # TF-initializer style, randomised BN
+        eng = Engine(device=local_rank, max_batch=BATCH)
+        eng.load_weights(w)
 
     # this rank's shard: its own reads (20 sites per read), NPOOL distinct batches resident in HBM
     NPOOL = 8
@@ -168,33 +290,37 @@ def main():
 
     def fence():
         eng.sync()
-        torch.cuda.synchronize()
+        dev_sync()
         if dist is not None:
             dist.barrier()
-            torch.cuda.synchronize()
+            dev_sync()
 
     for i in range(Wm):
         step(i, 0)
-    fence()
-    t0 = time.perf_counter()
-    for i in range(K):
-        step(i, i)
-    eng.sync()
-    if dist is not None:
-        # the path's only exchange: gather f32[n,2] + i32[n] (12 B/site) to the writer rank over RCCL
-        from deepsignal_amd import sharding
-        gidx = torch.arange(rank, world * K * BATCH, world, dtype=torch.int64, device=dev)   # this rank's global site ids
-        g_act, g_pred = sharding.gather_results(out_act.reshape(-1, 2), out_pred.reshape(-1), gidx, dist, dst=0, device=dev,
-                                                as_numpy=False)
-        if rank == 0:
-            assert g_act.shape[0] == world * K * BATCH
-    fence()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    windows = []
+    for rep in range(max(1, args.windows)):
+        fence()
+        t0 = time.perf_counter()
+        for i in range(K):
+            step(i, i)
+        eng.sync()
+        if dist is not None:
+            # the path's only exchange: gather f32[n,2] + i32[n] (12 B/site) to the writer rank over RCCL
+            from deepsignal_amd import sharding
+            gidx = torch.arange(rank, world * K * BATCH, world, dtype=torch.int64, device=dev)   # this rank's global site ids
+            g_act, g_pred = sharding.gather_results(out_act.reshape(-1, 2), out_pred.reshape(-1), gidx, dist, dst=0,
+                                                    device=dev, as_numpy=False)
+            if rank == 0:
+                assert g_act.shape[0] == world * K * BATCH
+        fence()
+        el = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        windows.append(el)
     assert bool(torch.isfinite(out_act).all())
+    elapsed = sorted(windows)[len(windows) // 2]          # median window
 
     result = {
         "metric": "CpG sites/sec (batch=512, k=17, sig=360)",
@@ -205,7 +331,21 @@ def main():
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": WORKLOAD, "batch": BATCH, "kmer_len": 17, "signal_len": 360,
                    "sharding": "by read, %d rank(s), full weight replica per GPU" % world},
+        "windows": {"n": len(windows), "steps_each": K, "statistic": "median",
+                    "sites_per_s": [round(world * K * BATCH / x, 1) for x in windows] if K else [],
+                    "min": round(world * K * BATCH / max(windows), 1) if K else 0.0,
+                    "max": round(world * K * BATCH / min(windows), 1) if K else 0.0},
     }
+    if args.dry_run:
+        result.update({"dry_run": True, "data": "none (launcher dry run: stub engine, gloo, no forward executed)",
+                       "value": 0.0, "ms_per_step": 0.0})
+        result["windows"].update({"sites_per_s": [], "min": 0.0, "max": 0.0})
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps(result))
+        return
 
     if rank == 0 and not args.no_profile_pass:
         # HIP events on the engine's own streams, eager replay of the same K steps.
@@ -262,6 +402,9 @@ def main():
                                           if k["name"] in alone else None}
                              for k in ks}
         result["stages_us_per_step"] = stages
+    if rank == 0 and world == 1 and not args.no_host_path:
+        result["pcie_inclusive"] = pcie_inclusive(eng, feats, max(K, 64), BATCH)
+        result["e2e_tsv"] = e2e_tsv(eng, feats, 40960, BATCH)
     eng.close()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(w)
