@@ -181,3 +181,26 @@ def test_model_path_resolution(tmp_path):
     assert cm.load_model_weights(dsw, 5, 40, 2) is None          # the engine reads weight files itself
     with pytest.raises(FileNotFoundError):
         cm.load_model_weights(str(tmp_path / "missing.ckpt"), 5, 40, 2)
+
+
+def test_importer_reads_a_checkpoint_it_did_not_write(tmp_path):
+    """tests/hand_checkpoint.py assembles the index table, the proto bytes and the checksums itself (pure Python
+    CRC-32C included); the importer must hand back exactly the tensors that went in, ignore the optimizer slots and
+    verify every checksum -- a flipped data byte is caught."""
+    from hand_checkpoint import hand_checkpoint
+    kw = dict(kmer_len=5, signal_len=40)
+    w = W.random_weights(seed=9, lstm_bias_std=0.1, **kw)
+    small = {k: v for k, v in w.items()}
+    tensors = dict(small)
+    tensors["dense/kernel/Adam"] = np.zeros_like(w["dense/kernel"])
+    tensors["beta1_power"] = np.array(0.9, np.float32)
+    prefix = str(tmp_path / "hand.ckpt")
+    hand_checkpoint(prefix, tensors, native_crc=False)
+    got = T.checkpoint_to_weights(prefix, **kw)
+    assert list(got) == [n for n, _ in spec.tensor_table(**kw)]
+    assert all(np.array_equal(got[k], w[k]) and got[k].shape == w[k].shape for k in w)
+    raw = bytearray(open(T.shard_path(prefix, 0, 1), "rb").read())
+    raw[100] ^= 0x10
+    open(T.shard_path(prefix, 0, 1), "wb").write(bytes(raw))
+    with pytest.raises(ValueError, match="checksum"):
+        T.checkpoint_to_weights(prefix, **kw)

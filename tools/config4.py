@@ -6,68 +6,100 @@
 20 sites per read, reads dealt round-robin to the ranks (deepsignal_amd.sharding), every rank runs its shard through
 ds_forward_device in `batch`-site forwards from a resident pool of synthetic batches (the shard is far larger than the
 pool; features repeat, work does not), results stay on the device, and the run ends with ONE gather of
-f32[n_i,2] + i32[n_i] to rank 0. Strong scaling: total work is fixed. Prints one JSON line on rank 0."""
+f32[n_i,2] + i32[n_i] to rank 0. Strong scaling: total work is fixed. Prints one JSON line on rank 0.
+
+`run_shard()` is the same path as a function (tests/test_gpu_configs.py drives it at >= 1 M sites on one GPU and checks
+sampled sites against the oracle)."""
 import argparse, json, os, sys, time
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
-import torch
-from deepsignal_amd import sharding, synth, weights as W
-from deepsignal_amd.engine import Engine
 
-ap = argparse.ArgumentParser()
-ap.add_argument("--sites", type=int, default=10_000_000)
-ap.add_argument("--batch", type=int, default=512)
-ap.add_argument("--precision", default="fp32")
-args = ap.parse_args()
-rank, local, world = int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
-dist = None
-if world > 1:
-    import torch.distributed as dist
-    torch.cuda.set_device(local)
-    dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-dev = torch.device("cuda", local)
-torch.cuda.set_device(dev)
-B = args.batch
-# shard by read: read r (sites 20r .. 20r+19) belongs to rank r % world
-nreads = args.sites // 20
-my_reads = np.arange(rank, nreads, world, dtype=np.int64)
-n_mine = int(my_reads.size) * 20
-eng = Engine(device=local, max_batch=B, precision=args.precision)
-eng.load_weights(W.random_weights(seed=W.WEIGHT_SEED))
-NPOOL = max(1, 4096 // B)
-f = synth.synthetic_features(NPOOL * B, seed=synth.FEATURE_SEED + rank)
-keys = ("kmer", "means", "stds", "sanums", "signals")
-d = {k: torch.from_numpy(f[k]).to(dev) for k in keys}
-nsteps = (n_mine + B - 1) // B
-out_act = torch.zeros((nsteps * B, 2), dtype=torch.float32, device=dev)
-out_pred = torch.zeros((nsteps * B,), dtype=torch.int32, device=dev)
+KEYS = ("kmer", "means", "stds", "sanums", "signals")
+SITES_PER_READ = 20
 
-def step(i):
-    b = (i % NPOOL) * B
-    eng.run_device(B, *(d[k][b:b + B].data_ptr() for k in keys), out_act[i * B:].data_ptr(), out_pred[i * B:].data_ptr())
 
-for i in range(min(8, nsteps)): step(i)
-eng.sync(); torch.cuda.synchronize()
-if dist is not None: dist.barrier(); torch.cuda.synchronize()
-t0 = time.perf_counter()
-for i in range(nsteps): step(i)
-eng.sync()
-t_compute = time.perf_counter() - t0
-# global site index of my j-th site: read my_reads[j // 20], position j % 20
-gidx = (torch.from_numpy(my_reads).to(dev).repeat_interleave(20) * 20 + torch.arange(20, device=dev).repeat(my_reads.size))
-g_act, g_pred = sharding.gather_results(out_act[:n_mine], out_pred[:n_mine], gidx, dist, dst=0, device=dev, as_numpy=False)
-torch.cuda.synchronize()
-if dist is not None: dist.barrier()
-elapsed = time.perf_counter() - t0
-if dist is not None:
-    t = torch.tensor([elapsed, t_compute], dtype=torch.float64, device=dev)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed, t_compute = float(t[0]), float(t[1])
-if rank == 0:
-    total = nreads * 20
-    if world > 1: assert g_act.shape[0] == total and bool(torch.isfinite(g_act).all())
-    print(json.dumps({"config": "configs[3]: per-read shard of %d synthetic sites, %d GPU(s), batch %d, %s" % (total, world, B, args.precision),
-                      "n_gpus": world, "sites": total, "seconds": round(elapsed, 3), "seconds_compute_max_rank": round(t_compute, 3),
-                      "sites_per_s": round(total / elapsed, 1), "gather_bytes": total * 12}))
-eng.close()
-if dist is not None: dist.destroy_process_group()
+def pool_features(pool_sites, rank=0):
+    from deepsignal_amd import synth
+    return synth.synthetic_features(pool_sites, seed=synth.FEATURE_SEED + rank)
+
+
+def run_shard(sites, batch=512, precision="fp32", weights=None, pool_sites=4096, dist=None, rank=0, local=0, world=1):
+    """This rank's reads of a `sites`-site job through the resident-input boundary, then the one result gather.
+    Returns (record, gathered act, gathered pred, my_reads); the gathered tensors are on rank 0's device (None elsewhere)."""
+    import torch
+    from deepsignal_amd import sharding, weights as W
+    from deepsignal_amd.engine import Engine
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    B = batch
+    # shard by read: read r (sites 20r .. 20r+19) belongs to rank r % world
+    nreads = sites // SITES_PER_READ
+    my_reads = np.arange(rank, nreads, world, dtype=np.int64)
+    n_mine = int(my_reads.size) * SITES_PER_READ
+    eng = Engine(device=local, max_batch=B, precision=precision)
+    eng.load_weights(weights if weights is not None else W.random_weights(seed=W.WEIGHT_SEED))
+    NPOOL = max(1, pool_sites // B)
+    f = pool_features(NPOOL * B, rank)
+    d = {k: torch.from_numpy(f[k]).to(dev) for k in KEYS}
+    nsteps = (n_mine + B - 1) // B
+    out_act = torch.zeros((nsteps * B, 2), dtype=torch.float32, device=dev)
+    out_pred = torch.zeros((nsteps * B,), dtype=torch.int32, device=dev)
+
+    def step(i):
+        b = (i % NPOOL) * B
+        eng.run_device(B, *(d[k][b:b + B].data_ptr() for k in KEYS), out_act[i * B:].data_ptr(), out_pred[i * B:].data_ptr())
+
+    for i in range(min(8, nsteps)):
+        step(i)
+    eng.sync(); torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(nsteps):
+        step(i)
+    eng.sync()
+    t_compute = time.perf_counter() - t0
+    # global site index of my j-th site: read my_reads[j // 20], position j % 20
+    gidx = (torch.from_numpy(my_reads).to(dev).repeat_interleave(SITES_PER_READ) * SITES_PER_READ
+            + torch.arange(SITES_PER_READ, device=dev).repeat(my_reads.size))
+    g_act, g_pred = sharding.gather_results(out_act[:n_mine], out_pred[:n_mine], gidx, dist, dst=0, device=dev, as_numpy=False)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed, t_compute], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed, t_compute = float(t[0]), float(t[1])
+    eng.close()
+    total = nreads * SITES_PER_READ
+    rec = {"config": "configs[3]: per-read shard of %d synthetic sites, %d GPU(s), batch %d, %s" % (total, world, B, precision),
+           "n_gpus": world, "sites": total, "seconds": round(elapsed, 3), "seconds_compute_max_rank": round(t_compute, 3),
+           "sites_per_s": round(total / elapsed, 1), "gather_bytes": total * 12, "pool_sites": NPOOL * B}
+    return rec, g_act, g_pred, my_reads
+
+
+def main():
+    import torch
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--sites", type=int, default=10_000_000)
+    ap.add_argument("--batch", type=int, default=512)
+    ap.add_argument("--precision", default="fp32")
+    args = ap.parse_args()
+    rank, local, world = int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    rec, g_act, g_pred, _ = run_shard(args.sites, args.batch, args.precision, dist=dist, rank=rank, local=local, world=world)
+    if rank == 0:
+        if world > 1:
+            assert g_act.shape[0] == rec["sites"] and bool(torch.isfinite(g_act).all())
+        print(json.dumps(rec))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
