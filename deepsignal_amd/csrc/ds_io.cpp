@@ -60,6 +60,7 @@ bool parse_list(const char* p, const char* e, int count, Out* out, bool as_int)
         if (p >= e) return false;
         if (as_int) {
             long v = 0;
+            if (*p == '+') ++p;
             auto r = std::from_chars(p, e, v);
             if (r.ec != std::errc()) return false;
             out[i] = (Out)v;
@@ -68,7 +69,18 @@ bool parse_list(const char* p, const char* e, int count, Out* out, bool as_int)
             double v = 0;
             if (*p == '+') ++p;
             auto r = std::from_chars(p, e, v);
-            if (r.ec != std::errc()) return false;
+            if (r.ec == std::errc::result_out_of_range) {
+                // Python's float() (the reference reader, call_modifications.py:78-85) gives +-inf for 1e400 and
+                // 0.0 for 1e-400 instead of failing: same here (strtod on a bounded copy of the token)
+                char tmp[64];
+                const size_t len = (size_t)(r.ptr - p);
+                if (len >= sizeof tmp) return false;
+                memcpy(tmp, p, len);
+                tmp[len] = 0;
+                v = strtod(tmp, nullptr);
+            } else if (r.ec != std::errc()) {
+                return false;
+            }
             out[i] = (Out)(float)v;                       // float64 -> float32, as the TF feed does
             p = r.ptr;
         }
@@ -91,6 +103,8 @@ int base_code(char c)
 // one row -> slot i of the batch arrays; returns false on a malformed row
 bool parse_row(ds_tsv* t, size_t i, const char* b, const char* e, int64_t* info_len)
 {
+    // col[c] = start of column c; col[12] = one past the tab (or line end) that closes column 11. Columns beyond the
+    // 12th are ignored, as the reference reader ignores words[12:] (call_modifications.py:47-57).
     const char* col[13];
     col[0] = b;
     int nc = 1;
@@ -100,8 +114,8 @@ bool parse_row(ds_tsv* t, size_t i, const char* b, const char* e, int64_t* info_
         col[nc++] = q + 1;
         p = q + 1;
     }
-    if (nc != 12) return false;
-    col[12] = e + 1;
+    if (nc < 12) return false;
+    if (nc == 12) col[12] = e + 1;
     auto cb = [&](int c) { return col[c]; };
     auto ce = [&](int c) { return col[c + 1] - 1; };
     const int K = t->kmer_len, S = t->signal_len;
@@ -238,7 +252,7 @@ int64_t ds_tsv_next(ds_tsv* t, int32_t max_reads)
     const char* prev_id = nullptr;
     size_t prev_len = 0;
     int reads = 0;
-    while (p < end) {
+    while (p && p < end) {
         const char* nl = (const char*)memchr(p, '\n', (size_t)(end - p));
         const char* le = nl ? nl : end;
         const char* ltrim = le;
@@ -261,7 +275,7 @@ int64_t ds_tsv_next(ds_tsv* t, int32_t max_reads)
         t->lines.emplace_back(p, ltrim);
         p = nl ? nl + 1 : end;
     }
-    t->pos = (size_t)(p - t->data);
+    t->pos = p ? (size_t)(p - t->data) : 0;
     const size_t n = t->lines.size();
     if (n == 0) return 0;
     const int K = t->kmer_len, S = t->signal_len;

@@ -77,6 +77,26 @@ def test_independent_torch_statement_agrees(gold, gold_weights):
         assert np.abs(v - t_taps[k]).max() <= 1e-6 * max(1.0, np.abs(v).max()), k
 
 
+def test_third_statement_in_nn_modules_agrees(gold, gold_weights):
+    """oracle/nn_statement.py: torch.nn.LSTM with the TF kernel's gate blocks permuted (i,j,f,o -> i,f,g,o) and
+    forget_bias folded into the bias, nn.Conv1d(padding="same"), nn.BatchNorm1d(eps=1e-3).eval(), ceil_mode max-pools,
+    nn.AvgPool1d(count_include_pad=False), nn.Linear -- library code neither other statement goes through. All three
+    must give the same numbers (float64, < 1 fp32 ulp on every tensor it taps) and the committed golden outputs."""
+    from oracle import nn_statement
+    feats = _feats(gold)
+    o_act, o_pred, o_taps = oracle.forward(gold_weights, feats, "f64", taps=True)
+    n_act, n_pred, n_taps = nn_statement.forward(gold_weights, feats, torch.float64, True)
+    assert np.abs(o_act - n_act).max() < 1e-7 and np.array_equal(o_pred, n_pred)
+    assert np.abs(n_act - gold["act"]).max() < 1e-7 and np.array_equal(n_pred, gold["pred"])
+    assert set(n_taps) >= {"lstm_fw_l2", "lstm_bw_l2", "stem_pool", "module1", "module4", "module9", "module11", "fc1"}
+    for k, v in n_taps.items():
+        assert np.abs(v - o_taps[k]).max() <= 1e-6 * max(1.0, np.abs(o_taps[k]).max()), k
+    # fp32 library kernels (oneDNN / MKL, fused LSTM cell) against the fp32 C oracle: summation order is all that differs
+    f_act, f_pred = nn_statement.forward(gold_weights, feats, torch.float32)
+    c_act, c_pred = oracle.forward(gold_weights, feats, "f32")
+    assert np.abs(f_act - c_act).max() < 1e-5
+
+
 def test_site_independence_and_batch_order(gold, gold_weights):
     """Every site is an independent forward (no cross-site state): permuting / slicing the batch
     permutes / slices the output bit-exactly."""
