@@ -97,7 +97,8 @@ def test_config4_one_million_site_shard_on_one_gpu(small_weights):
     rec, g_act, g_pred, my_reads = config4.run_shard(sites, batch=B, precision="fp32", weights=small_weights, pool_sites=pool)
     total = (sites // 20) * 20
     assert rec["sites"] == total and rec["n_gpus"] == 1 and my_reads.size == sites // 20
-    act, pred = g_act.cpu().numpy(), g_pred.cpu().numpy()
+    to_np = lambda x: x.cpu().numpy() if hasattr(x, "cpu") else np.asarray(x)      # world 1 returns host arrays
+    act, pred = to_np(g_act), to_np(g_pred)
     assert act.shape == (total, 2) and pred.shape == (total,)
     assert np.isfinite(act).all() and (act > 0).all() and (act < 1).all()
     assert np.array_equal(pred, np.argmax(act, axis=1).astype(np.int32))
