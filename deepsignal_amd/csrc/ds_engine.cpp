@@ -43,7 +43,7 @@ struct PackedGemm {      // device-resident packed weights of one GEMM
     int K = 0, N = 0;
 };
 
-enum OpKind { OP_GEMM, OP_STEM1, OP_MAXPOOL, OP_AVGPOOL, OP_HEAD, OP_FUSED, OP_PACKEV };
+enum OpKind { OP_GEMM, OP_STEM1, OP_MAXPOOL, OP_AVGPOOL, OP_HEAD, OP_FUSED, OP_PACKEV, OP_LSTM };
 
 struct Op {
     OpKind kind;
@@ -67,7 +67,7 @@ struct Op {
 
 // per-kernel accumulators (one entry per __global__ function / template instantiation)
 enum KernelClass { K_GEMM_CONV = 0, K_GEMM_FC, K_GEMM_LSTM, K_GEMM_CONV_WIDE, K_GEMM_CONV_POOL, K_GEMM_FC_DENSE, K_GEMM_LSTM_DENSE, K_FUSED1, K_FUSED2, K_FUSED3, K_STEM1, K_MAXPOOL, K_AVGPOOL, K_HEAD,
-                   K_GEMM_BCONV, K_GEMM_BCONV_POOL, K_GEMM_BFC, K_GEMM_BFC_DENSE, K_PACKEV, K_GEMM_BLSTM, K_GEMM_BLSTM_DENSE, K_FUSEDB1, K_FUSEDB2, K_FUSEDB3, K_GEMM_LSTM_T, K_GEMM_LSTM_T_DENSE, K_GEMM_BLSTM_T, K_GEMM_BLSTM_T_DENSE, K_COUNT };
+                   K_GEMM_BCONV, K_GEMM_BCONV_POOL, K_GEMM_BFC, K_GEMM_BFC_DENSE, K_PACKEV, K_GEMM_BLSTM, K_GEMM_BLSTM_DENSE, K_FUSEDB1, K_FUSEDB2, K_FUSEDB3, K_GEMM_LSTM_T, K_GEMM_LSTM_T_DENSE, K_GEMM_BLSTM_T, K_GEMM_BLSTM_T_DENSE, K_LSTM_CELL1, K_LSTM_CELL2, K_LSTM_CELL4, K_COUNT };
 const char* const kKernelNames[K_COUNT] = {"gemm_kernel<1,2,4,1,0,0,1,1>", "gemm_kernel<1,3,4,1,0,0,2,1>", "gemm_kernel<1,4,4,1,1,0,1,1>",
                                            "gemm_kernel<2,2,2,2,0,0,1,1>", "gemm_kernel<1,2,4,1,0,1,1,1>", "gemm_kernel<1,3,4,1,0,2,2,1>",
                                            "gemm_kernel<1,4,4,1,1,2,1,1>", "inception_fused_kernel<1>",
@@ -79,7 +79,8 @@ const char* const kKernelNames[K_COUNT] = {"gemm_kernel<1,2,4,1,0,0,1,1>", "gemm
                                            "gemm_kernel<1,4,4,1,1,2,3,1,bf16>", "inception_fused_bf16_kernel<1>",
                                            "inception_fused_bf16_kernel<2>", "inception_fused_bf16_kernel<3>",
                                            "gemm_kernel<1,1,4,1,2,0,1,1>", "gemm_kernel<1,1,4,1,2,2,1,1>",
-                                           "gemm_kernel<1,1,4,1,2,0,3,1,bf16>", "gemm_kernel<1,1,4,1,2,2,3,1,bf16>"};
+                                           "gemm_kernel<1,1,4,1,2,0,3,1,bf16>", "gemm_kernel<1,1,4,1,2,2,3,1,bf16>",
+                                           "lstm_cell_kernel<1>", "lstm_cell_kernel<2>", "lstm_cell_kernel<4>"};
 struct KernelStat {
     int64_t launches = 0;
     double total_ms = 0;
@@ -99,6 +100,8 @@ struct Plan {
     int n = 0;
     std::vector<GemmLaunch> launches;     // host copy
     GemmLaunch* d_launches = nullptr;
+    std::vector<LstmLaunch> lstm_launches;   // fp32 BiLSTM diagonals (lstm_cell_kernel)
+    LstmLaunch* d_lstm = nullptr;
     std::vector<Op> ops;                  // merged issue order
     hipGraphExec_t graph = nullptr;
     int64_t uses = 0, last_use = 0;       // ragged tails produce many one-off sizes: graphs are captured for sizes that
@@ -118,8 +121,10 @@ struct Slot {
     float *pool2 = nullptr, *pool3 = nullptr;
     float *tmpA = nullptr, *tmpS = nullptr, *tmpB = nullptr;
     float* sigfeat = nullptr;
-    float* H[2][NLAYER] = {{nullptr}};   // [T][B][256]
-    float* Cst[2][NLAYER] = {{nullptr}}; // [B][256]
+    float* H[2][NLAYER] = {{nullptr}};   // h of every step: fp32 cells [T][m-tiles][32 k-groups][64][4] (MFMA-fragment-major,
+                                         // ds_internal.h LstmCell); bf16-operand cells [T][B][256] bf16 row-major
+    float* Cst[2][NLAYER] = {{nullptr}}; // cell state, same layout as one step of H (fp32)
+    float* hlast[2] = {nullptr, nullptr};   // fp32 cells: row-major [B][256] copy of the top layer's final h (fw t = T-1, bw t = 0)
     float *fc1o = nullptr, *logits = nullptr, *act = nullptr;
     int* pred = nullptr;
     float* joint = nullptr;              // bf16 mode: [B][JP] bf16 FC operand (event features | signal features | zero pad)
@@ -151,6 +156,8 @@ struct ds_handle {
     int fuse_min_tiles = 128; // fused-module grids keep at least this many workgroups when the batch allows it
     bool lstm_bf16 = false;   // DS_PRECISION_BF16_ALL: additionally bf16 h / weight operands in the LSTM matmuls (fp32 accumulate,
                               // gates and cell state; the layer-0 input projection stays an fp32 table lookup)
+    bool lstm_frag = false;   // fp32 BiLSTM cells: lstm_cell_kernel on fragment-major h / c (every mode but DS_PRECISION_BF16_ALL)
+    int Bp32 = 0;             // max_batch rounded up to whole 32-site m-tiles (rows of the fragment-major buffers)
     int JP = 0;           // J rounded up to a whole K chunk (32 bf16)
     bool finalized = false;
     bool debug = false;
@@ -417,15 +424,16 @@ int finalize_weights(ds_handle* h)
                 const int p = pc / 32, i = pc % 32;
                 return kd[(size_t)(row0 + k) * 4 * HID + (i >> 3) * HID + p * 8 + (i & 7)];
             };
-            // both layouts are kept (2 x 11.6 MB fp32): the planner picks the tiling per forward size
-            for (int layout = 0; layout < 2; ++layout) {
+            // fp32 cells (lstm_cell_kernel) read the [gate][8 units] layout only; the bf16-operand cells keep both
+            // layouts (the planner picks the tiling per forward size)
+            for (int layout = h->lstm_frag ? 1 : 0; layout < 2; ++layout) {
                 PackedGemm& pg = layout == 0 ? h->lstm[d][l] : h->lstm_n[d][l];
                 std::function<float(int, int)> wfun = wfun_wide;
                 if (layout == 1) wfun = wfun_t;
                 std::vector<float> packed = h->lstm_bf16 ? pack_b_bf16(K, 4 * HID, wfun) : pack_b(K, 4 * HID, wfun);
                 pg.K = h->lstm_bf16 ? K / 2 : K; pg.N = 4 * HID;
                 if ((rc = upload(h, &pg.Bp, packed))) return rc;
-                if (layout == 0) { if ((rc = upload(h, &pg.bias, bias->data))) return rc; }
+                if (layout == 0 || h->lstm_frag) { if ((rc = upload(h, &pg.bias, bias->data))) return rc; }
                 else pg.bias = h->lstm[d][l].bias;
             }
             if (l == 0) {
@@ -475,7 +483,9 @@ int alloc_workspace(ds_handle* h)
     A(&h->cur->tmpA, B * h->wa * 96); A(&h->cur->tmpS, B * h->wa * 48); A(&h->cur->tmpB, B * h->wa * 64);
     A(&h->cur->sigfeat, B * h->SF);
     for (int d = 0; d < 2; ++d)
-        for (int l = 0; l < NLAYER; ++l) { A(&h->cur->H[d][l], (size_t)h->T * B * HID); A(&h->cur->Cst[d][l], B * HID); }
+        for (int l = 0; l < NLAYER; ++l) { A(&h->cur->H[d][l], (size_t)h->T * h->Bp32 * HID); A(&h->cur->Cst[d][l], (size_t)h->Bp32 * HID); }
+    if (h->lstm_frag)
+        for (int d = 0; d < 2; ++d) A(&h->cur->hlast[d], B * HID);
     A(&h->cur->fc1o, B * h->J); A(&h->cur->logits, B * h->C); A(&h->cur->act, B * h->C); A(&h->cur->pred, B);
     if (h->bf16) A(&h->cur->joint, B * (size_t)h->JP / 2);
     // module outputs: ping-pong pair normally; one buffer per module in debug mode (for taps)
@@ -734,7 +744,54 @@ int build_plan(ds_handle* h, int n, Plan* plan)
         return h->cur->H[dir][l] + (size_t)t * h->B * HU;
     };
     const GemmCfg fc_cfg = bf ? (n % 128 == 0 ? CFG_BFC_DENSE : CFG_BFC) : (n % 128 == 0 ? CFG_FC_DENSE : CFG_FC);
-    for (int d = 0; h->is_rnn && d < T + NLAYER - 1; ++d) {
+    if (h->is_rnn && h->lstm_frag) {
+        // fp32 cells: lstm_cell_kernel, h / c in MFMA-fragment-major buffers (ds_internal.h LstmCell). n-tiles per wave:
+        // 1 fills the GPU at <= 768 sites per forward (768 workgroups per full diagonal at 512), wider tiles re-read the
+        // activation fragments less at bigger batches. Every width gives the same bits (same K order per element).
+        const int mtiles = (n + 31) / 32;
+        const int nt = h->lstm_t == 1 ? 1 : h->lstm_t == 0 ? 4 : (n <= 768 ? 1 : n <= 2048 ? 2 : 4);
+        const size_t step = (size_t)h->Bp32 * HID;                         // floats of one time step in H
+        for (int d = 0; d < T + NLAYER - 1; ++d) {
+            LstmLaunch L;
+            memset(&L, 0, sizeof L);
+            L.n = n; L.mtiles = mtiles; L.T = T;
+            double flops = 0;
+            for (int dir = 0; dir < 2; ++dir)
+                for (int l = 0; l < NLAYER; ++l) {
+                    const int sidx = d - l;
+                    if (sidx < 0 || sidx >= T) continue;
+                    const int t = dir == 0 ? sidx : T - 1 - sidx;
+                    const int tprev = dir == 0 ? t - 1 : t + 1;
+                    LstmCell& C = L.cell[L.ncell++];
+                    C.ax = l > 0 ? h->cur->H[dir][l - 1] + (size_t)t * step : nullptr;
+                    C.ah = sidx > 0 ? h->cur->H[dir][l] + (size_t)tprev * step : nullptr;
+                    C.Bp = h->lstm_n[dir][l].Bp;
+                    C.kg_stride = (h->lstm_n[dir][l].K + 31) / 32 * 32 / 8;
+                    C.bias = h->lstm_n[dir][l].bias;
+                    C.table = l == 0 ? h->lstm_table[dir] : nullptr;
+                    C.wfeat = h->lstm_wfeat[dir];
+                    C.codes = h->cur->d_kmer; C.means = h->cur->d_means; C.stds = h->cur->d_stds; C.lens = h->cur->d_sanums;
+                    C.c = h->cur->Cst[dir][l];
+                    C.h_out = h->cur->H[dir][l] + (size_t)t * step;
+                    // the joint FC reads the top layer's final h (fw: t = T-1, bw: t = 0) row-major   layers.py:171-172
+                    C.h_row = (l == NLAYER - 1 && sidx == T - 1) ? h->cur->hlast[dir] : nullptr;
+                    C.t = t; C.use_feat = l == 0; C.c_zero = sidx == 0;
+                    flops += 2.0 * n * 4 * HID * ((l > 0 ? HID : 0) + (sidx > 0 ? HID : 0));
+                }
+            Op op{};
+            op.kind = OP_LSTM; op.stream = 1; op.stage = st;
+            op.launch_index = (int)plan->lstm_launches.size();
+            op.a = L.ncell; op.b = mtiles; op.c = nt;
+            op.flops = flops;
+            plan->lstm_launches.push_back(L);
+            rnn.push_back(op);
+            if (first_plan) {
+                h->stages[st].launches += 1;
+                h->stages[st].flops_per_site += flops / n;
+            }
+        }
+    }
+    for (int d = 0; h->is_rnn && !h->lstm_frag && d < T + NLAYER - 1; ++d) {
         GemmLaunch L{};
         for (int dir = 0; dir < 2; ++dir)
             for (int l = 0; l < NLAYER; ++l) {
@@ -771,9 +828,9 @@ int build_plan(ds_handle* h, int n, Plan* plan)
         if (bf) {
             add_seg(P, h->cur->joint, h->JP / 2, 0, h->JP / 2);
         } else {
-        if (h->is_rnn) {
-            add_seg(P, h->cur->H[0][NLAYER - 1] + (size_t)(T - 1) * h->B * HID, HID, 0, HID);
-            add_seg(P, h->cur->H[1][NLAYER - 1] + 0, HID, 0, HID);
+        if (h->is_rnn) {       // fp32 mode always runs the fp32 cells: their row-major copy of the two final h vectors
+            add_seg(P, h->cur->hlast[0], HID, 0, HID);
+            add_seg(P, h->cur->hlast[1], HID, 0, HID);
         }
         if (h->is_cnn) add_seg(P, h->cur->sigfeat, h->SF, 0, h->SF);
         }
@@ -803,6 +860,13 @@ int build_plan(ds_handle* h, int n, Plan* plan)
     h->allocs.push_back(p);
     plan->d_launches = static_cast<GemmLaunch*>(p);
     HIPCHK(h, hipMemcpy(p, LS.data(), LS.size() * sizeof(GemmLaunch), hipMemcpyHostToDevice));
+    if (!plan->lstm_launches.empty()) {
+        void* q = nullptr;
+        HIPCHK(h, hipMalloc(&q, plan->lstm_launches.size() * sizeof(LstmLaunch)));
+        h->allocs.push_back(q);
+        plan->d_lstm = static_cast<LstmLaunch*>(q);
+        HIPCHK(h, hipMemcpy(q, plan->lstm_launches.data(), plan->lstm_launches.size() * sizeof(LstmLaunch), hipMemcpyHostToDevice));
+    }
     return DS_OK;
 }
 
@@ -825,8 +889,14 @@ int issue_op(ds_handle* h, Plan& plan, const Op& op, hipStream_t s)
         else HIPCHK(h, launch_avgpool7(op.in, op.out, n, op.a, op.d, s));
         break;
     case OP_PACKEV:
-        HIPCHK(h, launch_pack_event_feat_bf16(h->cur->H[0][NLAYER - 1] + (size_t)(h->T - 1) * h->B * (h->lstm_bf16 ? HID / 2 : HID),
-                                              h->cur->H[1][NLAYER - 1], h->cur->joint, n, h->JP, h->lstm_bf16, s));
+        if (h->lstm_frag)
+            HIPCHK(h, launch_pack_event_feat_bf16(h->cur->hlast[0], h->cur->hlast[1], h->cur->joint, n, h->JP, 0, s));
+        else
+            HIPCHK(h, launch_pack_event_feat_bf16(h->cur->H[0][NLAYER - 1] + (size_t)(h->T - 1) * h->B * (HID / 2),
+                                                  h->cur->H[1][NLAYER - 1], h->cur->joint, n, h->JP, 1, s));
+        break;
+    case OP_LSTM:
+        HIPCHK(h, launch_lstm_cells(op.c, plan.d_lstm + op.launch_index, op.a, op.b, s));
         break;
     case OP_FUSED:
         if (h->bf16) HIPCHK(h, launch_inception_fused_bf16(op.tm, op.fa, s));
@@ -922,6 +992,7 @@ int kernel_class(const Op& op)
     case OP_AVGPOOL: return K_AVGPOOL;
     case OP_HEAD: return K_HEAD;
     case OP_PACKEV: return K_PACKEV;
+    case OP_LSTM: return op.c == 1 ? K_LSTM_CELL1 : op.c == 2 ? K_LSTM_CELL2 : K_LSTM_CELL4;
     }
     return K_HEAD;
 }
@@ -952,7 +1023,12 @@ void destroy_plan(ds_handle* h, Plan& p)
         auto it = std::find(h->allocs.begin(), h->allocs.end(), (void*)p.d_launches);
         if (it != h->allocs.end()) h->allocs.erase(it);
     }
-    p.graph = nullptr; p.d_launches = nullptr; p.ops.clear();
+    if (p.d_lstm) {
+        hipFree(p.d_lstm);
+        auto it = std::find(h->allocs.begin(), h->allocs.end(), (void*)p.d_lstm);
+        if (it != h->allocs.end()) h->allocs.erase(it);
+    }
+    p.graph = nullptr; p.d_launches = nullptr; p.d_lstm = nullptr; p.ops.clear();
 }
 
 constexpr size_t MAX_PLANS_PER_SLOT = 24;
@@ -1088,6 +1164,8 @@ static int ds_create_impl(const ds_config* cfg, ds_handle** out)
     h->lstm_t = cfg->reserved[3] == DS_LSTM_TILING_NARROW ? 1 : cfg->reserved[3] == DS_LSTM_TILING_WIDE ? 0 : -1;
     if (cfg->reserved[4] > 0) h->fuse_max_spt = cfg->reserved[4];
     if (cfg->reserved[5] > 0) h->fuse_min_tiles = cfg->reserved[5];
+    h->lstm_frag = h->is_rnn && !h->lstm_bf16;
+    h->Bp32 = (h->B + 31) / 32 * 32;
     h->JP = (h->J + 31) / 32 * 32;
     h->debug = cfg->reserved[0] != 0;
 #define CK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { fail(nullptr, DS_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); ds_destroy(h); return DS_ERR_HIP; } } while (0)
@@ -1442,11 +1520,16 @@ int64_t ds_get_intermediate(ds_handle* h, const char* name, float* out, int64_t 
                     }
             return count;
         }
-        std::vector<float> tmp((size_t)h->T * h->B * HID);
+        // fp32 cells keep h MFMA-fragment-major: [T][m-tile][k-group g][lane = 32*half + r][4] holds units
+        // 8g + 4*half .. + 3 of site 32*mtile + r (ds_internal.h LstmCell)
+        std::vector<float> tmp((size_t)h->T * h->Bp32 * HID);
         if (hipMemcpy(tmp.data(), h->cur->H[d][l], tmp.size() * 4, hipMemcpyDeviceToHost) != hipSuccess) return fail(h, DS_ERR_HIP, "hipMemcpy D2H");
         for (int i = 0; i < n; ++i)
             for (int t = 0; t < h->T; ++t)
-                memcpy(out + ((size_t)i * h->T + t) * HID, tmp.data() + ((size_t)t * h->B + i) * HID, HID * 4);
+                for (int g = 0; g < HID / 8; ++g)
+                    for (int half = 0; half < 2; ++half)
+                        memcpy(out + ((size_t)i * h->T + t) * HID + 8 * g + 4 * half,
+                               tmp.data() + (size_t)t * h->Bp32 * HID + (size_t)(i / 32) * LSTM_MT_FLOATS + ((size_t)g * 64 + half * 32 + i % 32) * 4, 16);
         return count;
     }
     if (s.rfind("stamps", 0) == 0) {   // "stampsN": phase stamp deltas (cycles) of fused module N, wave 0 and wave 7, averaged over workgroups
@@ -1471,8 +1554,10 @@ int64_t ds_get_intermediate(ds_handle* h, const char* name, float* out, int64_t 
         const int64_t count = (int64_t)n * h->J;
         if (count > capacity) return fail(h, DS_ERR_INVALID, "capacity too small");
         std::vector<float> fw((size_t)n * HID), bw((size_t)n * HID), sf((size_t)n * h->SF);
-        hipMemcpy(fw.data(), h->cur->H[0][NLAYER - 1] + (size_t)(h->T - 1) * h->B * HID, fw.size() * 4, hipMemcpyDeviceToHost);
-        hipMemcpy(bw.data(), h->cur->H[1][NLAYER - 1], bw.size() * 4, hipMemcpyDeviceToHost);
+        if (h->is_rnn) {     // fp32 tap (the bf16 modes return above): the row-major copies of the two final h vectors
+            hipMemcpy(fw.data(), h->cur->hlast[0], fw.size() * 4, hipMemcpyDeviceToHost);
+            hipMemcpy(bw.data(), h->cur->hlast[1], bw.size() * 4, hipMemcpyDeviceToHost);
+        }
         if (hipMemcpy(sf.data(), h->cur->sigfeat, sf.size() * 4, hipMemcpyDeviceToHost) != hipSuccess) return fail(h, DS_ERR_HIP, "hipMemcpy D2H");
         const int ev = h->is_rnn ? 2 * HID : 0;
         for (int i = 0; i < n; ++i) {

@@ -78,6 +78,41 @@ enum GemmCfg { CFG_CONV = 0, CFG_FC = 1, CFG_LSTM = 2, CFG_CONV_WIDE = 3, CFG_CO
                // fp32 LSTM cell on 128 x 32 tiles (transposed MFMA, [gate][8 units] column order inside a tile)
                CFG_LSTM_T = 13, CFG_LSTM_T_DENSE = 14, CFG_BLSTM_T = 15, CFG_BLSTM_T_DENSE = 16 };
 
+// ---- fp32 BiLSTM cell launch (lstm_cell_kernel) ---------------------------------------------------------------
+// h and c of the fp32 BiLSTM live in MFMA-FRAGMENT-MAJOR buffers: [m-tile of 32 sites][k-group of 8 units][64 lanes][4]
+// where lane (site r = lane & 31, half = lane >> 5) holds units 8g + 4*half .. + 3 of site 32*mtile + r. That is
+// exactly what one lane of a cell's epilogue produces (four neighbouring units of one site) AND exactly the float4 a
+// lane feeds to four consecutive v_mfma_f32_32x32x2_f32 as the activation operand of the next step, so h goes
+// global -> VGPR -> MFMA with fully coalesced 1 KiB wave loads: no LDS, no barrier, no staging arithmetic.
+constexpr int LSTM_MAX_CELLS = 6;
+constexpr int LSTM_MT_FLOATS = 32 * 256;      // floats of one m-tile (32 sites x 256 units) in a fragment-major buffer
+struct LstmCell {
+    const float* ax;      // x operand: h of the layer below at this step (fragment-major), nullptr for layer 0
+    const float* ah;      // h operand: this cell's h at the previous step (fragment-major), nullptr at the first step
+    const float* Bp;      // packed weights [32 n-tiles][kg_stride][64][4]; rows = x rows then h rows (layer 0: h rows only);
+                          // n-tile p, column i = gate (i >> 3) of unit 8p + (i & 7)
+    const float* bias;    // [4][256], TF column order i, j, f, o
+    const float* table;   // layer 0, is_base: [vocab][1024] embedding x W_x; else nullptr
+    const float* wfeat;   // layer 0: [3][1024] rows of W_x for (mean, std, len)
+    const int* codes;     // [n][T]
+    const float* means;   // [n][T]
+    const float* stds;
+    const float* lens;
+    float* c;             // cell state, fragment-major (read-modify-write)
+    float* h_out;         // fragment-major
+    float* h_row;         // optional row-major [n][256] copy of h_out (what the joint FC reads), or nullptr
+    int kg_stride;        // k-groups per n-tile panel in Bp (32 or 64)
+    int t;                // original time index of this step (layer-0 feature gather)
+    int use_feat;         // 1: layer 0 -- (mean, std, len) rank-1 terms (+ table row) enter the accumulator's initial value
+    int c_zero;           // 1: previous c is zero (first step)
+};
+struct LstmLaunch {
+    LstmCell cell[LSTM_MAX_CELLS];
+    int ncell, n, mtiles, T;
+};
+// nt = 32-column n-tiles per wave (1, 2 or 4): the same bits for every nt (same K order per output element)
+hipError_t launch_lstm_cells(int nt, const LstmLaunch* d_launch, int ncell, int mtiles, hipStream_t s);
+
 // tile geometry per config (host needs it for grid sizing)
 struct TileGeom { int bm, bn, threads, ksplit; };
 TileGeom gemm_geom(GemmCfg cfg);

@@ -681,21 +681,181 @@ hipError_t launch_gemm(GemmCfg cfg, const GemmLaunch* d_launch, int total_tiles,
     switch (cfg) {
     case CFG_CONV: hipLaunchKernelGGL((gemm_kernel<1, 2, 4, 1, 0, 0, 1, 1>), dim3(total_tiles), dim3(256), 0, s, d_launch); break;
     case CFG_FC: hipLaunchKernelGGL((gemm_kernel<1, 3, 4, 1, 0, 0, 2, 1>), dim3(total_tiles), dim3(256), 0, s, d_launch); break;
-    case CFG_LSTM: hipLaunchKernelGGL((gemm_kernel<1, 4, 4, 1, 1, 0, 1, 1>), dim3(total_tiles), dim3(256), 0, s, d_launch); break;
     case CFG_CONV_WIDE: hipLaunchKernelGGL((gemm_kernel<2, 2, 2, 2, 0, 0, 1, 1>), dim3(total_tiles), dim3(256), 0, s, d_launch); break;
     case CFG_CONV_POOL: hipLaunchKernelGGL((gemm_kernel<1, 2, 4, 1, 0, 1, 1, 1>), dim3(total_tiles), dim3(256), 0, s, d_launch); break;
     case CFG_FC_DENSE: hipLaunchKernelGGL((gemm_kernel<1, 3, 4, 1, 0, 2, 2, 1>), dim3(total_tiles), dim3(256), 0, s, d_launch); break;
-    case CFG_LSTM_DENSE: hipLaunchKernelGGL((gemm_kernel<1, 4, 4, 1, 1, 2, 1, 1>), dim3(total_tiles), dim3(256), 0, s, d_launch); break;
     case CFG_BCONV: hipLaunchKernelGGL((gemm_kernel<1, 2, 4, 1, 0, 0, 1, 1, true>), dim3(total_tiles), dim3(256), 0, s, d_launch); break;
     case CFG_BCONV_POOL: hipLaunchKernelGGL((gemm_kernel<1, 2, 4, 1, 0, 1, 1, 1, true>), dim3(total_tiles), dim3(256), 0, s, d_launch); break;
     case CFG_BFC: hipLaunchKernelGGL((gemm_kernel<4, 2, 1, 4, 0, 0, 2, 1, true>), dim3(total_tiles), dim3(256), 0, s, d_launch); break;
     case CFG_BFC_DENSE: hipLaunchKernelGGL((gemm_kernel<4, 2, 1, 4, 0, 2, 2, 1, true>), dim3(total_tiles), dim3(256), 0, s, d_launch); break;
     case CFG_BLSTM: hipLaunchKernelGGL((gemm_kernel<1, 4, 4, 1, 1, 0, 3, 1, true>), dim3(total_tiles), dim3(256), 0, s, d_launch); break;
     case CFG_BLSTM_DENSE: hipLaunchKernelGGL((gemm_kernel<1, 4, 4, 1, 1, 2, 3, 1, true>), dim3(total_tiles), dim3(256), 0, s, d_launch); break;
-    case CFG_LSTM_T: hipLaunchKernelGGL((gemm_kernel<1, 1, 4, 1, 2, 0, 1, 1>), dim3(total_tiles), dim3(256), 0, s, d_launch); break;
-    case CFG_LSTM_T_DENSE: hipLaunchKernelGGL((gemm_kernel<1, 1, 4, 1, 2, 2, 1, 1>), dim3(total_tiles), dim3(256), 0, s, d_launch); break;
     case CFG_BLSTM_T: hipLaunchKernelGGL((gemm_kernel<1, 1, 4, 1, 2, 0, 3, 1, true>), dim3(total_tiles), dim3(256), 0, s, d_launch); break;
     case CFG_BLSTM_T_DENSE: hipLaunchKernelGGL((gemm_kernel<1, 1, 4, 1, 2, 2, 3, 1, true>), dim3(total_tiles), dim3(256), 0, s, d_launch); break;
+    default: return hipErrorInvalidValue;      // fp32 LSTM cells run in lstm_cell_kernel, not through this template
+    }
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// fp32 BiLSTM cells of one wavefront diagonal (layers.py:45-72; TF LSTMCell: gate order i, j, f, o, forget_bias 1.0
+// added at run time; c' = sigmoid(f + 1) c + sigmoid(i) tanh(j); h' = sigmoid(o) tanh(c')).
+//
+// A workgroup = 4 INDEPENDENT waves (no LDS, no barrier): wave w owns the 32 sites of m-tile 4*mb + w and NT n-tiles of
+// 32 gate columns ([gate][8 units] order, so a lane ends up with the four gates of four neighbouring units of ONE
+// site). Both operands stream global -> VGPR in MFMA-fragment order with 1 KiB coalesced wave loads, four k-groups
+// ahead of the matrix pipe: the weights as packed by the host, the activations because the previous cell's epilogue
+// wrote h in exactly that order (ds_internal.h, LstmCell). The product is issued transposed -- mfma(weights, h) --
+// as in the fused inception kernel. Bias (+1 on the forget gate) and, for layer 0, the embedding-table row and the
+// (mean, std, len) rank-1 terms are the accumulator's INITIAL value, computed while the first fragments are in
+// flight; the previous cell state is requested up front as well, so the epilogue is pure gate arithmetic + two
+// coalesced 1 KiB stores.
+// Roofline: MFMA (fp32, 64 FLOP/clk/SIMD). Algorithmic FLOPs per launch = sum over cells of 2 * n * 1024 * K.
+template <int NT>
+__global__ __launch_bounds__(256, NT == 1 ? 4 : 2) void lstm_cell_kernel(const LstmLaunch* __restrict__ Lp)
+{
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // XCD-aware order (see gemm_kernel): every XCD gets a contiguous run of logical tiles, m-blocks of one weight
+    // panel adjacent, so a weight fragment is pulled into ONE L2 and stays there from launch to launch
+    int bid;
+    {
+        const int total = gridDim.x, q = total >> 3, r = total & 7;
+        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        bid = xcd * q + (xcd < r ? xcd : r) + idx;
+    }
+    const int mtiles = Lp->mtiles;
+    const int mblocks = (mtiles + 3) >> 2;
+    constexpr int NGROUPS = 32 / NT;
+    const int per_cell = mblocks * NGROUPS;
+    const int ci = bid / per_cell, rem = bid - ci * per_cell;
+    const int mb = rem % mblocks, ng = rem / mblocks;
+    const int mt = mb * 4 + wave;
+    if (mt >= mtiles) return;                       // waves are independent: a ragged last m-block just has fewer of them
+    const LstmCell& C = Lp->cell[ci];
+    const int half = lane >> 5, r31 = lane & 31;
+    const int n = Lp->n, T = Lp->T;
+    const int row = mt * 32 + r31;
+    const int rowc = row < n ? row : n - 1;         // padding rows of the last m-tile compute on a copy of the last site
+
+    // ---- requests that the accumulator's initial value needs
+    floatx16 acc[NT];
+    float4 cp[NT];
+    {
+        const float* biasp = C.bias;
+        const float* wf = C.wfeat;
+        const float* tab = C.table;
+        const bool has_feat = C.use_feat != 0, has_table = tab != nullptr;
+        float f0 = 0.f, f1 = 0.f, f2 = 0.f;
+        int code = 0;
+        if (has_feat) {
+            const unsigned it = (unsigned)rowc * T + C.t;
+            f0 = gload(C.means + it); f1 = gload(C.stds + it); f2 = gload(C.lens + it);
+            // codes index the folded [vocab = 1024][1024] table; a non-Python client may pass anything: clamp
+            if (has_table) code = min(max(*(const __attribute__((address_space(1))) int*)(C.codes + it), 0), 1023);
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int p8 = (ng * NT + nt) * 8 + 4 * half;           // first of this lane's four units
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float4 z = gload4(biasp + g * 256 + p8);
+                if (g == 2) { z.x += 1.0f; z.y += 1.0f; z.z += 1.0f; z.w += 1.0f; }       // forget_bias
+                if (has_feat) {
+                    const float4 w0 = gload4(wf + g * 256 + p8), w1 = gload4(wf + 1024 + g * 256 + p8),
+                                 w2 = gload4(wf + 2048 + g * 256 + p8);
+                    // explicit fma chains: every instantiation must round identically
+                    float4 x = make_float4(fmaf(f2, w2.x, fmaf(f1, w1.x, f0 * w0.x)), fmaf(f2, w2.y, fmaf(f1, w1.y, f0 * w0.y)),
+                                           fmaf(f2, w2.z, fmaf(f1, w1.z, f0 * w0.z)), fmaf(f2, w2.w, fmaf(f1, w1.w, f0 * w0.w)));
+                    if (has_table) {
+                        const float4 tb = gload4(tab + (size_t)code * 1024 + g * 256 + p8);
+                        x.x += tb.x; x.y += tb.y; x.z += tb.z; x.w += tb.w;
+                    }
+                    z.x += x.x; z.y += x.y; z.z += x.z; z.w += x.w;
+                }
+                acc[nt][4 * g] = z.x; acc[nt][4 * g + 1] = z.y; acc[nt][4 * g + 2] = z.z; acc[nt][4 * g + 3] = z.w;
+            }
+        }
+    }
+    const unsigned lane4 = (unsigned)lane * 4;
+    const size_t mt_off = (size_t)mt * LSTM_MT_FLOATS;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        cp[nt] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (!C.c_zero) cp[nt] = gload4(C.c + mt_off + (unsigned)(ng * NT + nt) * 256 + lane4);
+    }
+
+    // ---- K loop: k-groups of 8 (one 16-byte fragment per lane and operand = four MFMAs), a ring of four register
+    // stages; x rows first, then h rows, as in the TF kernel (and in the packed weights)
+    const bool has_x = C.ax != nullptr, has_h = C.ah != nullptr;
+    const int KG = (has_x ? 32 : 0) + (has_h ? 32 : 0);
+    // one linear k-group index for both segments: group kg lives at a0 + kg KiB (+ the distance between the two
+    // buffers from group 32 on when both are present) -- scalar arithmetic only, no branch in the loop
+    const char* const a0 = reinterpret_cast<const char*>(has_x ? C.ax : C.ah) + mt_off * 4;
+    const long dseg = (has_x && has_h) ? (reinterpret_cast<const char*>(C.ah) - reinterpret_cast<const char*>(C.ax)) - 32 * 1024 : 0;
+    const char* bpn[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) bpn[nt] = reinterpret_cast<const char*>(C.Bp + (size_t)(ng * NT + nt) * C.kg_stride * 256);
+    const unsigned lane16 = (unsigned)lane * 16;
+    if (KG > 0) {
+        float4 a[4], b[4][NT];
+        auto request = [&](int slot, int kg) {           // slot is a literal at every call site
+            const int kc = min(kg, KG - 1);              // past the end: re-request the last group (never consumed)
+            const long aoff = (long)kc * 1024 + (kc >= 32 ? dseg : 0);                               // wave-uniform
+            a[slot] = gload4(reinterpret_cast<const float*>(a0 + aoff + lane16));
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) b[slot][nt] = gload4(reinterpret_cast<const float*>(bpn[nt] + (long)kc * 1024 + lane16));
+        };
+        auto consume = [&](int slot) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[slot][nt].x, a[slot].x, acc[nt], 0, 0, 0);
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[slot][nt].y, a[slot].y, acc[nt], 0, 0, 0);
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[slot][nt].z, a[slot].z, acc[nt], 0, 0, 0);
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[slot][nt].w, a[slot].w, acc[nt], 0, 0, 0);
+            }
+        };
+        request(0, 0); request(1, 1); request(2, 2); request(3, 3);
+        for (int kg = 0; kg < KG; kg += 4) {             // KG is 32 or 64
+            // sched_barrier pins the ring: without it hipcc sinks all eight requests to the bottom of the trip, and a
+            // stage's operands are then only ~1 stage ahead of their MFMAs instead of 4
+            consume(0); request(0, kg + 4); __builtin_amdgcn_sched_barrier(0);
+            consume(1); request(1, kg + 5); __builtin_amdgcn_sched_barrier(0);
+            consume(2); request(2, kg + 6); __builtin_amdgcn_sched_barrier(0);
+            consume(3); request(3, kg + 7); __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+
+    // ---- gates, new state, coalesced fragment-major stores
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int ntile = ng * NT + nt;
+        float4 cn, hn;
+        cn.x = fmaf(fast_sigmoid(acc[nt][8]), cp[nt].x, fast_sigmoid(acc[nt][0]) * fast_tanh(acc[nt][4]));
+        cn.y = fmaf(fast_sigmoid(acc[nt][9]), cp[nt].y, fast_sigmoid(acc[nt][1]) * fast_tanh(acc[nt][5]));
+        cn.z = fmaf(fast_sigmoid(acc[nt][10]), cp[nt].z, fast_sigmoid(acc[nt][2]) * fast_tanh(acc[nt][6]));
+        cn.w = fmaf(fast_sigmoid(acc[nt][11]), cp[nt].w, fast_sigmoid(acc[nt][3]) * fast_tanh(acc[nt][7]));
+        hn.x = fast_sigmoid(acc[nt][12]) * fast_tanh(cn.x);
+        hn.y = fast_sigmoid(acc[nt][13]) * fast_tanh(cn.y);
+        hn.z = fast_sigmoid(acc[nt][14]) * fast_tanh(cn.z);
+        hn.w = fast_sigmoid(acc[nt][15]) * fast_tanh(cn.w);
+        const size_t off = mt_off + (unsigned)ntile * 256 + lane4;
+        const v4f co = {cn.x, cn.y, cn.z, cn.w}, ho = {hn.x, hn.y, hn.z, hn.w};
+        *(__attribute__((address_space(1))) v4f*)(C.c + off) = co;
+        *(__attribute__((address_space(1))) v4f*)(C.h_out + off) = ho;
+        if (C.h_row && row < n)
+            *(__attribute__((address_space(1))) v4f*)(C.h_row + (size_t)row * 256 + ntile * 8 + 4 * half) = ho;
+    }
+}
+
+hipError_t launch_lstm_cells(int nt, const LstmLaunch* d_launch, int ncell, int mtiles, hipStream_t s)
+{
+    if (ncell <= 0 || mtiles <= 0) return hipSuccess;
+    const int mblocks = (mtiles + 3) / 4;
+    switch (nt) {
+    case 1: hipLaunchKernelGGL(lstm_cell_kernel<1>, dim3(ncell * mblocks * 32), dim3(256), 0, s, d_launch); break;
+    case 2: hipLaunchKernelGGL(lstm_cell_kernel<2>, dim3(ncell * mblocks * 16), dim3(256), 0, s, d_launch); break;
+    case 4: hipLaunchKernelGGL(lstm_cell_kernel<4>, dim3(ncell * mblocks * 8), dim3(256), 0, s, d_launch); break;
+    default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
 }
