@@ -67,7 +67,7 @@ struct Op {
 
 // per-kernel accumulators (one entry per __global__ function / template instantiation)
 enum KernelClass { K_GEMM_CONV = 0, K_GEMM_FC, K_GEMM_LSTM, K_GEMM_CONV_WIDE, K_GEMM_CONV_POOL, K_GEMM_FC_DENSE, K_GEMM_LSTM_DENSE, K_FUSED1, K_FUSED2, K_FUSED3, K_STEM1, K_MAXPOOL, K_AVGPOOL, K_HEAD,
-                   K_GEMM_BCONV, K_GEMM_BCONV_POOL, K_GEMM_BFC, K_GEMM_BFC_DENSE, K_PACKEV, K_GEMM_BLSTM, K_GEMM_BLSTM_DENSE, K_FUSEDB1, K_FUSEDB2, K_FUSEDB3, K_GEMM_LSTM_T, K_GEMM_LSTM_T_DENSE, K_GEMM_BLSTM_T, K_GEMM_BLSTM_T_DENSE, K_LSTM_CELL1, K_LSTM_CELL2, K_LSTM_CELL4, K_COUNT };
+                   K_GEMM_BCONV, K_GEMM_BCONV_POOL, K_GEMM_BFC, K_GEMM_BFC_DENSE, K_PACKEV, K_GEMM_BLSTM, K_GEMM_BLSTM_DENSE, K_FUSEDB1, K_FUSEDB2, K_FUSEDB3, K_GEMM_LSTM_T, K_GEMM_LSTM_T_DENSE, K_GEMM_BLSTM_T, K_GEMM_BLSTM_T_DENSE, K_LSTM_CELL1, K_LSTM_CELL2, K_LSTM_CELL4, K_LSTM_LDS1, K_LSTM_LDS2, K_COUNT };
 const char* const kKernelNames[K_COUNT] = {"gemm_kernel<1,2,4,1,0,0,1,1>", "gemm_kernel<1,3,4,1,0,0,2,1>", "gemm_kernel<1,4,4,1,1,0,1,1>",
                                            "gemm_kernel<2,2,2,2,0,0,1,1>", "gemm_kernel<1,2,4,1,0,1,1,1>", "gemm_kernel<1,3,4,1,0,2,2,1>",
                                            "gemm_kernel<1,4,4,1,1,2,1,1>", "inception_fused_kernel<1>",
@@ -80,7 +80,8 @@ const char* const kKernelNames[K_COUNT] = {"gemm_kernel<1,2,4,1,0,0,1,1>", "gemm
                                            "inception_fused_bf16_kernel<2>", "inception_fused_bf16_kernel<3>",
                                            "gemm_kernel<1,1,4,1,2,0,1,1>", "gemm_kernel<1,1,4,1,2,2,1,1>",
                                            "gemm_kernel<1,1,4,1,2,0,3,1,bf16>", "gemm_kernel<1,1,4,1,2,2,3,1,bf16>",
-                                           "lstm_cell_kernel<1>", "lstm_cell_kernel<2>", "lstm_cell_kernel<4>"};
+                                           "lstm_cell_kernel<1>", "lstm_cell_kernel<2>", "lstm_cell_kernel<4>",
+                                           "lstm_cell_lds_kernel<1>", "lstm_cell_lds_kernel<2>"};
 struct KernelStat {
     int64_t launches = 0;
     double total_ms = 0;
@@ -148,6 +149,7 @@ struct ds_handle {
     int B = 512;
     bool is_cnn = true, is_rnn = true, is_base = true;   // model.py:28-29,59-75,89-95
     bool bf16 = false;    // DS_PRECISION_BF16: bf16 conv + FC operands (fp32 accumulate), fp32 BiLSTM
+    int lstm_variant = 0;     // ds_config.reserved[3] as given (DS_LSTM_TILING_*)
     int lstm_t = -1;          // LSTM cell tiling: 1 = always 128 x 32 (CFG_*LSTM_T), 0 = always 128 x 128, -1 = by forward size
     // per-handle tuning / diagnostic knobs, all from ds_config.reserved[2..5] (include/deepsignal_hip.h)
     bool no_fused = false;    // DS_TUNE_NO_FUSED: layer-granular inception modules instead of the fused kernel
@@ -749,7 +751,10 @@ int build_plan(ds_handle* h, int n, Plan* plan)
         // 1 fills the GPU at <= 768 sites per forward (768 workgroups per full diagonal at 512), wider tiles re-read the
         // activation fragments less at bigger batches. Every width gives the same bits (same K order per element).
         const int mtiles = (n + 31) / 32;
-        const int nt = h->lstm_t == 1 ? 1 : h->lstm_t == 0 ? 4 : (n <= 768 ? 1 : n <= 2048 ? 2 : 4);
+        // kernel variant: direct-to-register (1, 2 or 4 n-tiles per wave) or operands shared through LDS (101 / 102)
+        const int nt = h->lstm_variant == DS_LSTM_TILING_NARROW ? 1 : h->lstm_variant == DS_LSTM_TILING_WIDE ? 4
+                       : h->lstm_variant == DS_LSTM_TILING_LDS1 ? 101 : h->lstm_variant == DS_LSTM_TILING_LDS2 ? 102
+                       : (n <= 768 ? 1 : n <= 2048 ? 2 : 4);
         const size_t step = (size_t)h->Bp32 * HID;                         // floats of one time step in H
         for (int d = 0; d < T + NLAYER - 1; ++d) {
             LstmLaunch L;
@@ -992,7 +997,7 @@ int kernel_class(const Op& op)
     case OP_AVGPOOL: return K_AVGPOOL;
     case OP_HEAD: return K_HEAD;
     case OP_PACKEV: return K_PACKEV;
-    case OP_LSTM: return op.c == 1 ? K_LSTM_CELL1 : op.c == 2 ? K_LSTM_CELL2 : K_LSTM_CELL4;
+    case OP_LSTM: return op.c == 1 ? K_LSTM_CELL1 : op.c == 2 ? K_LSTM_CELL2 : op.c == 4 ? K_LSTM_CELL4 : op.c == 101 ? K_LSTM_LDS1 : K_LSTM_LDS2;
     }
     return K_HEAD;
 }
@@ -1162,6 +1167,7 @@ static int ds_create_impl(const ds_config* cfg, ds_handle** out)
     h->no_fused = (flags & DS_TUNE_NO_FUSED) != 0;
     h->serial = (flags & DS_TUNE_SERIAL) != 0;
     h->lstm_t = cfg->reserved[3] == DS_LSTM_TILING_NARROW ? 1 : cfg->reserved[3] == DS_LSTM_TILING_WIDE ? 0 : -1;
+    h->lstm_variant = cfg->reserved[3];
     if (cfg->reserved[4] > 0) h->fuse_max_spt = cfg->reserved[4];
     if (cfg->reserved[5] > 0) h->fuse_min_tiles = cfg->reserved[5];
     h->lstm_frag = h->is_rnn && !h->lstm_bf16;

@@ -27,7 +27,10 @@ __device__ __forceinline__ float4 f4max(float4 a, float4 b)
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 // LSTM gate non-linearities on the hardware exp (v_exp_f32, ~1 ulp): abs error < 2e-7, far inside the
 // 2e-5 parity budget, at a fraction of the ocml expf/tanhf instruction count.
-__device__ __forceinline__ float fast_sigmoid(float x) { return __fdividef(1.0f, 1.0f + __expf(-x)); }
+// v_rcp_f32 (1 ulp) instead of a division: hipcc expands __fdividef / `1.0f / x` into the full IEEE sequence
+// (v_div_scale, v_rcp, four fma, v_div_fmas, v_div_fixup -- ~12 instructions); ten of those per LSTM unit were most
+// of the cell epilogue's VALU time.
+__device__ __forceinline__ float fast_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 __device__ __forceinline__ float fast_tanh(float x) { return fmaf(2.0f, fast_sigmoid(2.0f * x), -1.0f); }
 
 // Pointers reach the kernels through descriptor structs, so the compiler only knows them as
@@ -697,6 +700,65 @@ hipError_t launch_gemm(GemmCfg cfg, const GemmLaunch* d_launch, int total_tiles,
     return hipGetLastError();
 }
 
+// Accumulator's initial value of an LSTM tile (transposed product: register 4g + e = gate g of unit p8 + e for one
+// site): bias (+1.0 on the forget gate: TF adds forget_bias at run time) and, for layer 0, the folded embedding-table
+// row plus the (mean, std, len) rank-1 terms. Every load of a group is issued before anything waits: one L2 round
+// trip for the biases, two (code -> table row) for layer 0 -- written with per-gate branches this was four to eight
+// SERIALIZED round trips in front of every tile.
+__device__ __forceinline__ void lstm_acc_init(const LstmCell& C, int p8, int rowc, int T, floatx16& acc)
+{
+    float4 z[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) z[g] = gload4(C.bias + g * 256 + p8);
+    if (C.use_feat) {                                    // wave-uniform: the two layer-0 cells of a diagonal
+        const float* wf = C.wfeat;
+        const float* tab = C.table;
+        const unsigned it = (unsigned)rowc * T + C.t;
+        const float f0 = gload(C.means + it), f1 = gload(C.stds + it), f2 = gload(C.lens + it);
+        // codes index the folded [vocab = 1024][1024] table; a non-Python client may pass anything: clamp
+        const int code = tab ? min(max(*(const __attribute__((address_space(1))) int*)(C.codes + it), 0), 1023) : 0;
+        float4 w0[4], w1[4], w2[4], tb[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            w0[g] = gload4(wf + g * 256 + p8);
+            w1[g] = gload4(wf + 1024 + g * 256 + p8);
+            w2[g] = gload4(wf + 2048 + g * 256 + p8);
+        }
+        const float* trow = tab ? tab + (size_t)code * 1024 : C.bias;      // no table (is_base = no): any valid address
+#pragma unroll
+        for (int g = 0; g < 4; ++g) tb[g] = gload4(trow + g * 256 + p8);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            // explicit fma chains: every instantiation / tiling must round identically
+            float4 x = make_float4(fmaf(f2, w2[g].x, fmaf(f1, w1[g].x, f0 * w0[g].x)), fmaf(f2, w2[g].y, fmaf(f1, w1[g].y, f0 * w0[g].y)),
+                                   fmaf(f2, w2[g].z, fmaf(f1, w1[g].z, f0 * w0[g].z)), fmaf(f2, w2[g].w, fmaf(f1, w1[g].w, f0 * w0[g].w)));
+            if (tab) { x.x += tb[g].x; x.y += tb[g].y; x.z += tb[g].z; x.w += tb[g].w; }
+            if (g == 2) { z[g].x += 1.0f; z[g].y += 1.0f; z[g].z += 1.0f; z[g].w += 1.0f; }
+            z[g].x += x.x; z[g].y += x.y; z[g].z += x.z; z[g].w += x.w;
+        }
+    } else {
+        z[2].x += 1.0f; z[2].y += 1.0f; z[2].z += 1.0f; z[2].w += 1.0f;
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        acc[4 * g] = z[g].x; acc[4 * g + 1] = z[g].y; acc[4 * g + 2] = z[g].z; acc[4 * g + 3] = z[g].w;
+    }
+}
+
+// Gate arithmetic of an LSTM tile (layers.py:49-50 / TF LSTMCell): registers 0-3 = i, 4-7 = j, 8-11 = f (+1 already
+// inside), 12-15 = o of four neighbouring units; returns the new c and h as float4.
+__device__ __forceinline__ void lstm_gates(const floatx16& acc, const float4& cp, float4& cn, float4& hn)
+{
+    cn.x = fmaf(fast_sigmoid(acc[8]), cp.x, fast_sigmoid(acc[0]) * fast_tanh(acc[4]));
+    cn.y = fmaf(fast_sigmoid(acc[9]), cp.y, fast_sigmoid(acc[1]) * fast_tanh(acc[5]));
+    cn.z = fmaf(fast_sigmoid(acc[10]), cp.z, fast_sigmoid(acc[2]) * fast_tanh(acc[6]));
+    cn.w = fmaf(fast_sigmoid(acc[11]), cp.w, fast_sigmoid(acc[3]) * fast_tanh(acc[7]));
+    hn.x = fast_sigmoid(acc[12]) * fast_tanh(cn.x);
+    hn.y = fast_sigmoid(acc[13]) * fast_tanh(cn.y);
+    hn.z = fast_sigmoid(acc[14]) * fast_tanh(cn.z);
+    hn.w = fast_sigmoid(acc[15]) * fast_tanh(cn.w);
+}
+
 // ---------------------------------------------------------------------------------------------
 // fp32 BiLSTM cells of one wavefront diagonal (layers.py:45-72; TF LSTMCell: gate order i, j, f, o, forget_bias 1.0
 // added at run time; c' = sigmoid(f + 1) c + sigmoid(i) tanh(j); h' = sigmoid(o) tanh(c')).
@@ -740,42 +802,8 @@ __global__ __launch_bounds__(256, NT == 1 ? 4 : 2) void lstm_cell_kernel(const L
     // ---- requests that the accumulator's initial value needs
     floatx16 acc[NT];
     float4 cp[NT];
-    {
-        const float* biasp = C.bias;
-        const float* wf = C.wfeat;
-        const float* tab = C.table;
-        const bool has_feat = C.use_feat != 0, has_table = tab != nullptr;
-        float f0 = 0.f, f1 = 0.f, f2 = 0.f;
-        int code = 0;
-        if (has_feat) {
-            const unsigned it = (unsigned)rowc * T + C.t;
-            f0 = gload(C.means + it); f1 = gload(C.stds + it); f2 = gload(C.lens + it);
-            // codes index the folded [vocab = 1024][1024] table; a non-Python client may pass anything: clamp
-            if (has_table) code = min(max(*(const __attribute__((address_space(1))) int*)(C.codes + it), 0), 1023);
-        }
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            const int p8 = (ng * NT + nt) * 8 + 4 * half;           // first of this lane's four units
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                float4 z = gload4(biasp + g * 256 + p8);
-                if (g == 2) { z.x += 1.0f; z.y += 1.0f; z.z += 1.0f; z.w += 1.0f; }       // forget_bias
-                if (has_feat) {
-                    const float4 w0 = gload4(wf + g * 256 + p8), w1 = gload4(wf + 1024 + g * 256 + p8),
-                                 w2 = gload4(wf + 2048 + g * 256 + p8);
-                    // explicit fma chains: every instantiation must round identically
-                    float4 x = make_float4(fmaf(f2, w2.x, fmaf(f1, w1.x, f0 * w0.x)), fmaf(f2, w2.y, fmaf(f1, w1.y, f0 * w0.y)),
-                                           fmaf(f2, w2.z, fmaf(f1, w1.z, f0 * w0.z)), fmaf(f2, w2.w, fmaf(f1, w1.w, f0 * w0.w)));
-                    if (has_table) {
-                        const float4 tb = gload4(tab + (size_t)code * 1024 + g * 256 + p8);
-                        x.x += tb.x; x.y += tb.y; x.z += tb.z; x.w += tb.w;
-                    }
-                    z.x += x.x; z.y += x.y; z.z += x.z; z.w += x.w;
-                }
-                acc[nt][4 * g] = z.x; acc[nt][4 * g + 1] = z.y; acc[nt][4 * g + 2] = z.z; acc[nt][4 * g + 3] = z.w;
-            }
-        }
-    }
+    for (int nt = 0; nt < NT; ++nt) lstm_acc_init(C, (ng * NT + nt) * 8 + 4 * half, rowc, T, acc[nt]);
     const unsigned lane4 = (unsigned)lane * 4;
     const size_t mt_off = (size_t)mt * LSTM_MT_FLOATS;
 #pragma unroll
@@ -830,14 +858,155 @@ __global__ __launch_bounds__(256, NT == 1 ? 4 : 2) void lstm_cell_kernel(const L
     for (int nt = 0; nt < NT; ++nt) {
         const int ntile = ng * NT + nt;
         float4 cn, hn;
-        cn.x = fmaf(fast_sigmoid(acc[nt][8]), cp[nt].x, fast_sigmoid(acc[nt][0]) * fast_tanh(acc[nt][4]));
-        cn.y = fmaf(fast_sigmoid(acc[nt][9]), cp[nt].y, fast_sigmoid(acc[nt][1]) * fast_tanh(acc[nt][5]));
-        cn.z = fmaf(fast_sigmoid(acc[nt][10]), cp[nt].z, fast_sigmoid(acc[nt][2]) * fast_tanh(acc[nt][6]));
-        cn.w = fmaf(fast_sigmoid(acc[nt][11]), cp[nt].w, fast_sigmoid(acc[nt][3]) * fast_tanh(acc[nt][7]));
-        hn.x = fast_sigmoid(acc[nt][12]) * fast_tanh(cn.x);
-        hn.y = fast_sigmoid(acc[nt][13]) * fast_tanh(cn.y);
-        hn.z = fast_sigmoid(acc[nt][14]) * fast_tanh(cn.z);
-        hn.w = fast_sigmoid(acc[nt][15]) * fast_tanh(cn.w);
+        lstm_gates(acc[nt], cp[nt], cn, hn);
+        const size_t off = mt_off + (unsigned)ntile * 256 + lane4;
+        const v4f co = {cn.x, cn.y, cn.z, cn.w}, ho = {hn.x, hn.y, hn.z, hn.w};
+        *(__attribute__((address_space(1))) v4f*)(C.c + off) = co;
+        *(__attribute__((address_space(1))) v4f*)(C.h_out + off) = ho;
+        if (C.h_row && row < n)
+            *(__attribute__((address_space(1))) v4f*)(C.h_row + (size_t)row * 256 + ntile * 8 + 4 * half) = ho;
+    }
+}
+
+// The same cells with the operands SHARED through LDS. A CU's vector-memory path moves ~64 B/clk at best; the
+// direct-to-register kernel above asks it for 32 B/clk/CU (every wave fetches its own 1 KiB activation and weight
+// fragment per four MFMAs), which is what bounds it. Here a workgroup owns a 64-site x (64 * NT)-column block: waves
+// (mi, nj) = (wave & 1, wave >> 1) take m-tile mi and the NT n-tiles of column group nj, so every activation
+// fragment feeds two waves and every weight fragment two waves -- half the global traffic per MFMA. Fragments are
+// 1 KiB images in global memory already, so they go global -> LDS by LDS-DMA (no VGPR round trip): a ring of three
+// stages of four k-groups, requests two stages ahead, ONE barrier per stage (16 * NT MFMAs per wave), a counted vmcnt
+// in front of it so the next stage's requests stay in flight across the barrier.
+// LDS-DMA of one 1 KiB wave fragment: lane i's 16 bytes at gsrc land at LDS byte address lds_dst + 16 i (lds_dst is
+// wave-uniform and goes through M0). Written as inline asm on purpose: with the builtin, hipcc (ROCm 7.2) tracks the
+// transfer as an LDS store and puts `s_waitcnt vmcnt(0)` in front of the next ds_read, which would drain the
+// requests this kernel keeps in flight across its barrier; the kernel counts its own vmcnt instead (see the loop).
+// M0 is compiler-reserved: saved and restored inside the statement (cdna_hip_programming.md 5.7).
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst)
+{
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_dst)
+                 : "memory");
+}
+
+template <int NT>
+__global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void lstm_cell_lds_kernel(const LstmLaunch* __restrict__ Lp)
+{
+    constexpr int FR = 2 + 2 * NT;            // fragments per k-group: 2 m-tiles of h, 2 * NT n-tiles of weights
+    constexpr int KGS = 4;                    // k-groups per stage
+    constexpr int LPS = FR;                   // DMA requests per wave and stage (KGS * FR over 4 waves)
+    constexpr int STAGE = KGS * FR * 256;     // floats
+    __shared__ __attribute__((aligned(16))) float ring[3 * STAGE];
+
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int mi = wave & 1, nj = wave >> 1;
+    int bid;
+    {
+        const int total = gridDim.x, q = total >> 3, r = total & 7;
+        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        bid = xcd * q + (xcd < r ? xcd : r) + idx;
+    }
+    const int mtiles = Lp->mtiles;
+    const int mblocks = (mtiles + 1) >> 1;
+    constexpr int NGROUPS = 16 / NT;
+    const int per_cell = mblocks * NGROUPS;
+    const int ci = bid / per_cell, rem = bid - ci * per_cell;
+    const int mb = rem % mblocks, ng = rem / mblocks;
+    const LstmCell& C = Lp->cell[ci];
+    const int mt_raw = mb * 2 + mi;
+    const bool valid = mt_raw < mtiles;                       // odd m-tile count: the last block's second half idles along
+    const int mt = valid ? mt_raw : mtiles - 1;
+    const int half = lane >> 5, r31 = lane & 31;
+    const int n = Lp->n, T = Lp->T;
+    const int row = mt * 32 + r31;
+    const int rowc = row < n ? row : n - 1;
+    const unsigned lane16 = (unsigned)lane * 16;
+
+    const bool has_x = C.ax != nullptr, has_h = C.ah != nullptr;
+    const int KG = (has_x ? 32 : 0) + (has_h ? 32 : 0);
+    const int nstages = KG / KGS;
+    const char* const a0 = reinterpret_cast<const char*>(has_x ? C.ax : C.ah);
+    const long dseg = (has_x && has_h) ? (reinterpret_cast<const char*>(C.ah) - reinterpret_cast<const char*>(C.ax)) - 32 * 1024 : 0;
+    // request j of this wave: linear fragment index q = wave + 4 j of the stage -> (k-group kgi, fragment f)
+    const char* src[LPS];
+    int kgi_[LPS];
+    bool is_a[LPS];
+#pragma unroll
+    for (int j = 0; j < LPS; ++j) {
+        const int q = wave + 4 * j, kgi = q / FR, f = q - kgi * FR;
+        kgi_[j] = kgi;
+        is_a[j] = f < 2;
+        if (f < 2) {
+            const int m = min(mb * 2 + f, mtiles - 1);
+            src[j] = a0 + (size_t)m * LSTM_MT_FLOATS * 4 + (size_t)kgi * 1024 + lane16;
+        } else {
+            const int ntile = ng * 2 * NT + (f - 2);
+            src[j] = reinterpret_cast<const char*>(C.Bp) + ((size_t)ntile * C.kg_stride + kgi) * 1024 + lane16;
+        }
+    }
+    const unsigned ring_lds = (unsigned)(size_t)(__attribute__((address_space(3))) float*)ring;    // LDS byte address
+    auto request = [&](int st) {                               // stage st -> ring slot st % 3
+        const unsigned dst = __builtin_amdgcn_readfirstlane(ring_lds + ((st % 3) * STAGE + wave * 256) * 4);
+#pragma unroll
+        for (int j = 0; j < LPS; ++j) {
+            const int kg = st * KGS + kgi_[j];
+            const long off = (long)st * (KGS * 1024) + ((is_a[j] && kg >= 32) ? dseg : 0);
+            glds16(src[j] + off, dst + j * 4096);              // fragment q = wave + 4 j of the stage, 1 KiB each
+        }
+    };
+    if (nstages > 0) request(0);
+    if (nstages > 1) request(1);
+
+    // ---- accumulator's initial value: bias (+1 on f), layer 0: table row + (mean, std, len) terms
+    floatx16 acc[NT];
+    float4 cp[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) lstm_acc_init(C, ((ng * 2 + nj) * NT + nt) * 8 + 4 * half, rowc, T, acc[nt]);
+    const size_t mt_off = (size_t)mt * LSTM_MT_FLOATS;
+    const unsigned lane4 = (unsigned)lane * 4;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        cp[nt] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (!C.c_zero) cp[nt] = gload4(C.c + mt_off + (unsigned)(((ng * 2 + nj) * NT + nt)) * 256 + lane4);
+    }
+
+    // every compiler-visible load is retired here, so hipcc has no reason to put a vmcnt wait into the loop below (it
+    // cannot see the LDS-DMA requests, which are counted by hand)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        asm volatile("" : "+v"(cp[nt].x), "+v"(cp[nt].y), "+v"(cp[nt].z), "+v"(cp[nt].w));
+        asm volatile("" : "+v"(acc[nt]));          // bias loads land directly in the accumulator registers
+    }
+    for (int st = 0; st < nstages; ++st) {
+        // stage st has landed in LDS once every wave's requests for it are done: counted wait (stage st + 1 stays in
+        // flight), then the barrier; it also tells everybody that ring slot (st + 2) % 3 -- read during stage st - 1 --
+        // is free again
+        if (st + 1 < nstages) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (st + 2 < nstages) request(st + 2);
+        const float* sb = ring + (st % 3) * STAGE + lane4;
+#pragma unroll
+        for (int kgi = 0; kgi < KGS; ++kgi) {
+            const float4 a = *reinterpret_cast<const float4*>(sb + (kgi * FR + mi) * 256);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const float4 b = *reinterpret_cast<const float4*>(sb + (kgi * FR + 2 + nj * NT + nt) * 256);
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(b.x, a.x, acc[nt], 0, 0, 0);
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(b.y, a.y, acc[nt], 0, 0, 0);
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(b.z, a.z, acc[nt], 0, 0, 0);
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(b.w, a.w, acc[nt], 0, 0, 0);
+            }
+        }
+    }
+
+    if (!valid) return;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int ntile = (ng * 2 + nj) * NT + nt;
+        float4 cn, hn;
+        lstm_gates(acc[nt], cp[nt], cn, hn);
         const size_t off = mt_off + (unsigned)ntile * 256 + lane4;
         const v4f co = {cn.x, cn.y, cn.z, cn.w}, ho = {hn.x, hn.y, hn.z, hn.w};
         *(__attribute__((address_space(1))) v4f*)(C.c + off) = co;
@@ -850,8 +1019,10 @@ __global__ __launch_bounds__(256, NT == 1 ? 4 : 2) void lstm_cell_kernel(const L
 hipError_t launch_lstm_cells(int nt, const LstmLaunch* d_launch, int ncell, int mtiles, hipStream_t s)
 {
     if (ncell <= 0 || mtiles <= 0) return hipSuccess;
-    const int mblocks = (mtiles + 3) / 4;
+    const int mblocks = (mtiles + 3) / 4, mblocks2 = (mtiles + 1) / 2;
     switch (nt) {
+    case 101: hipLaunchKernelGGL(lstm_cell_lds_kernel<1>, dim3(ncell * mblocks2 * 16), dim3(256), 0, s, d_launch); break;
+    case 102: hipLaunchKernelGGL(lstm_cell_lds_kernel<2>, dim3(ncell * mblocks2 * 8), dim3(256), 0, s, d_launch); break;
     case 1: hipLaunchKernelGGL(lstm_cell_kernel<1>, dim3(ncell * mblocks * 32), dim3(256), 0, s, d_launch); break;
     case 2: hipLaunchKernelGGL(lstm_cell_kernel<2>, dim3(ncell * mblocks * 16), dim3(256), 0, s, d_launch); break;
     case 4: hipLaunchKernelGGL(lstm_cell_kernel<4>, dim3(ncell * mblocks * 8), dim3(256), 0, s, d_launch); break;

@@ -71,8 +71,10 @@ typedef struct ds_config {
 #define DS_TUNE_DEBUG_STAMPS 4   /* attach the s_memtime stamp buffer of the fused kernels (tools/stamps.py)          */
 /* ds_config.reserved[3] */
 #define DS_LSTM_TILING_AUTO 0    /* by forward size */
-#define DS_LSTM_TILING_NARROW 1
-#define DS_LSTM_TILING_WIDE 2
+#define DS_LSTM_TILING_NARROW 1  /* one 32-column n-tile per wave  */
+#define DS_LSTM_TILING_WIDE 2    /* four n-tiles per wave          */
+#define DS_LSTM_TILING_LDS1 3    /* fp32 cells: operands shared through LDS, 64 x 64 workgroup tile  */
+#define DS_LSTM_TILING_LDS2 4    /* fp32 cells: operands shared through LDS, 64 x 128 workgroup tile */
 
 /* Replaces Model(...) + tf.Session(): call_modifications.py:203-209. */
 int ds_create(const ds_config *cfg, ds_handle **out);

@@ -127,18 +127,33 @@ def test_cli_accepts_a_tf_checkpoint_prefix_and_precision(small_weights, tmp_pat
     assert np.abs(p32 - p16).max() <= 5e-3 and np.abs(p16.sum(axis=1) - 1.0).max() <= 1e-6
 
 
-def test_run_item_pipelines_chunks_with_identical_bits(small_weights):
-    """The per-item helper of the multi-GPU harness keeps an item's chunks in flight (ds_submit / ds_wait)."""
-    from types import SimpleNamespace
-    from deepsignal_amd import call_modifications as cm
+def test_row_pipeline_fills_batches_across_items_with_identical_bits(small_weights):
+    """call_mods' row pipeline (ds_submit / ds_wait, batches filled across queue items, several in flight): the rows it
+    emits carry the bits of a plain blocking run over the same sites, in feed order, tags intact."""
+    from deepsignal_amd import call_modifications as cm, fastio
     from deepsignal_amd.engine import Engine
     n = 1000
     feats = synth.synthetic_features(n, seed=3)
-    item = SimpleNamespace(labels=np.zeros(n, np.int32), kmer=feats["kmer"], means=feats["means"], stds=feats["stds"],
-                           lens=feats["sanums"], signals=feats["signals"])
     eng = Engine(max_batch=128, slots=3)
     eng.load_weights(small_weights)
-    a, p = cm._run_item(eng, item, 128)
     ra, rp = eng.run(feats["kmer"], feats["means"], feats["stds"], feats["sanums"], feats["signals"])
+    cuts = [0, 37, 37 + 128, 400, 401, 1000]          # ragged items: batches straddle item borders
+    items = []
+    for tag, (s0, e0) in enumerate(zip(cuts[:-1], cuts[1:])):
+        m = e0 - s0
+        info = np.frombuffer(("r%04d" * m % tuple(range(s0, e0))).encode(), np.uint8).copy()
+        items.append(fastio.FeatureItem(info, np.arange(m + 1, dtype=np.int64) * 5, feats["kmer"][s0:e0], feats["means"][s0:e0],
+                                        feats["stds"][s0:e0], feats["sanums"][s0:e0], feats["signals"][s0:e0],
+                                        np.zeros(m, np.int32)))
+    got = []
+    pipe = cm._RowPipeline(eng, 128, lambda tag, data: got.append((tag, data)))
+    for tag, it in enumerate(items):
+        pipe.feed(it, tag)
+    pipe.flush()
     eng.close()
-    assert np.array_equal(a, ra) and np.array_equal(p, rp)
+    assert pipe.nsites == n and [t for t, _ in got] == sorted(t for t, _ in got)
+    rows = b"".join(d for _, d in got).decode().splitlines()
+    assert len(rows) == n
+    info_all = np.frombuffer(("r%04d" * n % tuple(range(n))).encode(), np.uint8)
+    expect = fastio.format_rows(info_all, np.arange(n + 1, dtype=np.int64) * 5, ra, rp, feats["kmer"]).decode().splitlines()
+    assert rows == expect
