@@ -184,6 +184,7 @@ struct ds_handle {
     bool debug_keep_pool = false;   // keep the stand-alone maxpool kernels (diagnostic)
     const float* zero_seg = nullptr;
     unsigned long long* dbg_stamps = nullptr;   // [NMOD][1024 wgs][2 waves][8] when DS_TUNE_DEBUG_STAMPS is set
+    unsigned long long* dbg_lstm = nullptr;     // [32 diagonals][1024 wgs][8] stamps of the fp32 BiLSTM cell launches
     std::vector<Stage> stages;
     KernelStat kstat[K_COUNT];
     // pipelining: consecutive forwards rotate over independent slots (own workspace, streams, graphs), so the
@@ -754,12 +755,13 @@ int build_plan(ds_handle* h, int n, Plan* plan)
         // kernel variant: direct-to-register (1, 2 or 4 n-tiles per wave) or operands shared through LDS (101 / 102)
         const int nt = h->lstm_variant == DS_LSTM_TILING_NARROW ? 1 : h->lstm_variant == DS_LSTM_TILING_WIDE ? 4
                        : h->lstm_variant == DS_LSTM_TILING_LDS1 ? 101 : h->lstm_variant == DS_LSTM_TILING_LDS2 ? 102
-                       : (n <= 768 ? 1 : n <= 2048 ? 2 : 4);
+                       : (n <= 1024 ? 101 : 102);
         const size_t step = (size_t)h->Bp32 * HID;                         // floats of one time step in H
         for (int d = 0; d < T + NLAYER - 1; ++d) {
             LstmLaunch L;
             memset(&L, 0, sizeof L);
             L.n = n; L.mtiles = mtiles; L.T = T;
+            L.dbg = (h->dbg_lstm && d < 32) ? h->dbg_lstm + (size_t)d * 1024 * 8 : nullptr;
             double flops = 0;
             for (int dir = 0; dir < 2; ++dir)
                 for (int l = 0; l < NLAYER; ++l) {
@@ -783,6 +785,10 @@ int build_plan(ds_handle* h, int n, Plan* plan)
                     C.t = t; C.use_feat = l == 0; C.c_zero = sidx == 0;
                     flops += 2.0 * n * 4 * HID * ((l > 0 ? HID : 0) + (sidx > 0 ? HID : 0));
                 }
+            // heaviest cells first (K = 512, then 256, then 0): lstm_logical_tile deals tiles to the CUs in that order
+            std::stable_sort(L.cell, L.cell + L.ncell, [](const LstmCell& a, const LstmCell& b) {
+                return (a.ax != nullptr) + (a.ah != nullptr) > (b.ax != nullptr) + (b.ah != nullptr);
+            });
             Op op{};
             op.kind = OP_LSTM; op.stream = 1; op.stage = st;
             op.launch_index = (int)plan->lstm_launches.size();
@@ -1200,6 +1206,8 @@ static int ds_create_impl(const ds_config* cfg, ds_handle** out)
         if (!rc && (flags & DS_TUNE_DEBUG_STAMPS)) {
             rc = dalloc(h, &h->dbg_stamps, (size_t)NMOD * 1024 * 16);
             if (!rc) hipMemset(h->dbg_stamps, 0, (size_t)NMOD * 1024 * 16 * 8);
+            if (!rc) rc = dalloc(h, &h->dbg_lstm, (size_t)32 * 1024 * 8);
+            if (!rc) hipMemset(h->dbg_lstm, 0, (size_t)32 * 1024 * 8 * 8);
         }
     }
     if (rc) { g_create_error = h->err; ds_destroy(h); return rc; }
@@ -1537,6 +1545,65 @@ int64_t ds_get_intermediate(ds_handle* h, const char* name, float* out, int64_t 
                         memcpy(out + ((size_t)i * h->T + t) * HID + 8 * g + 4 * half,
                                tmp.data() + (size_t)t * h->Bp32 * HID + (size_t)(i / 32) * LSTM_MT_FLOATS + ((size_t)g * 64 + half * 32 + i % 32) * 4, 16);
         return count;
+    }
+    if (s.rfind("lstm_rawstamps", 0) == 0) {
+        // "lstm_rawstampsD": per workgroup of diagonal D, 8 floats: entry (10 ns ticks after the first entry), cycles
+        // entry -> K loop, K loop, exit part, exit tick, CU key (xcc << 8 | se << 5 | sh << 4 | cu), 0, valid
+        if (!h->dbg_lstm) return fail(h, DS_ERR_INVALID, "create the handle with DS_TUNE_DEBUG_STAMPS in ds_config.reserved[2]");
+        const int d = atoi(s.c_str() + 14);
+        if (d < 0 || d >= 32 || capacity < 1024 * 8) return fail(h, DS_ERR_INVALID, "bad lstm_rawstamps request");
+        std::vector<unsigned long long> st(1024 * 8);
+        if (hipMemcpy(st.data(), h->dbg_lstm + (size_t)d * 1024 * 8, st.size() * 8, hipMemcpyDeviceToHost) != hipSuccess) return fail(h, DS_ERR_HIP, "hipMemcpy D2H");
+        unsigned long long t0 = ~0ull;
+        for (int wg = 0; wg < 1024; ++wg) if (st[(size_t)wg * 8 + 5]) t0 = std::min(t0, st[(size_t)wg * 8]);
+        for (int wg = 0; wg < 1024; ++wg) {
+            const unsigned long long* q = &st[(size_t)wg * 8];
+            float* o = out + (size_t)wg * 8;
+            if (!q[5]) { for (int i = 0; i < 8; ++i) o[i] = 0.f; continue; }
+            const unsigned hw = (unsigned)q[6];
+            o[0] = (float)(q[0] - t0); o[1] = (float)(q[2] - q[1]); o[2] = (float)(q[3] - q[2]); o[3] = (float)(q[4] - q[3]);
+            o[4] = (float)(q[5] - t0);
+            o[5] = (float)((((unsigned)q[7] & 0xf) << 8) | (((hw >> 13) & 7) << 5) | (((hw >> 12) & 1) << 4) | ((hw >> 8) & 0xf));
+            o[6] = 0.f; o[7] = 1.f;
+        }
+        return 1024 * 8;
+    }
+    if (s.rfind("lstm_stamps", 0) == 0) {
+        // "lstm_stampsD": diagonal D of the last forward, 12 floats: workgroups, mean / max cycles of [entry -> K loop],
+        // [K loop], [exit part], kernel span (us, first entry -> last exit), entry spread (us), mean workgroup life (us),
+        // distinct CUs seen, most workgroups on one CU, mean in-kernel clock (GHz)
+        if (!h->dbg_lstm) return fail(h, DS_ERR_INVALID, "create the handle with DS_TUNE_DEBUG_STAMPS in ds_config.reserved[2]");
+        const int d = atoi(s.c_str() + 11);
+        if (d < 0 || d >= 32 || capacity < 12) return fail(h, DS_ERR_INVALID, "bad lstm_stamps request");
+        std::vector<unsigned long long> st(1024 * 8);
+        if (hipMemcpy(st.data(), h->dbg_lstm + (size_t)d * 1024 * 8, st.size() * 8, hipMemcpyDeviceToHost) != hipSuccess) return fail(h, DS_ERR_HIP, "hipMemcpy D2H");
+        hipMemset(h->dbg_lstm + (size_t)d * 1024 * 8, 0, 1024 * 8 * 8);
+        double sum[3] = {0, 0, 0}, mx[3] = {0, 0, 0}, life = 0, clk = 0;
+        unsigned long long t0 = ~0ull, t0max = 0, t1 = 0;
+        std::map<unsigned, int> per_cu;
+        int cnt = 0;
+        for (int wg = 0; wg < 1024; ++wg) {
+            const unsigned long long* q = &st[(size_t)wg * 8];
+            if (!q[5]) continue;
+            ++cnt;
+            for (int i = 0; i < 3; ++i) { const double dlt = (double)(q[2 + i] - q[1 + i]); sum[i] += dlt; mx[i] = std::max(mx[i], dlt); }
+            t0 = std::min(t0, q[0]); t0max = std::max(t0max, q[0]); t1 = std::max(t1, q[5]);
+            life += (double)(q[5] - q[0]) * 0.01;
+            if (q[5] > q[0]) clk += (double)(q[4] - q[1]) / ((double)(q[5] - q[0]) * 10.0);
+            const unsigned hw = (unsigned)q[6], key = ((unsigned)q[7] & 0xf) << 16 | ((hw >> 13) & 7) << 12 | ((hw >> 12) & 1) << 8 | ((hw >> 8) & 0xf);
+            per_cu[key] += 1;
+        }
+        int most = 0;
+        for (auto& kv : per_cu) most = std::max(most, kv.second);
+        out[0] = (float)cnt;
+        for (int i = 0; i < 3; ++i) { out[1 + 2 * i] = cnt ? (float)(sum[i] / cnt) : 0.f; out[2 + 2 * i] = (float)mx[i]; }
+        out[7] = cnt ? (float)((double)(t1 - t0) * 0.01) : 0.f;
+        out[8] = cnt ? (float)((double)(t0max - t0) * 0.01) : 0.f;
+        out[9] = cnt ? (float)(life / cnt) : 0.f;
+        out[10] = (float)per_cu.size();
+        out[11] = (float)most;
+        if (capacity >= 13) out[12] = cnt ? (float)(clk / cnt) : 0.f;
+        return capacity >= 13 ? 13 : 12;
     }
     if (s.rfind("stamps", 0) == 0) {   // "stampsN": phase stamp deltas (cycles) of fused module N, wave 0 and wave 7, averaged over workgroups
         if (!h->dbg_stamps) return fail(h, DS_ERR_INVALID, "create the handle with DS_TUNE_DEBUG_STAMPS in ds_config.reserved[2]");

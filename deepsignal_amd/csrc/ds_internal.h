@@ -109,6 +109,7 @@ struct LstmCell {
 struct LstmLaunch {
     LstmCell cell[LSTM_MAX_CELLS];
     int ncell, n, mtiles, T;
+    unsigned long long* dbg;   // diagnostic (DS_TUNE_DEBUG_STAMPS): [workgroup][8] time stamps of wave 0, null in normal runs
 };
 // nt = 32-column n-tiles per wave (1, 2 or 4): the same bits for every nt (same K order per output element)
 hipError_t launch_lstm_cells(int nt, const LstmLaunch* d_launch, int ncell, int mtiles, hipStream_t s);

@@ -759,6 +759,22 @@ __device__ __forceinline__ void lstm_gates(const floatx16& acc, const float4& cp
     hn.w = fast_sigmoid(acc[15]) * fast_tanh(cn.w);
 }
 
+// Workgroup -> logical tile of an LSTM launch. Cells of a diagonal differ in K (layer 0 multiplies h only, first steps
+// x only): a tile of a K = 256 cell is half the matrix work of a K = 512 one, and a launch is as slow as its busiest
+// CU. The host sorts the cells by descending K; this map then deals the logical tiles (cell-major, so heaviest first)
+// in ROUNDS of one tile per CU, using the dispatch pattern observed on MI355X (workgroup b -> XCD b % 8, CU slot
+// (b >> 3) % 32 of that XCD, i.e. blocks b, b + 256, b + 512 share a CU; tools/lstm_rawstamps.py): on a full diagonal
+// every CU gets two K = 512 tiles and one K = 256 tile instead of three of a kind. Inside a round an XCD owns 32
+// consecutive logical tiles (m-blocks of a few weight panels), so its L2 holds a contiguous slice of one cell.
+// Placement is a speed assumption only: any other dispatch order gives the same results, just less balance.
+__device__ __forceinline__ int lstm_logical_tile(int b, int total)
+{
+    const int full = total & ~255;                 // tiles in whole rounds
+    if (b < full) return (b & ~255) + (b & 7) * 32 + ((b & 255) >> 3);
+    const int R = total - full, p = b - full, q = R >> 3, r = R & 7, xcd = p & 7;
+    return full + xcd * q + (xcd < r ? xcd : r) + (p >> 3);
+}
+
 // ---------------------------------------------------------------------------------------------
 // fp32 BiLSTM cells of one wavefront diagonal (layers.py:45-72; TF LSTMCell: gate order i, j, f, o, forget_bias 1.0
 // added at run time; c' = sigmoid(f + 1) c + sigmoid(i) tanh(j); h' = sigmoid(o) tanh(c')).
@@ -777,14 +793,17 @@ template <int NT>
 __global__ __launch_bounds__(256, NT == 1 ? 4 : 2) void lstm_cell_kernel(const LstmLaunch* __restrict__ Lp)
 {
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    // XCD-aware order (see gemm_kernel): every XCD gets a contiguous run of logical tiles, m-blocks of one weight
-    // panel adjacent, so a weight fragment is pulled into ONE L2 and stays there from launch to launch
-    int bid;
-    {
-        const int total = gridDim.x, q = total >> 3, r = total & 7;
-        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
-        bid = xcd * q + (xcd < r ? xcd : r) + idx;
-    }
+    // diagnostic stamps (wave 0, lane 0 of every workgroup; only when a debug buffer is attached):
+    // [0] s_memrealtime at entry (100 MHz, comparable across CUs)  [1..4] s_memtime (shader clock) at entry / before the
+    // K loop / after it / at exit  [5] s_memrealtime at exit  [6] HW_ID  [7] XCC_ID
+    unsigned long long* const sdst = Lp->dbg ? Lp->dbg + (size_t)blockIdx.x * 8 : nullptr;
+    const bool stamp = sdst != nullptr && threadIdx.x == 0;
+#define DS_LSTAMP(i, v) do { if (stamp) sdst[i] = (v); } while (0)
+    DS_LSTAMP(0, __builtin_amdgcn_s_memrealtime());
+    DS_LSTAMP(1, __builtin_amdgcn_s_memtime());
+    DS_LSTAMP(6, (unsigned long long)__builtin_amdgcn_s_getreg(63492));     // HW_REG_HW_ID, all 32 bits
+    DS_LSTAMP(7, (unsigned long long)__builtin_amdgcn_s_getreg(63508));     // HW_REG_XCC_ID
+    const int bid = lstm_logical_tile(blockIdx.x, gridDim.x);      // work-balanced, XCD-aware order
     const int mtiles = Lp->mtiles;
     const int mblocks = (mtiles + 3) >> 2;
     constexpr int NGROUPS = 32 / NT;
@@ -824,6 +843,7 @@ __global__ __launch_bounds__(256, NT == 1 ? 4 : 2) void lstm_cell_kernel(const L
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) bpn[nt] = reinterpret_cast<const char*>(C.Bp + (size_t)(ng * NT + nt) * C.kg_stride * 256);
     const unsigned lane16 = (unsigned)lane * 16;
+    DS_LSTAMP(2, __builtin_amdgcn_s_memtime());
     if (KG > 0) {
         float4 a[4], b[4][NT];
         auto request = [&](int slot, int kg) {           // slot is a literal at every call site
@@ -852,6 +872,7 @@ __global__ __launch_bounds__(256, NT == 1 ? 4 : 2) void lstm_cell_kernel(const L
             consume(3); request(3, kg + 7); __builtin_amdgcn_sched_barrier(0);
         }
     }
+    DS_LSTAMP(3, __builtin_amdgcn_s_memtime());
 
     // ---- gates, new state, coalesced fragment-major stores
 #pragma unroll
@@ -866,6 +887,9 @@ __global__ __launch_bounds__(256, NT == 1 ? 4 : 2) void lstm_cell_kernel(const L
         if (C.h_row && row < n)
             *(__attribute__((address_space(1))) v4f*)(C.h_row + (size_t)row * 256 + ntile * 8 + 4 * half) = ho;
     }
+    DS_LSTAMP(4, __builtin_amdgcn_s_memtime());
+    DS_LSTAMP(5, __builtin_amdgcn_s_memrealtime());
+#undef DS_LSTAMP
 }
 
 // The same cells with the operands SHARED through LDS. A CU's vector-memory path moves ~64 B/clk at best; the
@@ -901,12 +925,17 @@ __global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void lstm_cell_lds_kernel(con
 
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int mi = wave & 1, nj = wave >> 1;
-    int bid;
-    {
-        const int total = gridDim.x, q = total >> 3, r = total & 7;
-        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
-        bid = xcd * q + (xcd < r ? xcd : r) + idx;
-    }
+    // diagnostic stamps (wave 0, lane 0 of every workgroup; only when a debug buffer is attached):
+    // [0] s_memrealtime at entry (100 MHz, comparable across CUs)  [1..4] s_memtime (shader clock) at entry / before the
+    // K loop / after it / at exit  [5] s_memrealtime at exit  [6] HW_ID  [7] XCC_ID
+    unsigned long long* const sdst = Lp->dbg ? Lp->dbg + (size_t)blockIdx.x * 8 : nullptr;
+    const bool stamp = sdst != nullptr && threadIdx.x == 0;
+#define DS_LSTAMP(i, v) do { if (stamp) sdst[i] = (v); } while (0)
+    DS_LSTAMP(0, __builtin_amdgcn_s_memrealtime());
+    DS_LSTAMP(1, __builtin_amdgcn_s_memtime());
+    DS_LSTAMP(6, (unsigned long long)__builtin_amdgcn_s_getreg(63492));     // HW_REG_HW_ID, all 32 bits
+    DS_LSTAMP(7, (unsigned long long)__builtin_amdgcn_s_getreg(63508));     // HW_REG_XCC_ID
+    const int bid = lstm_logical_tile(blockIdx.x, gridDim.x);      // work-balanced, XCD-aware order
     const int mtiles = Lp->mtiles;
     const int mblocks = (mtiles + 1) >> 1;
     constexpr int NGROUPS = 16 / NT;
@@ -978,6 +1007,7 @@ __global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void lstm_cell_lds_kernel(con
         asm volatile("" : "+v"(cp[nt].x), "+v"(cp[nt].y), "+v"(cp[nt].z), "+v"(cp[nt].w));
         asm volatile("" : "+v"(acc[nt]));          // bias loads land directly in the accumulator registers
     }
+    DS_LSTAMP(2, __builtin_amdgcn_s_memtime());
     for (int st = 0; st < nstages; ++st) {
         // stage st has landed in LDS once every wave's requests for it are done: counted wait (stage st + 1 stays in
         // flight), then the barrier; it also tells everybody that ring slot (st + 2) % 3 -- read during stage st - 1 --
@@ -1001,6 +1031,7 @@ __global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void lstm_cell_lds_kernel(con
         }
     }
 
+    DS_LSTAMP(3, __builtin_amdgcn_s_memtime());
     if (!valid) return;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
@@ -1014,6 +1045,9 @@ __global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void lstm_cell_lds_kernel(con
         if (C.h_row && row < n)
             *(__attribute__((address_space(1))) v4f*)(C.h_row + (size_t)row * 256 + ntile * 8 + 4 * half) = ho;
     }
+    DS_LSTAMP(4, __builtin_amdgcn_s_memtime());
+    DS_LSTAMP(5, __builtin_amdgcn_s_memrealtime());
+#undef DS_LSTAMP
 }
 
 hipError_t launch_lstm_cells(int nt, const LstmLaunch* d_launch, int ncell, int mtiles, hipStream_t s)
