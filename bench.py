@@ -235,6 +235,8 @@ def main():
                     help="skip pass C (every launch on one stream); used for the rocprofv3 cross-check, whose per-kernel "
                          "averages would otherwise blend co-resident and stand-alone launches")
     ap.add_argument("--no-host-path", action="store_true", help="skip the pcie_inclusive and e2e_tsv legs")
+    ap.add_argument("--lstm-tiling", default="auto", help="diagnostic: force a BiLSTM cell-kernel variant (Engine(lstm_tiling=...))")
+    ap.add_argument("--slots", type=int, default=0, help="diagnostic: forwards in flight (0 = engine default, 8)")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher / collective / JSON plumbing only (stub engine, gloo, CPU): NOT a measurement")
     args = ap.parse_args()
@@ -271,7 +273,7 @@ def main():
     else:
         from deepsignal_amd.engine import Engine
         w = W.random_weights(seed=W.WEIGHT_SEED)          # TF-initializer style, randomised BN
-        eng = Engine(device=local_rank, max_batch=BATCH)
+        eng = Engine(device=local_rank, max_batch=BATCH, lstm_tiling=args.lstm_tiling, slots=args.slots)
         eng.load_weights(w)
 
     # this rank's shard: its own reads (20 sites per read), NPOOL distinct batches resident in HBM

@@ -11,7 +11,7 @@ f = synth.synthetic_features(B, seed=2)
 args = [f[k] for k in ("kmer", "means", "stds", "sanums", "signals")]
 ref = None
 for rep in range(2):
-    for var in ("narrow", "wide", "lds1", "lds2"):
+    for var in (sys.argv[2].split(",") if len(sys.argv) > 2 else ("narrow", "wide", "lds1", "lds2")):
         e = Engine(max_batch=B, slots=1, serial=True, lstm_tiling=var); e.load_weights(w)
         act, pred = e.run(*args)
         if ref is None: ref = act
