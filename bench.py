@@ -206,12 +206,14 @@ def e2e_tsv(eng, feats, rows, batch):
     with open(path, "w") as f:
         for i in range(rows):
             f.write("chr1\t%d\t+\t%d\tread_%06d\tt\t%s\n" % (1000 + i, i, i // 20, tails[i % nuniq]))
+    import contextlib
     try:
         out = os.path.join(tmpdir, "calls.tsv")
-        cm.call_mods(path, "unused", out, 17, 360, batch, 0.001, 2, 1, True, True, True, True, None, engine=eng)   # warm
-        t0 = time.perf_counter()
-        n = cm.call_mods(path, "unused", out, 17, 360, batch, 0.001, 2, 1, True, True, True, True, None, engine=eng)
-        dt = time.perf_counter() - t0
+        with contextlib.redirect_stdout(sys.stderr):       # call_mods prints its own timing line; stdout carries ONE JSON line
+            cm.call_mods(path, "unused", out, 17, 360, batch, 0.001, 2, 1, True, True, True, True, None, engine=eng)   # warm
+            t0 = time.perf_counter()
+            n = cm.call_mods(path, "unused", out, 17, 360, batch, 0.001, 2, 1, True, True, True, True, None, engine=eng)
+            dt = time.perf_counter() - t0
         assert n == rows and sum(1 for _ in open(out)) == rows
         size = os.path.getsize(path)
     finally:
