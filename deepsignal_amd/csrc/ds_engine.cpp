@@ -101,8 +101,7 @@ struct Plan {
     int n = 0;
     std::vector<GemmLaunch> launches;     // host copy
     GemmLaunch* d_launches = nullptr;
-    std::vector<LstmLaunch> lstm_launches;   // fp32 BiLSTM diagonals (lstm_cell_kernel)
-    LstmLaunch* d_lstm = nullptr;
+    std::vector<LstmLaunch> lstm_launches;   // fp32 BiLSTM diagonals (lstm_cell_*kernel): passed by value at launch
     std::vector<Op> ops;                  // merged issue order
     hipGraphExec_t graph = nullptr;
     int64_t uses = 0, last_use = 0;       // ragged tails produce many one-off sizes: graphs are captured for sizes that
@@ -871,13 +870,6 @@ int build_plan(ds_handle* h, int n, Plan* plan)
     h->allocs.push_back(p);
     plan->d_launches = static_cast<GemmLaunch*>(p);
     HIPCHK(h, hipMemcpy(p, LS.data(), LS.size() * sizeof(GemmLaunch), hipMemcpyHostToDevice));
-    if (!plan->lstm_launches.empty()) {
-        void* q = nullptr;
-        HIPCHK(h, hipMalloc(&q, plan->lstm_launches.size() * sizeof(LstmLaunch)));
-        h->allocs.push_back(q);
-        plan->d_lstm = static_cast<LstmLaunch*>(q);
-        HIPCHK(h, hipMemcpy(q, plan->lstm_launches.data(), plan->lstm_launches.size() * sizeof(LstmLaunch), hipMemcpyHostToDevice));
-    }
     return DS_OK;
 }
 
@@ -907,7 +899,7 @@ int issue_op(ds_handle* h, Plan& plan, const Op& op, hipStream_t s)
                                                   h->cur->H[1][NLAYER - 1], h->cur->joint, n, h->JP, 1, s));
         break;
     case OP_LSTM:
-        HIPCHK(h, launch_lstm_cells(op.c, plan.d_lstm + op.launch_index, op.a, op.b, s));
+        HIPCHK(h, launch_lstm_cells(op.c, plan.lstm_launches[op.launch_index], s));
         break;
     case OP_FUSED:
         if (h->bf16) HIPCHK(h, launch_inception_fused_bf16(op.tm, op.fa, s));
@@ -1034,12 +1026,7 @@ void destroy_plan(ds_handle* h, Plan& p)
         auto it = std::find(h->allocs.begin(), h->allocs.end(), (void*)p.d_launches);
         if (it != h->allocs.end()) h->allocs.erase(it);
     }
-    if (p.d_lstm) {
-        hipFree(p.d_lstm);
-        auto it = std::find(h->allocs.begin(), h->allocs.end(), (void*)p.d_lstm);
-        if (it != h->allocs.end()) h->allocs.erase(it);
-    }
-    p.graph = nullptr; p.d_launches = nullptr; p.d_lstm = nullptr; p.ops.clear();
+    p.graph = nullptr; p.d_launches = nullptr; p.ops.clear();
 }
 
 constexpr size_t MAX_PLANS_PER_SLOT = 24;

@@ -112,7 +112,7 @@ struct LstmLaunch {
     unsigned long long* dbg;   // diagnostic (DS_TUNE_DEBUG_STAMPS): [workgroup][8] time stamps of wave 0, null in normal runs
 };
 // nt = 32-column n-tiles per wave (1, 2 or 4): the same bits for every nt (same K order per output element)
-hipError_t launch_lstm_cells(int nt, const LstmLaunch* d_launch, int ncell, int mtiles, hipStream_t s);
+hipError_t launch_lstm_cells(int nt, const LstmLaunch& L, hipStream_t s);      // L travels as a by-value kernel argument
 
 // tile geometry per config (host needs it for grid sizing)
 struct TileGeom { int bm, bn, threads, ksplit; };

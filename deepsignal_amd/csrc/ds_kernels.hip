@@ -790,8 +790,10 @@ __device__ __forceinline__ int lstm_logical_tile(int b, int total)
 // coalesced 1 KiB stores.
 // Roofline: MFMA (fp32, 64 FLOP/clk/SIMD). Algorithmic FLOPs per launch = sum over cells of 2 * n * 1024 * K.
 template <int NT>
-__global__ __launch_bounds__(256, NT == 1 ? 4 : 2) void lstm_cell_kernel(const LstmLaunch* __restrict__ Lp)
+__global__ __launch_bounds__(256, NT == 1 ? 4 : 2) void lstm_cell_kernel(const LstmLaunch L_)
 {
+    const LstmLaunch* const Lp = &L_;      // by-value kernel argument: the descriptor arrives with the dispatch packet (kernarg
+                                           // segment) instead of behind a cold pointer chase at the start of every workgroup
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // diagnostic stamps (wave 0, lane 0 of every workgroup; only when a debug buffer is attached):
     // [0] s_memrealtime at entry (100 MHz, comparable across CUs)  [1..4] s_memtime (shader clock) at entry / before the
@@ -915,8 +917,9 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst)
 }
 
 template <int NT>
-__global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void lstm_cell_lds_kernel(const LstmLaunch* __restrict__ Lp)
+__global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void lstm_cell_lds_kernel(const LstmLaunch L_)
 {
+    const LstmLaunch* const Lp = &L_;      // by-value kernel argument (see lstm_cell_kernel)
     constexpr int FR = 2 + 2 * NT;            // fragments per k-group: 2 m-tiles of h, 2 * NT n-tiles of weights
     constexpr int KGS = 4;                    // k-groups per stage
     constexpr int LPS = FR;                   // DMA requests per wave and stage (KGS * FR over 4 waves)
@@ -1050,16 +1053,17 @@ __global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void lstm_cell_lds_kernel(con
 #undef DS_LSTAMP
 }
 
-hipError_t launch_lstm_cells(int nt, const LstmLaunch* d_launch, int ncell, int mtiles, hipStream_t s)
+hipError_t launch_lstm_cells(int nt, const LstmLaunch& L, hipStream_t s)
 {
+    const int ncell = L.ncell, mtiles = L.mtiles;
     if (ncell <= 0 || mtiles <= 0) return hipSuccess;
     const int mblocks = (mtiles + 3) / 4, mblocks2 = (mtiles + 1) / 2;
     switch (nt) {
-    case 101: hipLaunchKernelGGL(lstm_cell_lds_kernel<1>, dim3(ncell * mblocks2 * 16), dim3(256), 0, s, d_launch); break;
-    case 102: hipLaunchKernelGGL(lstm_cell_lds_kernel<2>, dim3(ncell * mblocks2 * 8), dim3(256), 0, s, d_launch); break;
-    case 1: hipLaunchKernelGGL(lstm_cell_kernel<1>, dim3(ncell * mblocks * 32), dim3(256), 0, s, d_launch); break;
-    case 2: hipLaunchKernelGGL(lstm_cell_kernel<2>, dim3(ncell * mblocks * 16), dim3(256), 0, s, d_launch); break;
-    case 4: hipLaunchKernelGGL(lstm_cell_kernel<4>, dim3(ncell * mblocks * 8), dim3(256), 0, s, d_launch); break;
+    case 101: hipLaunchKernelGGL(lstm_cell_lds_kernel<1>, dim3(ncell * mblocks2 * 16), dim3(256), 0, s, L); break;
+    case 102: hipLaunchKernelGGL(lstm_cell_lds_kernel<2>, dim3(ncell * mblocks2 * 8), dim3(256), 0, s, L); break;
+    case 1: hipLaunchKernelGGL(lstm_cell_kernel<1>, dim3(ncell * mblocks * 32), dim3(256), 0, s, L); break;
+    case 2: hipLaunchKernelGGL(lstm_cell_kernel<2>, dim3(ncell * mblocks * 16), dim3(256), 0, s, L); break;
+    case 4: hipLaunchKernelGGL(lstm_cell_kernel<4>, dim3(ncell * mblocks * 8), dim3(256), 0, s, L); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
