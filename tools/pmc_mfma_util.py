@@ -1,5 +1,13 @@
 """MFMA-pipe utilisation per kernel from one rocprofv3 --pmc run (SQ_VALU_MFMA_BUSY_CYCLES, GRBM_GUI_ACTIVE):
-busy cycles summed over the 1024 SIMDs / (1024 x active GPU cycles); GRBM_GUI_ACTIVE is summed over the 8 XCDs."""
+busy cycles summed over the 1024 SIMDs / (1024 x active GPU cycles); GRBM_GUI_ACTIVE is summed over the 8 XCDs.
+
+Two denominators are reported. `mfma_busy_frac` divides by GRBM_GUI_ACTIVE / 8, which MI355X_MICROARCH.md warns "reads
+high on dispatches shorter than about 0.3 ms" (the quotient GUI_ACTIVE / duration comes out at 2.6 - 2.9 GHz for the
+30 us LSTM launches, above the part's 2.4 GHz maximum), so it UNDER-states the busy share of short kernels.
+`mfma_busy_frac_at_inkernel_clock` divides by dispatch duration x the in-kernel clock that the kernels' own
+s_memtime / s_memrealtime stamps give under this load (2.17 GHz, tools/lstm_stamps.py): busy cycles per SIMD over the
+cycles the SIMD actually had."""
+INKERNEL_CLOCK_GHZ = 2.17
 import csv, glob, collections, json, sys
 f = (glob.glob(sys.argv[1] + '/*/*counter_collection.csv') + glob.glob(sys.argv[1] + '/*counter_collection.csv'))[0]
 disp = collections.OrderedDict()
@@ -17,7 +25,10 @@ out = {}
 for name, a in agg.items():
     if a['gui'] <= 0: continue
     util = a['busy'] / 1024 / a['gui']
-    out[name] = {'dispatches': a['n'], 'mean_us': round(a['dur_us'] / a['n'], 1), 'clock_ghz': round(a['gui'] / a['dur_us'] / 1e3, 2), 'mfma_busy_frac': round(util, 3)}
-    print('%-44s n %4d  mean %8.1f us  clk %.2f GHz  MFMA pipe busy %5.1f %%' % (name, a['n'], a['dur_us'] / a['n'], a['gui'] / a['dur_us'] / 1e3, 100 * util))
+    util2 = a['busy'] / 1024 / (a['dur_us'] * INKERNEL_CLOCK_GHZ * 1e3)
+    out[name] = {'dispatches': a['n'], 'mean_us': round(a['dur_us'] / a['n'], 1), 'gui_active_over_duration_ghz': round(a['gui'] / a['dur_us'] / 1e3, 2),
+                 'mfma_busy_frac': round(util, 3), 'mfma_busy_frac_at_inkernel_clock': round(util2, 3)}
+    print('%-44s n %4d  mean %8.1f us  GUI_ACTIVE/duration %.2f GHz  MFMA pipe busy %5.1f %% (of GUI_ACTIVE)  %5.1f %% (of duration x %.2f GHz)' % (
+        name, a['n'], a['dur_us'] / a['n'], a['gui'] / a['dur_us'] / 1e3, 100 * util, 100 * util2, INKERNEL_CLOCK_GHZ))
 if len(sys.argv) > 2:
     json.dump({'source': 'rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -- python3 tools/probe_engine.py fp32 512 (every launch on one stream)', 'kernels': out}, open(sys.argv[2], 'w'), indent=1)
