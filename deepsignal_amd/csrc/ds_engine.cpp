@@ -788,6 +788,15 @@ int build_plan(ds_handle* h, int n, Plan* plan)
             std::stable_sort(L.cell, L.cell + L.ncell, [](const LstmCell& a, const LstmCell& b) {
                 return (a.ax != nullptr) + (a.ah != nullptr) > (b.ax != nullptr) + (b.ah != nullptr);
             });
+            {   // tiles per work class, for lstm_logical_tile (workgroup tile = 64 sites x 64 nt columns, or 128 x 32 nt)
+                const int wg_nt = nt > 100 ? nt - 100 : nt;
+                const int per_cell = nt > 100 ? ((mtiles + 1) / 2) * (16 / wg_nt) : ((mtiles + 3) / 4) * (32 / wg_nt);
+                L.cls_tiles[0] = L.cls_tiles[1] = 0;
+                for (int i = 0; i < L.ncell; ++i) {
+                    const int k = (L.cell[i].ax != nullptr) + (L.cell[i].ah != nullptr);
+                    if (k == 2) L.cls_tiles[0] += per_cell; else if (k == 1) L.cls_tiles[1] += per_cell;
+                }
+            }
             Op op{};
             op.kind = OP_LSTM; op.stream = 1; op.stage = st;
             op.launch_index = (int)plan->lstm_launches.size();

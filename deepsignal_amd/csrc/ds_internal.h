@@ -109,6 +109,7 @@ struct LstmCell {
 struct LstmLaunch {
     LstmCell cell[LSTM_MAX_CELLS];
     int ncell, n, mtiles, T;
+    int cls_tiles[2];          // workgroup tiles of the K = 512 cells and of the K = 256 cells (cells are sorted by K)
     unsigned long long* dbg;   // diagnostic (DS_TUNE_DEBUG_STAMPS): [workgroup][8] time stamps of wave 0, null in normal runs
 };
 // nt = 32-column n-tiles per wave (1, 2 or 4): the same bits for every nt (same K order per output element)

@@ -761,15 +761,25 @@ __device__ __forceinline__ void lstm_gates(const floatx16& acc, const float4& cp
 
 // Workgroup -> logical tile of an LSTM launch. Cells of a diagonal differ in K (layer 0 multiplies h only, first steps
 // x only): a tile of a K = 256 cell is half the matrix work of a K = 512 one, and a launch is as slow as its busiest
-// CU. The host sorts the cells by descending K; this map then deals the logical tiles (cell-major, so heaviest first)
-// in ROUNDS of one tile per CU, using the dispatch pattern observed on MI355X (workgroup b -> XCD b % 8, CU slot
-// (b >> 3) % 32 of that XCD, i.e. blocks b, b + 256, b + 512 share a CU; tools/lstm_rawstamps.py): on a full diagonal
-// every CU gets two K = 512 tiles and one K = 256 tile instead of three of a kind. Inside a round an XCD owns 32
-// consecutive logical tiles (m-blocks of a few weight panels), so its L2 holds a contiguous slice of one cell.
+// CU. The host sorts the cells by descending K and passes the tile counts c0, c1 of the two heaviest classes; logical
+// tiles are cell-major (heaviest first), inside a cell n-group-major with the m-blocks of one weight panel adjacent.
+// The map uses the dispatch pattern observed on MI355X -- workgroup b runs on XCD b % 8, CU slot (b >> 3) % 32 of that
+// XCD, so blocks b, b + 256, b + 512 share a CU (tools/lstm_rawstamps.py):
+//   * every XCD takes a CONTIGUOUS eighth of each class (half a K = 512 cell and a quarter of a K = 256 cell on a full
+//     diagonal), so a cell's activation rows are fetched by two L2s, not by four, and a weight panel by one;
+//   * inside the XCD the heavier classes come first in dispatch order, so CU slot s gets the XCD's tiles s, s + 32,
+//     s + 64: two K = 512 tiles and one K = 256 tile instead of three of a kind.
 // Placement is a speed assumption only: any other dispatch order gives the same results, just less balance.
-__device__ __forceinline__ int lstm_logical_tile(int b, int total)
+__device__ __forceinline__ int lstm_logical_tile(int b, int total, int c0, int c1)
 {
-    const int full = total & ~255;                 // tiles in whole rounds
+    if (((c0 | c1 | total) & 7) == 0) {
+        const int x = b & 7, j = b >> 3, p0 = c0 >> 3, p1 = c1 >> 3;
+        if (j < p0) return x * p0 + j;
+        if (j < p0 + p1) return c0 + x * p1 + (j - p0);
+        return c0 + c1 + x * ((total - c0 - c1) >> 3) + (j - p0 - p1);
+    }
+    // class sizes not divisible by the XCD count (ragged batches): rounds of one tile per CU in sorted order
+    const int full = total & ~255;
     if (b < full) return (b & ~255) + (b & 7) * 32 + ((b & 255) >> 3);
     const int R = total - full, p = b - full, q = R >> 3, r = R & 7, xcd = p & 7;
     return full + xcd * q + (xcd < r ? xcd : r) + (p >> 3);
@@ -805,7 +815,7 @@ __global__ __launch_bounds__(256, NT == 1 ? 4 : 2) void lstm_cell_kernel(const L
     DS_LSTAMP(1, __builtin_amdgcn_s_memtime());
     DS_LSTAMP(6, (unsigned long long)__builtin_amdgcn_s_getreg(63492));     // HW_REG_HW_ID, all 32 bits
     DS_LSTAMP(7, (unsigned long long)__builtin_amdgcn_s_getreg(63508));     // HW_REG_XCC_ID
-    const int bid = lstm_logical_tile(blockIdx.x, gridDim.x);      // work-balanced, XCD-aware order
+    const int bid = lstm_logical_tile(blockIdx.x, gridDim.x, Lp->cls_tiles[0], Lp->cls_tiles[1]);   // work-balanced, XCD-aware order
     const int mtiles = Lp->mtiles;
     const int mblocks = (mtiles + 3) >> 2;
     constexpr int NGROUPS = 32 / NT;
@@ -938,7 +948,7 @@ __global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void lstm_cell_lds_kernel(con
     DS_LSTAMP(1, __builtin_amdgcn_s_memtime());
     DS_LSTAMP(6, (unsigned long long)__builtin_amdgcn_s_getreg(63492));     // HW_REG_HW_ID, all 32 bits
     DS_LSTAMP(7, (unsigned long long)__builtin_amdgcn_s_getreg(63508));     // HW_REG_XCC_ID
-    const int bid = lstm_logical_tile(blockIdx.x, gridDim.x);      // work-balanced, XCD-aware order
+    const int bid = lstm_logical_tile(blockIdx.x, gridDim.x, Lp->cls_tiles[0], Lp->cls_tiles[1]);   // work-balanced, XCD-aware order
     const int mtiles = Lp->mtiles;
     const int mblocks = (mtiles + 1) >> 1;
     constexpr int NGROUPS = 16 / NT;
