@@ -311,9 +311,10 @@ def main():
         if dist is not None:
             # the path's only exchange: gather f32[n,2] + i32[n] (12 B/site) to the writer rank over RCCL
             from deepsignal_amd import sharding
-            gidx = torch.arange(rank, world * K * BATCH, world, dtype=torch.int64, device=dev)   # this rank's global site ids
-            g_act, g_pred = sharding.gather_results(out_act.reshape(-1, 2), out_pred.reshape(-1), gidx, dist, dst=0,
-                                                    device=dev, as_numpy=False)
+            # rank r owns the sites r, r + world, ...: the writer derives the indices, only the 12 B/site travel
+            g_act, g_pred = sharding.gather_results(
+                out_act.reshape(-1, 2), out_pred.reshape(-1), None, dist, dst=0, device=dev, as_numpy=False,
+                index_of_rank=lambda r, cnt: torch.arange(r, r + world * cnt, world, dtype=torch.int64, device=dev))
             if rank == 0:
                 assert g_act.shape[0] == world * K * BATCH
         fence()

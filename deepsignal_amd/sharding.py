@@ -27,57 +27,64 @@ def shard_indices(read_ids: Sequence[str], world: int, rank: int) -> np.ndarray:
     return np.nonzero(assign_reads(read_ids, world) == rank)[0]
 
 
-def gather_results(act, pred, index, dist=None, dst: int = 0, device=None, as_numpy: bool = True):
-    """Gather (act float32[n_i,C], pred int32[n_i], index int64[n_i]) from all ranks to `dst`.
+def gather_results(act, pred, index, dist=None, dst: int = 0, device=None, as_numpy: bool = True, index_of_rank=None):
+    """Gather (act float32[n_i,C], pred int32[n_i]) from all ranks to `dst`, re-ordered so that row j is the site with
+    global index j; returns (act, pred) on dst and (None, None) elsewhere.
 
-    Ragged: every rank pads to the max shard length; returns on dst (act, pred) re-ordered so that
-    row j is the site with global index j, and (None, None) elsewhere. `dist` = torch.distributed
-    (already initialised) or None for single-process. as_numpy=False keeps the re-ordered results as tensors on
-    `device` (no device-to-host copy inside the call: what bench.py times is the RCCL exchange itself)."""
+    On the wire: act as float32 and pred as int32 -- **12 B/site at C = 2**  -- in two ragged gathers
+    (every rank pads to the longest shard). The global indices travel as a third int64 gather only when the writer
+    cannot derive them: with `index_of_rank(rank, count) -> int64 tensor` (the sharding rule, e.g. "rank r owns reads
+    r, r + world, ...") nothing but the 12 B/site moves. `dist` = torch.distributed (already initialised) or None for
+    single-process. as_numpy=False keeps the re-ordered results as tensors on `device` (no device-to-host copy inside the
+    call: what bench.py times is the RCCL exchange itself)."""
     import torch
     act_t = torch.as_tensor(act, dtype=torch.float32)
     pred_t = torch.as_tensor(pred, dtype=torch.int32)
-    idx_t = torch.as_tensor(index, dtype=torch.int64)
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        idx_t = torch.as_tensor(index, dtype=torch.int64) if index is not None else index_of_rank(0, act_t.shape[0])
         order = torch.argsort(idx_t.cpu())
         return act_t.cpu()[order].numpy(), pred_t.cpu()[order].numpy()
     world, rank = dist.get_world_size(), dist.get_rank()
     dev = device if device is not None else act_t.device
     C = act_t.shape[1]
-    n_local = torch.tensor([act_t.shape[0]], dtype=torch.int64, device=dev)
+    n = act_t.shape[0]
+    n_local = torch.tensor([n], dtype=torch.int64, device=dev)
     counts = [torch.zeros_like(n_local) for _ in range(world)]
     dist.all_gather(counts, n_local)
     counts = [int(c.item()) for c in counts]
     nmax = max(max(counts), 1)
-    # one packed float64 buffer per rank: [nmax, C + 2] = act | pred | index (exact for int < 2^53)
-    packed = torch.zeros((nmax, C + 2), dtype=torch.float64, device=dev)
-    n = act_t.shape[0]
-    if n:
-        packed[:n, :C] = act_t.to(dev, torch.float64)
-        packed[:n, C] = pred_t.to(dev, torch.float64)
-        packed[:n, C + 1] = idx_t.to(dev, torch.float64)
-    gl = [torch.empty_like(packed) for _ in range(world)] if rank == dst else None
-    dist.gather(packed, gl, dst=dst)
+
+    def padded(t, dtype, width=None):
+        shape = (nmax,) if width is None else (nmax, width)
+        buf = torch.zeros(shape, dtype=dtype, device=dev)
+        if n:
+            buf[:n] = t.to(dev, dtype)
+        return buf
+
+    def gather(buf):
+        gl = [torch.empty_like(buf) for _ in range(world)] if rank == dst else None
+        dist.gather(buf, gl, dst=dst)
+        return gl
+
+    g_act = gather(padded(act_t, torch.float32, C))
+    g_pred = gather(padded(pred_t, torch.int32))
+    g_idx = None
+    if index_of_rank is None:
+        g_idx = gather(padded(torch.as_tensor(index, dtype=torch.int64), torch.int64))
     if rank != dst:
         return None, None
     total = sum(counts)
-    if not as_numpy:
-        t_act = torch.empty((total, C), dtype=torch.float32, device=dev)
-        t_pred = torch.empty((total,), dtype=torch.int32, device=dev)
-        for r in range(world):
-            blk = gl[r][:counts[r]]
-            gi = blk[:, C + 1].to(torch.int64)
-            t_act[gi] = blk[:, :C].to(torch.float32)
-            t_pred[gi] = blk[:, C].to(torch.int32)
-        return t_act, t_pred
-    out_act = np.empty((total, C), np.float32)
-    out_pred = np.empty((total,), np.int32)
+    t_act = torch.empty((total, C), dtype=torch.float32, device=dev)
+    t_pred = torch.empty((total,), dtype=torch.int32, device=dev)
     for r in range(world):
-        blk = gl[r][:counts[r]].cpu().numpy()
-        gi = blk[:, C + 1].astype(np.int64)
-        out_act[gi] = blk[:, :C].astype(np.float32)
-        out_pred[gi] = blk[:, C].astype(np.int32)
-    return out_act, out_pred
+        if not counts[r]:
+            continue
+        gi = g_idx[r][:counts[r]] if g_idx is not None else torch.as_tensor(index_of_rank(r, counts[r]), dtype=torch.int64).to(dev)
+        t_act[gi] = g_act[r][:counts[r]]
+        t_pred[gi] = g_pred[r][:counts[r]]
+    if not as_numpy:
+        return t_act, t_pred
+    return t_act.cpu().numpy(), t_pred.cpu().numpy()
 
 
 class OrderedRowGather:

@@ -36,8 +36,13 @@ def _worker(rank, world, port, tmp):
     act, pred = oracle.forward(w, sub, "f32", nthreads=2) if len(mine) else (np.zeros((0, 2), np.float32), np.zeros((0,), np.int32))
     g_act, g_pred = sharding.gather_results(act, pred, mine, dist)
     t_act, t_pred = sharding.gather_results(act, pred, mine, dist, as_numpy=False)      # tensor form used by bench.py
+    # 12 B/site form: the writer derives the indices from the sharding rule instead of receiving them
+    import torch
+    rule = lambda r, cnt: torch.from_numpy(sharding.shard_indices(reads, world, r)[:cnt])
+    r_act, r_pred = sharding.gather_results(act, pred, None, dist, index_of_rank=rule)
     if rank == 0:
         assert np.array_equal(t_act.numpy(), g_act) and np.array_equal(t_pred.numpy(), g_pred)
+        assert np.array_equal(r_act, g_act) and np.array_equal(r_pred, g_pred)
         np.savez(os.path.join(tmp, "gathered.npz"), act=g_act, pred=g_pred)
     else:
         assert g_act is None

@@ -60,9 +60,11 @@ def run_shard(sites, batch=512, precision="fp32", weights=None, pool_sites=4096,
     eng.sync()
     t_compute = time.perf_counter() - t0
     # global site index of my j-th site: read my_reads[j // 20], position j % 20
-    gidx = (torch.from_numpy(my_reads).to(dev).repeat_interleave(SITES_PER_READ) * SITES_PER_READ
-            + torch.arange(SITES_PER_READ, device=dev).repeat(my_reads.size))
-    g_act, g_pred = sharding.gather_results(out_act[:n_mine], out_pred[:n_mine], gidx, dist, dst=0, device=dev, as_numpy=False)
+    def index_of_rank(r, cnt):       # the sharding rule: rank r owns reads r, r + world, ...; 20 sites per read
+        reads = torch.arange(r, r + world * (cnt // SITES_PER_READ), world, dtype=torch.int64, device=dev)
+        return (reads.repeat_interleave(SITES_PER_READ) * SITES_PER_READ + torch.arange(SITES_PER_READ, device=dev).repeat(reads.numel()))
+    g_act, g_pred = sharding.gather_results(out_act[:n_mine], out_pred[:n_mine], None, dist, dst=0, device=dev, as_numpy=False,
+                                            index_of_rank=index_of_rank)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
