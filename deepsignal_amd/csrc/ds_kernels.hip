@@ -926,6 +926,18 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst)
                  : "memory");
 }
 
+// The same with the source as (wave-uniform 64-bit base in SGPRs) + (per-lane 32-bit byte offset): no vector address
+// arithmetic when the base moves.
+__device__ __forceinline__ void glds16s(const void* gbase, unsigned lane_off, unsigned lds_dst)
+{
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(lane_off), "s"(gbase), "s"(lds_dst)
+                 : "memory");
+}
+template <int I> struct LdsSlot { static constexpr int value = I; };
+
 template <int NT>
 __global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void lstm_cell_lds_kernel(const LstmLaunch L_)
 {
@@ -970,7 +982,10 @@ __global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void lstm_cell_lds_kernel(con
     const int nstages = KG / KGS;
     const char* const a0 = reinterpret_cast<const char*>(has_x ? C.ax : C.ah);
     const long dseg = (has_x && has_h) ? (reinterpret_cast<const char*>(C.ah) - reinterpret_cast<const char*>(C.ax)) - 32 * 1024 : 0;
-    // request j of this wave: linear fragment index q = wave + 4 j of the stage -> (k-group kgi, fragment f)
+    // request j of this wave: linear fragment index q = wave + 4 j of the stage -> (k-group kgi, fragment f). The
+    // source of a request is WAVE-UNIFORM up to the lane's 16 bytes, so it is kept as a scalar base (advanced with
+    // scalar adds) plus one loop-invariant VGPR offset: on gfx950 a VALU instruction does not run in the shadow of an
+    // fp32 MFMA (tools/mfma_valu.hip) -- per-lane 64-bit pointer arithmetic in the K loop is matrix-pipe time lost.
     const char* src[LPS];
     int kgi_[LPS];
     bool is_a[LPS];
@@ -981,24 +996,24 @@ __global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void lstm_cell_lds_kernel(con
         is_a[j] = f < 2;
         if (f < 2) {
             const int m = min(mb * 2 + f, mtiles - 1);
-            src[j] = a0 + (size_t)m * LSTM_MT_FLOATS * 4 + (size_t)kgi * 1024 + lane16;
+            src[j] = a0 + (size_t)m * LSTM_MT_FLOATS * 4 + (size_t)kgi * 1024;
         } else {
             const int ntile = ng * 2 * NT + (f - 2);
-            src[j] = reinterpret_cast<const char*>(C.Bp) + ((size_t)ntile * C.kg_stride + kgi) * 1024 + lane16;
+            src[j] = reinterpret_cast<const char*>(C.Bp) + ((size_t)ntile * C.kg_stride + kgi) * 1024;
         }
     }
     const unsigned ring_lds = (unsigned)(size_t)(__attribute__((address_space(3))) float*)ring;    // LDS byte address
-    auto request = [&](int st) {                               // stage st -> ring slot st % 3
-        const unsigned dst = __builtin_amdgcn_readfirstlane(ring_lds + ((st % 3) * STAGE + wave * 256) * 4);
+    auto request = [&](int st, int slot) __attribute__((always_inline)) {      // stage st -> ring slot st % 3
+        const unsigned dst = __builtin_amdgcn_readfirstlane(ring_lds + (slot * STAGE + wave * 256) * 4);
 #pragma unroll
         for (int j = 0; j < LPS; ++j) {
             const int kg = st * KGS + kgi_[j];
             const long off = (long)st * (KGS * 1024) + ((is_a[j] && kg >= 32) ? dseg : 0);
-            glds16(src[j] + off, dst + j * 4096);              // fragment q = wave + 4 j of the stage, 1 KiB each
+            glds16s(src[j] + off, lane16, dst + j * 4096);     // fragment q = wave + 4 j of the stage, 1 KiB each
         }
     };
-    if (nstages > 0) request(0);
-    if (nstages > 1) request(1);
+    if (nstages > 0) request(0, 0);
+    if (nstages > 1) request(1, 1);
 
     // ---- accumulator's initial value: bias (+1 on f), layer 0: table row + (mean, std, len) terms
     floatx16 acc[NT];
@@ -1021,27 +1036,35 @@ __global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void lstm_cell_lds_kernel(con
         asm volatile("" : "+v"(acc[nt]));          // bias loads land directly in the accumulator registers
     }
     DS_LSTAMP(2, __builtin_amdgcn_s_memtime());
-    for (int st = 0; st < nstages; ++st) {
-        // stage st has landed in LDS once every wave's requests for it are done: counted wait (stage st + 1 stays in
-        // flight), then the barrier; it also tells everybody that ring slot (st + 2) % 3 -- read during stage st - 1 --
-        // is free again
+    // stage st has landed in LDS once every wave's requests for it are done: counted wait (stage st + 1 stays in
+    // flight), then the barrier; it also tells everybody that ring slot (st + 2) % 3 -- read during stage st - 1 -- is
+    // free again. The ring index is a compile-time constant of each of the three unrolled bodies, so every LDS address
+    // is a loop-invariant VGPR plus an immediate.
+    const float* const fa0 = ring + mi * 256 + lane4;
+    const float* const fb0 = ring + (2 + nj * NT) * 256 + lane4;
+    auto stage = [&](int st, auto slot_c) __attribute__((always_inline)) {
+        constexpr int SLOT = decltype(slot_c)::value;
         if (st + 1 < nstages) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        if (st + 2 < nstages) request(st + 2);
-        const float* sb = ring + (st % 3) * STAGE + lane4;
+        if (st + 2 < nstages) request(st + 2, (SLOT + 2) % 3);
 #pragma unroll
         for (int kgi = 0; kgi < KGS; ++kgi) {
-            const float4 a = *reinterpret_cast<const float4*>(sb + (kgi * FR + mi) * 256);
+            const float4 a = *reinterpret_cast<const float4*>(fa0 + SLOT * STAGE + kgi * FR * 256);
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
-                const float4 b = *reinterpret_cast<const float4*>(sb + (kgi * FR + 2 + nj * NT + nt) * 256);
+                const float4 b = *reinterpret_cast<const float4*>(fb0 + SLOT * STAGE + (kgi * FR + nt) * 256);
                 acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(b.x, a.x, acc[nt], 0, 0, 0);
                 acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(b.y, a.y, acc[nt], 0, 0, 0);
                 acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(b.z, a.z, acc[nt], 0, 0, 0);
                 acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(b.w, a.w, acc[nt], 0, 0, 0);
             }
         }
+    };
+    for (int st = 0; st < nstages;) {
+        stage(st, LdsSlot<0>{}); if (++st >= nstages) break;
+        stage(st, LdsSlot<1>{}); if (++st >= nstages) break;
+        stage(st, LdsSlot<2>{}); ++st;
     }
 
     DS_LSTAMP(3, __builtin_amdgcn_s_memtime());
