@@ -43,7 +43,7 @@ struct PackedGemm {      // device-resident packed weights of one GEMM
     int K = 0, N = 0;
 };
 
-enum OpKind { OP_GEMM, OP_STEM1, OP_MAXPOOL, OP_AVGPOOL, OP_HEAD, OP_FUSED, OP_PACKEV, OP_LSTM };
+enum OpKind { OP_GEMM, OP_STEM1, OP_MAXPOOL, OP_AVGPOOL, OP_HEAD, OP_FUSED, OP_PACKEV, OP_LSTM, OP_STEM23 };
 
 struct Op {
     OpKind kind;
@@ -57,6 +57,7 @@ struct Op {
     float* out = nullptr;
     int a = 0, b = 0, c = 0, d = 0;
     FusedArgs fa{};                       // OP_FUSED
+    Stem23Args sa{};                      // OP_STEM23
     int tm = 0;
     double flops = 0;                     // algorithmic FLOPs of this launch
     hipEvent_t ev0 = nullptr, ev1 = nullptr;   // profiling mode only
@@ -67,7 +68,7 @@ struct Op {
 
 // per-kernel accumulators (one entry per __global__ function / template instantiation)
 enum KernelClass { K_GEMM_CONV = 0, K_GEMM_FC, K_GEMM_LSTM, K_GEMM_CONV_WIDE, K_GEMM_CONV_POOL, K_GEMM_FC_DENSE, K_GEMM_LSTM_DENSE, K_FUSED1, K_FUSED2, K_FUSED3, K_STEM1, K_MAXPOOL, K_AVGPOOL, K_HEAD,
-                   K_GEMM_BCONV, K_GEMM_BCONV_POOL, K_GEMM_BFC, K_GEMM_BFC_DENSE, K_PACKEV, K_GEMM_BLSTM, K_GEMM_BLSTM_DENSE, K_FUSEDB1, K_FUSEDB2, K_FUSEDB3, K_GEMM_LSTM_T, K_GEMM_LSTM_T_DENSE, K_GEMM_BLSTM_T, K_GEMM_BLSTM_T_DENSE, K_LSTM_CELL1, K_LSTM_CELL2, K_LSTM_CELL4, K_LSTM_LDS1, K_LSTM_LDS2, K_COUNT };
+                   K_GEMM_BCONV, K_GEMM_BCONV_POOL, K_GEMM_BFC, K_GEMM_BFC_DENSE, K_PACKEV, K_GEMM_BLSTM, K_GEMM_BLSTM_DENSE, K_FUSEDB1, K_FUSEDB2, K_FUSEDB3, K_GEMM_LSTM_T, K_GEMM_LSTM_T_DENSE, K_GEMM_BLSTM_T, K_GEMM_BLSTM_T_DENSE, K_LSTM_CELL1, K_LSTM_CELL2, K_LSTM_CELL4, K_LSTM_LDS1, K_LSTM_LDS2, K_STEM23, K_COUNT };
 const char* const kKernelNames[K_COUNT] = {"gemm_kernel<1,2,4,1,0,0,1,1>", "gemm_kernel<1,3,4,1,0,0,2,1>", "gemm_kernel<1,4,4,1,1,0,1,1>",
                                            "gemm_kernel<2,2,2,2,0,0,1,1>", "gemm_kernel<1,2,4,1,0,1,1,1>", "gemm_kernel<1,3,4,1,0,2,2,1>",
                                            "gemm_kernel<1,4,4,1,1,2,1,1>", "inception_fused_kernel<1>",
@@ -81,7 +82,7 @@ const char* const kKernelNames[K_COUNT] = {"gemm_kernel<1,2,4,1,0,0,1,1>", "gemm
                                            "gemm_kernel<1,1,4,1,2,0,1,1>", "gemm_kernel<1,1,4,1,2,2,1,1>",
                                            "gemm_kernel<1,1,4,1,2,0,3,1,bf16>", "gemm_kernel<1,1,4,1,2,2,3,1,bf16>",
                                            "lstm_cell_kernel<1>", "lstm_cell_kernel<2>", "lstm_cell_kernel<4>",
-                                           "lstm_cell_lds_kernel<1>", "lstm_cell_lds_kernel<2>"};
+                                           "lstm_cell_lds_kernel<1>", "lstm_cell_lds_kernel<2>", "stem23_kernel"};
 struct KernelStat {
     int64_t launches = 0;
     double total_ms = 0;
@@ -605,6 +606,21 @@ int build_plan(ds_handle* h, int n, Plan* plan)
         add_ew_op(cnn, op);
         if (first_plan) h->stages[st].flops_per_site += 2.0 * h->w1 * 7 * 64;
         const int M = n * h->wa;
+        if (!bf && !h->no_fused && h->wa <= 96) {
+            // conv_layer2 + conv_layer3 in one kernel (stem23_kernel): tiles of whole sites, conv2's rows never leave LDS
+            Op o2{};
+            o2.kind = OP_STEM23; o2.stream = 0; o2.stage = st;
+            o2.sa.X = h->cur->stem_pool; o2.sa.Y = h->cur->conv3o; o2.sa.C2 = h->debug ? h->cur->conv2o : nullptr;
+            o2.sa.Bp2 = h->conv2.Bp; o2.sa.bias2 = h->conv2.bias; o2.sa.Bp3 = h->conv3.Bp; o2.sa.bias3 = h->conv3.bias;
+            o2.sa.n_sites = n; o2.sa.W = h->wa;
+            // sites per tile: as full as 96 rows allow, as long as every CU still gets a tile
+            int spt = std::max(1, 96 / h->wa);
+            while (spt > 1 && (n + spt - 1) / spt < 256) --spt;
+            o2.sa.spt = spt;
+            o2.flops = 2.0 * M * (64.0 * 128 + 384.0 * 256);
+            add_ew_op(cnn, o2);
+            if (first_plan) h->stages[st].flops_per_site += 2.0 * h->wa * (64.0 * 128 + 384.0 * 256);
+        } else {
         GemmLaunch L{};
         const GemmCfg ccfg = bf ? CFG_BCONV : CFG_CONV;
         GemmProblem P = base_problem(M, 128, h->wa, h->conv2);                 // conv_layer2 1x1 (layers.py:192-197)
@@ -618,6 +634,7 @@ int build_plan(ds_handle* h, int n, Plan* plan)
         add_out(P3, h->cur->conv3o, 256, 0, 256, 1, nullptr, 0, bf);
         add_tiles(L3, P3, ccfg, h->zero_seg);
         add_gemm_op(cnn, 0, st, ccfg, L3);
+        }
     }
     const float* x = h->cur->conv3o;
     int cin = 256;
@@ -910,6 +927,9 @@ int issue_op(ds_handle* h, Plan& plan, const Op& op, hipStream_t s)
     case OP_LSTM:
         HIPCHK(h, launch_lstm_cells(op.c, plan.lstm_launches[op.launch_index], s));
         break;
+    case OP_STEM23:
+        HIPCHK(h, launch_stem23(op.sa, s));
+        break;
     case OP_FUSED:
         if (h->bf16) HIPCHK(h, launch_inception_fused_bf16(op.tm, op.fa, s));
         else HIPCHK(h, launch_inception_fused(op.tm, op.fa, s));
@@ -1000,6 +1020,7 @@ int kernel_class(const Op& op)
         if (op.fa.cin == 128) return op.tm == 1 ? K_FUSEDB1 : op.tm == 2 ? K_FUSEDB2 : K_FUSEDB3;   // bf16 rows: pitch in units
         return op.tm == 1 ? K_FUSED1 : op.tm == 2 ? K_FUSED2 : K_FUSED3;
     case OP_STEM1: return K_STEM1;
+    case OP_STEM23: return K_STEM23;
     case OP_MAXPOOL: return K_MAXPOOL;
     case OP_AVGPOOL: return K_AVGPOOL;
     case OP_HEAD: return K_HEAD;

@@ -143,6 +143,17 @@ hipError_t configure_fused_kernels();
 hipError_t launch_inception_fused_bf16(int tm, const FusedArgs& a, hipStream_t s);
 size_t inception_fused_bf16_lds_bytes(int tm, int W, int spt);
 
+// conv_layer2 (1x1, 64 -> 128) + conv_layer3 (1x3, 128 -> 256), both with folded BN + ReLU        layers.py:192-203
+struct Stem23Args {
+    const float* X;        // [n_sites * W][64]  stem_pool rows (NWC)
+    float* Y;              // [n_sites * W][256] conv_layer3 output
+    float* C2;             // optional [n_sites * W][128] copy of conv_layer2's output (debug taps), or nullptr
+    const float *Bp2, *bias2;   // packed [64 x 128] (pack_b) and its bias
+    const float *Bp3, *bias3;   // packed [384 x 256], K = tap-major (tap * 128 + channel)
+    int n_sites, W, spt;   // spt = whole sites per workgroup tile, spt * W <= 96
+};
+hipError_t launch_stem23(const Stem23Args& a, hipStream_t s);
+size_t stem23_lds_bytes(int W, int spt);
 // stem conv1 (K=7, stride 2, Cin=1) + folded BN + ReLU + maxpool(3, stride 2)   layers.py:183-191
 hipError_t launch_stem1(const float* signals, const float* w7x64, const float* bias64, float* out,
                         int n, int signal_len, int w1, int pad_l_conv, int wa, int pad_l_pool, int out_bf16, hipStream_t s);

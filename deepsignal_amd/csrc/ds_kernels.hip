@@ -1842,6 +1842,163 @@ __global__ __launch_bounds__(512, DS_FUSEDB_WPS) void inception_fused_bf16_kerne
 #undef DS_STAMP
 }
 
+// ---------------------------------------------------------------------------------------------
+// conv_layer2 (1x1, 64 -> 128) + conv_layer3 (1x3, 128 -> 256), BN folded, ReLU            layers.py:192-203
+// One workgroup (8 waves) owns a tile of whole sites (<= 96 rows), two workgroups per CU (<= 128 VGPRs, ~76 KB of LDS),
+// so one workgroup's staging / epilogue runs under the other's MFMAs.
+//   stage  the 64-channel input rows (stem_pool) -> Xs
+//   conv2  12 units of (32 rows x 32 channels, K = 64), three per SIMD -> T (ReLU) with one zero halo row on either
+//          side of every site = conv3's SAME padding
+//   conv3  wave w = output channels [32 w, 32 w + 32) of all three m-tiles. The WHOLE activation tile is in LDS, so the
+//          48 k-groups (3 taps x 16) run without a barrier: weights global -> VGPR through a ring of four register
+//          stages, activation fragments from T one k-group ahead. Every LDS / global offset is an immediate on a
+//          loop-invariant base (fully unrolled): no vector ALU work between the MFMAs (tools/mfma_valu.hip).
+// MFMAs are issued transposed (weights, activations) as in the fused module: a lane holds 4 x 4 consecutive channels of
+// one row, bias = accumulator init, float4 stores.
+// Roofline: MFMA. Algorithmic FLOPs per site = 2 * W * (64 * 128 + 3 * 128 * 256); HBM bytes per row 256 in, 1024 out.
+constexpr int S23_LDX = 68;     // Xs row stride (floats): 17 x 16 B, odd -> conflict-free b128 fragment reads
+constexpr int S23_LDT = 132;    // T row stride: 33 x 16 B
+size_t stem23_lds_bytes(int W, int spt)
+{
+    return (size_t)(96 * S23_LDX + (spt * (W + 2) + 3) * S23_LDT + 96) * sizeof(float);
+}
+
+__global__ __launch_bounds__(512, 2) void stem23_kernel(const Stem23Args a)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* const Xs = smem;                                   // [96][S23_LDX]
+    float* const T = smem + 96 * S23_LDX;                     // [spt * (W + 2) + 3][S23_LDT]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int W = a.W, spt = a.spt;
+    const int trows = spt * (W + 2) + 3;                      // last three rows: halo | dump row (padding rows of the tile) | halo
+    int* const rowmap = reinterpret_cast<int*>(T + trows * S23_LDT);     // [96] tile row -> T row
+    const int site0 = blockIdx.x * spt;
+    const int nhere = min(spt, a.n_sites - site0);
+    const int TRv = nhere * W;
+    const size_t grow0 = (size_t)site0 * W;
+    const int h4 = 4 * (lane >> 5), rlane = lane & 31;
+
+    // ---- stage: zero T (halo rows must be zero; the rest is overwritten), row map, input rows
+    for (int i = tid; i < trows * (S23_LDT / 4); i += 512) reinterpret_cast<float4*>(T)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (tid < 96) rowmap[tid] = tid < TRv ? (tid / W) * (W + 2) + 1 + tid % W : spt * (W + 2) + 1;
+    {
+        float4 v[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {                          // 96 rows x 16 float4
+            const int idx = tid + 512 * i, row = idx >> 4, q = idx & 15;
+            const int rr = row < TRv ? row : TRv - 1;
+            v[i] = gload4(a.X + (grow0 + rr) * 64 + q * 4);
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int idx = tid + 512 * i, row = idx >> 4, q = idx & 15;
+            *reinterpret_cast<float4*>(Xs + row * S23_LDX + q * 4) = v[i];
+        }
+    }
+    // conv3 weights of the first ring stages and both bias vectors are requested before the barrier
+    const char* const b3 = reinterpret_cast<const char*>(a.Bp3) + (size_t)wave * 48 * 1024;
+    const unsigned lane16 = (unsigned)lane * 16;
+    float4 bq[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) bq[i] = gload4(reinterpret_cast<const float*>(b3 + i * 1024 + lane16));
+    float4 bias3[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) bias3[g] = gload4(a.bias3 + wave * 32 + 8 * g + h4);
+    __syncthreads();
+
+    // ---- conv2: unit u = (m, n); waves 0..3 take (0, w) and (2, w), waves 4..7 take (1, w - 4): three units per SIMD
+    {
+        const int n2 = wave & 3;
+        float4 w2[8];
+#pragma unroll
+        for (int g = 0; g < 8; ++g) w2[g] = gload4(a.Bp2 + ((size_t)(n2 * 8 + g) * 64 + lane) * 4);
+        float4 bias2[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) bias2[g] = gload4(a.bias2 + n2 * 32 + 8 * g + h4);
+        const int nunits = wave < 4 ? 2 : 1;
+        for (int ui = 0; ui < nunits; ++ui) {
+            const int m = wave < 4 ? 2 * ui : 1;
+            floatx16 u;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) { u[4 * g] = bias2[g].x; u[4 * g + 1] = bias2[g].y; u[4 * g + 2] = bias2[g].z; u[4 * g + 3] = bias2[g].w; }
+            const float* xr = Xs + (m * 32 + rlane) * S23_LDX + h4;
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+                const float4 x = *reinterpret_cast<const float4*>(xr + g * 8);
+                u = __builtin_amdgcn_mfma_f32_32x32x2f32(w2[g].x, x.x, u, 0, 0, 0);
+                u = __builtin_amdgcn_mfma_f32_32x32x2f32(w2[g].y, x.y, u, 0, 0, 0);
+                u = __builtin_amdgcn_mfma_f32_32x32x2f32(w2[g].z, x.z, u, 0, 0, 0);
+                u = __builtin_amdgcn_mfma_f32_32x32x2f32(w2[g].w, x.w, u, 0, 0, 0);
+            }
+            const int row = m * 32 + rlane;
+            float* const td = T + rowmap[row] * S23_LDT + n2 * 32 + h4;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 o = make_float4(fmaxf(u[4 * g], 0.0f), fmaxf(u[4 * g + 1], 0.0f), fmaxf(u[4 * g + 2], 0.0f), fmaxf(u[4 * g + 3], 0.0f));
+                *reinterpret_cast<float4*>(td + 8 * g) = o;
+                if (a.C2 && row < TRv) {                       // diagnostic tap (debug mode): conv_layer2's output rows
+                    const v4f ov = {o.x, o.y, o.z, o.w};
+                    *(__attribute__((address_space(1))) v4f*)(a.C2 + (grow0 + row) * 128 + n2 * 32 + 8 * g + h4) = ov;
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- conv3
+    floatx16 acc[3];
+#pragma unroll
+    for (int m = 0; m < 3; ++m)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) { acc[m][4 * g] = bias3[g].x; acc[m][4 * g + 1] = bias3[g].y; acc[m][4 * g + 2] = bias3[g].z; acc[m][4 * g + 3] = bias3[g].w; }
+    const float* tb[3];
+#pragma unroll
+    for (int m = 0; m < 3; ++m) tb[m] = T + (rowmap[m * 32 + rlane] - 1) * S23_LDT + h4;     // tap t reads row + t - 1
+    float4 af[2][3];
+#pragma unroll
+    for (int m = 0; m < 3; ++m) af[0][m] = *reinterpret_cast<const float4*>(tb[m]);
+#pragma unroll
+    for (int kgl = 0; kgl < 48; ++kgl) {
+        const int cur = kgl & 1, slot = kgl & 3;
+        if (kgl + 1 < 48) {
+            const int t1 = (kgl + 1) >> 4, g1 = (kgl + 1) & 15;
+#pragma unroll
+            for (int m = 0; m < 3; ++m) af[cur ^ 1][m] = *reinterpret_cast<const float4*>(tb[m] + t1 * S23_LDT + g1 * 8);
+        }
+#pragma unroll
+        for (int m = 0; m < 3; ++m) {
+            acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(bq[slot].x, af[cur][m].x, acc[m], 0, 0, 0);
+            acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(bq[slot].y, af[cur][m].y, acc[m], 0, 0, 0);
+            acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(bq[slot].z, af[cur][m].z, acc[m], 0, 0, 0);
+            acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(bq[slot].w, af[cur][m].w, acc[m], 0, 0, 0);
+        }
+        if (kgl + 4 < 48) bq[slot] = gload4(reinterpret_cast<const float*>(b3 + (kgl + 4) * 1024 + lane16));
+        __builtin_amdgcn_sched_barrier(0);       // pins the ring: requests stay four k-groups ahead of their MFMAs
+    }
+
+    // ---- ReLU, rows out (each lane: 4 x 16 B of one row)
+#pragma unroll
+    for (int m = 0; m < 3; ++m) {
+        const int row = m * 32 + rlane;
+        if (row < TRv) {
+            float* const yd = a.Y + (grow0 + row) * 256 + wave * 32 + h4;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const v4f o = {fmaxf(acc[m][4 * g], 0.0f), fmaxf(acc[m][4 * g + 1], 0.0f), fmaxf(acc[m][4 * g + 2], 0.0f), fmaxf(acc[m][4 * g + 3], 0.0f)};
+                *(__attribute__((address_space(1))) v4f*)(yd + 8 * g) = o;
+            }
+        }
+    }
+}
+
+hipError_t launch_stem23(const Stem23Args& a, hipStream_t s)
+{
+    if (a.n_sites <= 0) return hipSuccess;
+    const int grid = (a.n_sites + a.spt - 1) / a.spt;
+    hipLaunchKernelGGL(stem23_kernel, dim3(grid), dim3(512), stem23_lds_bytes(a.W, a.spt), s, a);
+    return hipGetLastError();
+}
+
 // The fused kernels need more than the default 64 KB of dynamic LDS: opt in once per device (ds_create calls this
 // after hipSetDevice; function attributes are per device and must not be changed during stream capture).
 hipError_t configure_fused_kernels()
@@ -1853,7 +2010,7 @@ hipError_t configure_fused_kernels()
         const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
     }
-    return hipSuccess;
+    return hipFuncSetAttribute((const void*)stem23_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
 }
 
 hipError_t launch_inception_fused_bf16(int tm, const FusedArgs& a, hipStream_t s)
