@@ -237,6 +237,7 @@ def main():
                     help="skip pass C (every launch on one stream); used for the rocprofv3 cross-check, whose per-kernel "
                          "averages would otherwise blend co-resident and stand-alone launches")
     ap.add_argument("--no-host-path", action="store_true", help="skip the pcie_inclusive and e2e_tsv legs")
+    ap.add_argument("--no-three-step", action="store_true", help="skip the joint_three_step leg (unfolded joint model)")
     ap.add_argument("--lstm-tiling", default="auto", help="diagnostic: force a BiLSTM cell-kernel variant (Engine(lstm_tiling=...))")
     ap.add_argument("--slots", type=int, default=0, help="diagnostic: forwards in flight (0 = engine default, 8)")
     ap.add_argument("--dry-run", action="store_true",
@@ -335,6 +336,8 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": WORKLOAD, "batch": BATCH, "kmer_len": 17, "signal_len": 360,
+                   "joint_model": "folded: avgpool x dense(6032,6032) x dense(6032,2) -> one 6032 x 2 matrix (float64 at "
+                                  "weight load); the three-step form is timed in joint_three_step",
                    "sharding": "by read, %d rank(s), full weight replica per GPU" % world},
         "windows": {"n": len(windows), "steps_each": K, "statistic": "median",
                     "sites_per_s": [round(world * K * BATCH / x, 1) for x in windows] if K else [],
@@ -362,6 +365,7 @@ def main():
             step(i, i)
         eng.sync()
         stages = {s["name"]: round(1e3 * s["total_ms"] / max(s["calls"], 1), 1) for s in eng.stage_times()}
+        exec_flops_per_site = float(sum(s["flops_per_site"] for s in eng.stage_times()))
         # pass B (mode 1, one pair per run of same-kernel launches): per-kernel durations for the roofline
         eng.set_profiling(1)
         eng.reset_stage_times()
@@ -391,7 +395,10 @@ def main():
             "kernel": dom["name"], "launches_per_step": dom["launches"] // max(KP, 1),
             "avg_launch_us": round(avg_ms * 1e3, 2), "flops_per_launch": per_launch_flops,
             "profiled_ms_per_step": round(prof_ms, 4),
-            "whole_path_tflops": round(spec.FLOPS_PER_SITE * result["value"] / world / 1e12, 2),
+            # FLOPs the engine EXECUTES per site (layer-0 input projection = table lookup, joint model folded into
+            # one J x 2 matrix at weight load), not the reference graph's contract FLOPs
+            "whole_path_tflops": round(exec_flops_per_site * result["value"] / world / 1e12, 2),
+            "flops_per_site": {"executed": exec_flops_per_site, "reference_graph": spec.FLOPS_PER_SITE},
         }
         if dom["name"] in alone:     # the same kernel with the GPU to itself (no signal-model kernels co-resident)
             a = alone[dom["name"]]
@@ -407,6 +414,35 @@ def main():
                                           if k["name"] in alone else None}
                              for k in ks}
         result["stages_us_per_step"] = stages
+    if rank == 0 and world == 1 and not args.dry_run and not args.no_three_step:
+        # like-for-like leg: the reference's three joint-model steps (avgpool kernel, J x J GEMM, head) instead of
+        # the folded J x 2 matrix -- same inputs, same timed-region rules, 3 windows
+        eng3 = Engine(device=local_rank, max_batch=BATCH, lstm_tiling=args.lstm_tiling, slots=args.slots, fold_fc=False)
+        eng3.load_weights(w)
+        def step3(i, slot):
+            b = (i % NPOOL) * BATCH
+            eng3.run_device(BATCH, d["kmer"][b:b + BATCH].data_ptr(), d["means"][b:b + BATCH].data_ptr(),
+                            d["stds"][b:b + BATCH].data_ptr(), d["sanums"][b:b + BATCH].data_ptr(),
+                            d["signals"][b:b + BATCH].data_ptr(), out_act[slot].data_ptr(), out_pred[slot].data_ptr())
+        for i in range(Wm):
+            step3(i, 0)
+        w3 = []
+        for rep in range(3):
+            eng3.sync(); dev_sync()
+            t0 = time.perf_counter()
+            for i in range(K):
+                step3(i, i)
+            eng3.sync(); dev_sync()
+            w3.append(time.perf_counter() - t0)
+        el3 = sorted(w3)[1]
+        st3 = {s["name"]: s for s in eng3.stage_times()}
+        result["joint_three_step"] = {
+            "value": round(K * BATCH / el3, 1) if K else 0.0, "unit": "sites/s", "ms_per_step": round(1e3 * el3 / max(K, 1), 4),
+            "whole_path_tflops": round(sum(s["flops_per_site"] for s in st3.values()) * K * BATCH / el3 / 1e12, 2) if K else 0.0,
+            "note": "Engine(fold_fc=False) = DS_TUNE_NO_FOLD_FC: avgpool7_kernel + dense(6032, 6032) GEMM + head_kernel "
+                    "as the reference graph runs them; the default engine folds them into one 6032 x 2 matrix "
+                    "(float64 product at weight load; layers.py:75-77,233-238,257-263 have no bias / activation)"}
+        eng3.close()
     if rank == 0 and world == 1 and not args.no_host_path:
         result["pcie_inclusive"] = pcie_inclusive(eng, feats, max(K, 64), BATCH)
         result["e2e_tsv"] = e2e_tsv(eng, feats, 40960, BATCH)

@@ -43,7 +43,7 @@ struct PackedGemm {      // device-resident packed weights of one GEMM
     int K = 0, N = 0;
 };
 
-enum OpKind { OP_GEMM, OP_STEM1, OP_MAXPOOL, OP_AVGPOOL, OP_HEAD, OP_FUSED, OP_PACKEV, OP_LSTM, OP_STEM23 };
+enum OpKind { OP_GEMM, OP_STEM1, OP_MAXPOOL, OP_AVGPOOL, OP_HEAD, OP_FUSED, OP_PACKEV, OP_LSTM, OP_STEM23, OP_HEADF };
 
 struct Op {
     OpKind kind;
@@ -58,6 +58,7 @@ struct Op {
     int a = 0, b = 0, c = 0, d = 0;
     FusedArgs fa{};                       // OP_FUSED
     Stem23Args sa{};                      // OP_STEM23
+    HeadFoldedArgs ha{};                  // OP_HEADF
     int tm = 0;
     double flops = 0;                     // algorithmic FLOPs of this launch
     hipEvent_t ev0 = nullptr, ev1 = nullptr;   // profiling mode only
@@ -68,7 +69,7 @@ struct Op {
 
 // per-kernel accumulators (one entry per __global__ function / template instantiation)
 enum KernelClass { K_GEMM_CONV = 0, K_GEMM_FC, K_GEMM_LSTM, K_GEMM_CONV_WIDE, K_GEMM_CONV_POOL, K_GEMM_FC_DENSE, K_GEMM_LSTM_DENSE, K_FUSED1, K_FUSED2, K_FUSED3, K_STEM1, K_MAXPOOL, K_AVGPOOL, K_HEAD,
-                   K_GEMM_BCONV, K_GEMM_BCONV_POOL, K_GEMM_BFC, K_GEMM_BFC_DENSE, K_PACKEV, K_GEMM_BLSTM, K_GEMM_BLSTM_DENSE, K_FUSEDB1, K_FUSEDB2, K_FUSEDB3, K_GEMM_LSTM_T, K_GEMM_LSTM_T_DENSE, K_GEMM_BLSTM_T, K_GEMM_BLSTM_T_DENSE, K_LSTM_CELL1, K_LSTM_CELL2, K_LSTM_CELL4, K_LSTM_LDS1, K_LSTM_LDS2, K_STEM23, K_COUNT };
+                   K_GEMM_BCONV, K_GEMM_BCONV_POOL, K_GEMM_BFC, K_GEMM_BFC_DENSE, K_PACKEV, K_GEMM_BLSTM, K_GEMM_BLSTM_DENSE, K_FUSEDB1, K_FUSEDB2, K_FUSEDB3, K_GEMM_LSTM_T, K_GEMM_LSTM_T_DENSE, K_GEMM_BLSTM_T, K_GEMM_BLSTM_T_DENSE, K_LSTM_CELL1, K_LSTM_CELL2, K_LSTM_CELL4, K_LSTM_LDS1, K_LSTM_LDS2, K_STEM23, K_HEADF, K_COUNT };
 const char* const kKernelNames[K_COUNT] = {"gemm_kernel<1,2,4,1,0,0,1,1>", "gemm_kernel<1,3,4,1,0,0,2,1>", "gemm_kernel<1,4,4,1,1,0,1,1>",
                                            "gemm_kernel<2,2,2,2,0,0,1,1>", "gemm_kernel<1,2,4,1,0,1,1,1>", "gemm_kernel<1,3,4,1,0,2,2,1>",
                                            "gemm_kernel<1,4,4,1,1,2,1,1>", "inception_fused_kernel<1>",
@@ -82,7 +83,7 @@ const char* const kKernelNames[K_COUNT] = {"gemm_kernel<1,2,4,1,0,0,1,1>", "gemm
                                            "gemm_kernel<1,1,4,1,2,0,1,1>", "gemm_kernel<1,1,4,1,2,2,1,1>",
                                            "gemm_kernel<1,1,4,1,2,0,3,1,bf16>", "gemm_kernel<1,1,4,1,2,2,3,1,bf16>",
                                            "lstm_cell_kernel<1>", "lstm_cell_kernel<2>", "lstm_cell_kernel<4>",
-                                           "lstm_cell_lds_kernel<1>", "lstm_cell_lds_kernel<2>", "stem23_kernel"};
+                                           "lstm_cell_lds_kernel<1>", "lstm_cell_lds_kernel<2>", "stem23_kernel", "head_folded_kernel"};
 struct KernelStat {
     int64_t launches = 0;
     double total_ms = 0;
@@ -153,6 +154,7 @@ struct ds_handle {
     int lstm_t = -1;          // LSTM cell tiling: 1 = always 128 x 32 (CFG_*LSTM_T), 0 = always 128 x 128, -1 = by forward size
     // per-handle tuning / diagnostic knobs, all from ds_config.reserved[2..5] (include/deepsignal_hip.h)
     bool no_fused = false;    // DS_TUNE_NO_FUSED: layer-granular inception modules instead of the fused kernel
+    bool fold_fc = false;     // joint model folded into one J x class_num matrix (fp32, not DS_TUNE_NO_FOLD_FC, not debug)
     bool serial = false;      // DS_TUNE_SERIAL: every launch of a forward on ONE stream (stand-alone kernel times)
     int fuse_max_spt = 8;     // sites per fused-module tile, upper bound
     int fuse_min_tiles = 128; // fused-module grids keep at least this many workgroups when the batch allows it
@@ -180,6 +182,7 @@ struct ds_handle {
     float* lstm_wfeat[2] = {nullptr, nullptr};
     PackedGemm fc1;
     float* fc2 = nullptr;
+    float* w12f = nullptr;    // fold_fc: [J][C] = (avgpool^T on the signal rows) (W1 W2), float64 product rounded once
 
     bool debug_keep_pool = false;   // keep the stand-alone maxpool kernels (diagnostic)
     const float* zero_seg = nullptr;
@@ -459,7 +462,41 @@ int finalize_weights(ds_handle* h)
     const int J = h->J;
     if (!w1 || !w2 || (int64_t)w1->data.size() != (int64_t)J * J || (int64_t)w2->data.size() != (int64_t)J * h->C)
         return fail(h, DS_ERR_INVALID, "missing/bad dense kernels");
-    {
+    if (h->fold_fc) {
+        // W12 = W1 W2 in float64 (no bias, no activation, identity dropout between the two dense layers), then the
+        // transpose of avgpool(7, SAME, divisor = in-bounds taps) applied to the signal rows: the head reads module 11's
+        // rows directly
+        const int C = h->C;
+        std::vector<double> w12((size_t)J * C, 0.0);
+        const float* a1 = w1->data.data();
+        const float* a2 = w2->data.data();
+        for (int k = 0; k < J; ++k) {
+            double* o = &w12[(size_t)k * C];
+            const float* r = a1 + (size_t)k * J;
+            for (int m = 0; m < J; ++m) {
+                const double v = r[m];
+                for (int c = 0; c < C; ++c) o[c] += v * (double)a2[(size_t)m * C + c];
+            }
+        }
+        std::vector<float> wf((size_t)J * C);
+        const int ev = h->is_rnn ? 2 * HID : 0;
+        for (int k = 0; k < ev; ++k)
+            for (int c = 0; c < C; ++c) wf[(size_t)k * C + c] = (float)w12[(size_t)k * C + c];
+        if (h->is_cnn) {
+            const int wc = h->wc;
+            for (int w = 0; w < wc; ++w)
+                for (int ch = 0; ch < INC_OUT; ++ch)
+                    for (int c = 0; c < C; ++c) {
+                        double sacc = 0.0;
+                        for (int wp = std::max(0, w - 3); wp <= std::min(wc - 1, w + 3); ++wp) {
+                            const int cnt = std::min(wc - 1, wp + 3) - std::max(0, wp - 3) + 1;
+                            sacc += w12[(size_t)(ev + wp * INC_OUT + ch) * C + c] / cnt;
+                        }
+                        wf[(size_t)(ev + w * INC_OUT + ch) * C + c] = (float)sacc;
+                    }
+        }
+        if ((rc = upload(h, &h->w12f, wf))) return rc;
+    } else {
         const float* wd = w1->data.data();
         auto wfun = [&](int k, int col) { return wd[(size_t)k * J + col]; };
         std::vector<float> packed = h->bf16 ? pack_b_bf16(J, J, wfun) : pack_b(J, J, wfun);
@@ -597,6 +634,7 @@ int build_plan(ds_handle* h, int n, Plan* plan)
 
     // ================= signal model (stream 0) — layers.py:181-239 =================
     int st = 0;
+    const float* sig_rows = nullptr;      // module 11's output rows (what the folded head reads)
     if (h->is_cnn) {
     st = stage_id(h, "stem", 0);
     {
@@ -736,7 +774,8 @@ int build_plan(ds_handle* h, int n, Plan* plan)
             }
         }
     }
-    {   // avgpool_layer1 + flatten                                              layers.py:233-238
+    sig_rows = x;
+    if (!h->fold_fc) {   // avgpool_layer1 + flatten                                              layers.py:233-238
         Op op{};
         op.kind = OP_AVGPOOL; op.stream = 0; op.stage = stage_id(h, "pools", 0);
         op.in = x; op.out = bf ? h->cur->joint : h->cur->sigfeat; op.a = h->wc; op.d = INC_OUT;
@@ -856,6 +895,21 @@ int build_plan(ds_handle* h, int n, Plan* plan)
 
     // ================= joint model (stream 0 after join) — layers.py:247-264 =================
     std::vector<Op> tail;
+    if (h->fold_fc) {
+        st = stage_id(h, "head", 0);
+        Op op{};
+        op.kind = OP_HEADF; op.stream = 0; op.stage = st;
+        HeadFoldedArgs& a = op.ha;
+        if (h->is_rnn) {
+            a.seg[a.nseg] = h->cur->hlast[0]; a.len[a.nseg++] = HID;
+            a.seg[a.nseg] = h->cur->hlast[1]; a.len[a.nseg++] = HID;
+        }
+        if (h->is_cnn) { a.seg[a.nseg] = sig_rows; a.len[a.nseg++] = h->SF; }
+        a.w = h->w12f; a.logits = h->cur->logits; a.act = h->cur->act; a.pred = h->cur->pred; a.n = n; a.C = h->C;
+        op.flops = 2.0 * h->J * h->C * n;
+        add_ew_op(tail, op);
+        if (first_plan) h->stages[st].flops_per_site += 2.0 * h->J * h->C;
+    } else {
     st = stage_id(h, "fc1", 0);
     {
         GemmLaunch L{};
@@ -881,6 +935,7 @@ int build_plan(ds_handle* h, int n, Plan* plan)
         op.flops = 2.0 * h->J * h->C * n;
         add_ew_op(tail, op);
         if (first_plan) h->stages[st].flops_per_site += 2.0 * h->J * h->C;
+    }
     }
 
     // merged issue order: alternate the two independent branches, then the tail
@@ -929,6 +984,9 @@ int issue_op(ds_handle* h, Plan& plan, const Op& op, hipStream_t s)
         break;
     case OP_STEM23:
         HIPCHK(h, launch_stem23(op.sa, s));
+        break;
+    case OP_HEADF:
+        HIPCHK(h, launch_head_folded(op.ha, s));
         break;
     case OP_FUSED:
         if (h->bf16) HIPCHK(h, launch_inception_fused_bf16(op.tm, op.fa, s));
@@ -1021,6 +1079,7 @@ int kernel_class(const Op& op)
         return op.tm == 1 ? K_FUSED1 : op.tm == 2 ? K_FUSED2 : K_FUSED3;
     case OP_STEM1: return K_STEM1;
     case OP_STEM23: return K_STEM23;
+    case OP_HEADF: return K_HEADF;
     case OP_MAXPOOL: return K_MAXPOOL;
     case OP_AVGPOOL: return K_AVGPOOL;
     case OP_HEAD: return K_HEAD;
@@ -1189,6 +1248,7 @@ static int ds_create_impl(const ds_config* cfg, ds_handle** out)
     const int32_t flags = cfg->reserved[2];
     h->no_fused = (flags & DS_TUNE_NO_FUSED) != 0;
     h->serial = (flags & DS_TUNE_SERIAL) != 0;
+    h->fold_fc = !(flags & DS_TUNE_NO_FOLD_FC) && cfg->precision == DS_PRECISION_FP32 && cfg->reserved[0] == 0 && cfg->class_num <= 16;
     h->lstm_t = cfg->reserved[3] == DS_LSTM_TILING_NARROW ? 1 : cfg->reserved[3] == DS_LSTM_TILING_WIDE ? 0 : -1;
     h->lstm_variant = cfg->reserved[3];
     if (cfg->reserved[4] > 0) h->fuse_max_spt = cfg->reserved[4];
@@ -1526,6 +1586,8 @@ int64_t ds_get_intermediate(ds_handle* h, const char* name, float* out, int64_t 
     if (s == "stem_pool") return copy(h->cur->stem_pool, (int64_t)n * h->wa * 64);
     if (s == "stem_conv2") return copy(h->cur->conv2o, (int64_t)n * h->wa * 128);
     if (s == "stem_conv3") return copy(h->cur->conv3o, (int64_t)n * h->wa * 256);
+    if (h->fold_fc && (s == "signal_feat" || s == "fc1" || s == "joint"))
+        return fail(h, DS_ERR_INVALID, "the folded joint model has no " + s + " tensor: use debug mode or DS_TUNE_NO_FOLD_FC");
     if (s == "signal_feat") return copy(h->cur->sigfeat, (int64_t)n * h->SF);
     if (s == "fc1") return copy(h->cur->fc1o, (int64_t)n * h->J);
     if (s == "logits") return copy(h->cur->logits, (int64_t)n * h->C);

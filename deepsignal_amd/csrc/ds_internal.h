@@ -170,6 +170,18 @@ hipError_t launch_avgpool7(const float* in, float* out, int n, int w, int ch, hi
 // fc2 (J x class_num, no bias) + sigmoid + argmax                               layers.py:261-263, model.py:100,108
 hipError_t launch_head(const float* fc1, const float* w2, float* logits, float* act, int* pred,
                        int n, int J, int class_num, hipStream_t s);
+// Folded joint model (DS_TUNE_NO_FOLD_FC off): logits = x W12', x = up to three row segments per site (h_fw(T-1), h_bw(0),
+// module-11 rows), W12' [J][class_num] k-major; then sigmoid + argmax as launch_head        layers.py:233-238,247-264
+struct HeadFoldedArgs {
+    const float* seg[3];
+    int len[3];           // floats per site in the segment (multiple of 4)
+    int nseg;
+    const float* w;       // [sum len][C]
+    float *logits, *act;
+    int* pred;
+    int n, C;
+};
+hipError_t launch_head_folded(const HeadFoldedArgs& a, hipStream_t s);
 // table[v][c] = sum_e emb[v][e] * kernel[e][c]  (embedding folded into layer-0 W_x; model.py:61-69)
 hipError_t launch_embed_table(const float* emb, const float* kernel, float* table, int vocab, int esize, int ncol, hipStream_t s);
 

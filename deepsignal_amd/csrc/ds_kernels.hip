@@ -2205,6 +2205,65 @@ hipError_t launch_head(const float* fc1, const float* w2, float* logits, float* 
     return hipGetLastError();
 }
 
+// Folded joint model: one workgroup per site, x = concatenation of up to three contiguous row segments.
+__global__ __launch_bounds__(256) void head_folded_kernel(const HeadFoldedArgs a)
+{
+    __shared__ float part[4][16];
+    const int site = blockIdx.x, C = a.C;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float accv[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) accv[c] = 0.0f;
+    int koff = 0;
+    for (int sg = 0; sg < a.nseg; ++sg) {                 // uniform
+        const int len = a.len[sg];
+        const float4* x4 = reinterpret_cast<const float4*>(a.seg[sg] + (size_t)site * len);
+        for (int k4 = tid; k4 < (len >> 2); k4 += 256) {
+            const float4 x = x4[k4];
+            const float* w = a.w + (size_t)(koff + k4 * 4) * C;
+            if (C == 2) {
+                const float4 wa = *reinterpret_cast<const float4*>(w);
+                const float4 wb = *reinterpret_cast<const float4*>(w + 4);
+                accv[0] = fmaf(x.x, wa.x, fmaf(x.y, wa.z, fmaf(x.z, wb.x, fmaf(x.w, wb.z, accv[0]))));
+                accv[1] = fmaf(x.x, wa.y, fmaf(x.y, wa.w, fmaf(x.z, wb.y, fmaf(x.w, wb.w, accv[1]))));
+            } else {
+#pragma unroll
+                for (int c = 0; c < 16; ++c)
+                    if (c < C) accv[c] += x.x * w[c] + x.y * w[C + c] + x.z * w[2 * C + c] + x.w * w[3 * C + c];
+            }
+        }
+        koff += len;
+    }
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        if (c >= C) break;
+        float v = accv[c];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+        if (lane == 0) part[wave][c] = v;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        float best = 0.0f;
+        int bi = 0;
+        for (int c = 0; c < C; ++c) {
+            const float v = (part[0][c] + part[1][c]) + (part[2][c] + part[3][c]);
+            const float sgm = sigmoidf_(v);
+            a.logits[(size_t)site * C + c] = v;
+            a.act[(size_t)site * C + c] = sgm;
+            if (c == 0 || sgm > best) { best = sgm; bi = c; }
+        }
+        a.pred[site] = bi;
+    }
+}
+
+hipError_t launch_head_folded(const HeadFoldedArgs& a, hipStream_t s)
+{
+    if (a.n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(head_folded_kernel, dim3(a.n), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
 // ---- bf16-mode elementwise kernels: 8 channels (16 B) per thread ----
 __global__ __launch_bounds__(256) void maxpool_s2_bf16_kernel(const float4* __restrict__ in, float4* __restrict__ out,
                                                                long total, int win, int wout, int pad_l, int ch8)

@@ -65,10 +65,17 @@ typedef struct ds_config {
                              process-global tuning state, so two handles in one process never influence each other. */
 } ds_config;
 
-/* ds_config.reserved[2] bits — diagnostics, results are unchanged (same bits out) */
+/* ds_config.reserved[2] bits — bits 1, 2, 4 are diagnostics: results are unchanged (same bits out) */
 #define DS_TUNE_NO_FUSED 1       /* layer-granular GEMM launches for the inception modules instead of the fused kernel */
 #define DS_TUNE_SERIAL 2         /* every launch of a forward on ONE stream (stand-alone kernel durations)            */
 #define DS_TUNE_DEBUG_STAMPS 4   /* attach the s_memtime stamp buffer of the fused kernels (tools/stamps.py)          */
+/* not a diagnostic: changes the arithmetic (within rounding). By default the fp32 engine FOLDS the joint model: the two
+   dense layers have no bias, no activation and (at inference) an identity dropout between them (layers.py:75-77,257-263),
+   and the average pool in front of them is linear too (layers.py:233-238), so
+   logits = [h_fw | h_bw | avgpool(module 11)] W1 W2 = [h_fw | h_bw | module 11] W12' with a J x class_num matrix W12'
+   computed once per weight load in float64 — like the BN fold, exact in real arithmetic. This bit keeps the reference's
+   three steps (avgpool kernel, J x J GEMM, head); debug mode (reserved[0]) implies it, so the fc1 / signal_feat taps exist. */
+#define DS_TUNE_NO_FOLD_FC 8
 /* ds_config.reserved[3] */
 #define DS_LSTM_TILING_AUTO 0    /* by forward size */
 #define DS_LSTM_TILING_NARROW 1  /* one 32-column n-tile per wave  */

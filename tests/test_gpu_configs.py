@@ -80,6 +80,14 @@ def test_forward_golden_vectors_replayed_on_the_gpu():
     close(eng.intermediate("signal_feat", (n, 5520))[:, :512], g["signal_feat_head"], "signal_feat")
     close(eng.intermediate("fc1", (n, 6032))[:, :512], g["fc1_head"], "fc1")
     eng.close()
+    # the product default (not debug): joint model folded into one 6032 x 2 matrix -- same golden outputs
+    eng = Engine(max_batch=16)
+    eng.load_weights(w)
+    act, pred = eng.run(*(g["in_" + k] for k in KEYS))
+    assert np.abs(act - g["act"]).max() <= ACT_ATOL and (pred[decided] == g["pred"][decided]).all()
+    close(eng.intermediate("logits", (n, 2)), g["logits"], "logits (folded)")
+    close(eng.intermediate("module11", (n, 23, 240)), g["module11"], "module11 (folded)")
+    eng.close()
 
 
 # ------------------------------------------------------------------------------------------------------------------

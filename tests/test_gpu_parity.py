@@ -96,10 +96,12 @@ def test_graph_and_eager_agree_and_are_deterministic(small_weights):
     assert np.array_equal(a_g, a_g2) and np.array_equal(a_g, a_e) and np.array_equal(a_g, a_p)
     assert np.array_equal(p_g, p_e)
     st = {s["name"]: s for s in eng.stage_times()}
-    assert st["fc1"]["calls"] == 1 and st["fc1"]["total_ms"] > 0
+    # the default engine folds the joint model (no fc1 stage); layer-0 input projection is a table lookup, so the LSTM
+    # does fewer MACs than the reference graph
+    assert "fc1" not in st and st["head"]["calls"] == 1 and st["head"]["total_ms"] > 0
     total = sum(s["flops_per_site"] for s in st.values())
-    # layer-0 input projection is a table lookup, so the LSTM does fewer MACs than the reference graph
-    assert 0.9 * spec.FLOPS_PER_SITE < total <= spec.FLOPS_PER_SITE * 1.001
+    folded = spec.FLOPS_PER_SITE - 2.0 * 6032 * 6032
+    assert 0.9 * folded < total <= folded * 1.001
     eng.close()
 
 
@@ -324,3 +326,36 @@ def test_class_num_three():
     decided = srt[:, -1] - srt[:, -2] > 1e-3
     assert (pred[decided] == o_pred[decided]).all()
     eng.close()
+
+
+@pytest.mark.parametrize("variant", [dict(), dict(is_cnn=False), dict(is_rnn=False), dict(class_num=3)])
+def test_folded_joint_model_matches_the_three_step_path(variant):
+    """Default fp32 engine: avgpool + dense(J, J) + dense(J, C) (layers.py:233-238,257-263: no bias, no activation,
+    identity dropout) are folded into ONE J x C matrix at weight load (float64 product). DS_TUNE_NO_FOLD_FC keeps the
+    reference's three steps. Same function, different rounding: logits agree to fp32 rounding, both agree with the
+    oracle, and the folded handle refuses the taps it no longer computes."""
+    from deepsignal_amd import weights as W
+    from oracle import oracle
+    w = W.random_weights(seed=21, lstm_bias_std=0.1, **variant)
+    feats = synth.synthetic_features(300, seed=77)
+    keys = ("kmer", "means", "stds", "sanums", "signals")
+    folded = _engine(w, max_batch=512, **variant)
+    steps = _engine(w, max_batch=512, fold_fc=False, **variant)
+    act_f, pred_f = folded.run(*[feats[k] for k in keys])
+    act_s, pred_s = steps.run(*[feats[k] for k in keys])
+    C = variant.get("class_num", 2)
+    lf, ls = folded.intermediate("logits", (300, C)), steps.intermediate("logits", (300, C))
+    assert np.abs(lf - ls).max() <= 2e-6 * max(1.0, float(np.abs(ls).max()))
+    assert np.abs(act_f - act_s).max() <= 2e-6
+    o_act, o_pred = oracle.forward(w, feats, "f32", **variant)
+    _check_outputs(act_f, pred_f, o_act, o_pred)
+    _check_outputs(act_s, pred_s, o_act, o_pred)
+    with pytest.raises(RuntimeError):
+        folded.intermediate("fc1", (300, steps_j(variant)))
+    assert steps.intermediate("fc1", (300, steps_j(variant))).shape[1] == steps_j(variant)
+    assert "fc1" in {s["name"] for s in steps.stage_times()} and "fc1" not in {s["name"] for s in folded.stage_times()}
+    folded.close(); steps.close()
+
+
+def steps_j(variant):
+    return spec.net_dims(is_cnn=variant.get("is_cnn", True), is_rnn=variant.get("is_rnn", True)).joint
