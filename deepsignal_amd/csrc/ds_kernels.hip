@@ -1181,7 +1181,8 @@ __global__ __launch_bounds__(512, DS_FUSED_WPS) void inception_fused_kernel(cons
     unsigned long long* sdst = a.dbg + ((size_t)blockIdx.x * 2 + (wave == 7)) * 8;
 #define DS_STAMP(i) do { if (stamp) sdst[i] = __builtin_amdgcn_s_memtime(); } while (0)
     DS_STAMP(0);
-    for (int i = tid; i < (spt * (W + 4) + 5) * F_LD1; i += 512) T1[i] = 0.0f;   // halos (and everything else) = 0
+    for (int i = tid; i < (spt * (W + 4) + 5) * (F_LD1 / 4); i += 512)          // halos (and everything else) = 0
+        reinterpret_cast<float4*>(T1)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (tid < TR32)   // rows past the tile's last site map to the dump row, so LDS writes need no predicate
         rowmap[tid] = tid < TRv ? (tid / W) * (W + 4) + 2 + tid % W : spt * (W + 4) + 2;
     if (tid >= 256 && tid < 448) {
