@@ -482,7 +482,9 @@ int finalize_weights(ds_handle* h)
         const int ev = h->is_rnn ? 2 * HID : 0;
         for (int k = 0; k < ev; ++k)
             for (int c = 0; c < C; ++c) wf[(size_t)k * C + c] = (float)w12[(size_t)k * C + c];
-        if (h->is_cnn) {
+        if (h->is_cnn && h->bf16) {      // bf16 modes keep the pooling kernel (it writes the bf16 joint row the head reads)
+            for (size_t i = (size_t)ev * C; i < wf.size(); ++i) wf[i] = (float)w12[i];
+        } else if (h->is_cnn) {
             const int wc = h->wc;
             for (int w = 0; w < wc; ++w)
                 for (int ch = 0; ch < INC_OUT; ++ch)
@@ -775,7 +777,7 @@ int build_plan(ds_handle* h, int n, Plan* plan)
         }
     }
     sig_rows = x;
-    if (!h->fold_fc) {   // avgpool_layer1 + flatten                                              layers.py:233-238
+    if (!h->fold_fc || bf) {   // avgpool_layer1 + flatten (folded into the head's matrix in fp32)            layers.py:233-238
         Op op{};
         op.kind = OP_AVGPOOL; op.stream = 0; op.stage = stage_id(h, "pools", 0);
         op.in = x; op.out = bf ? h->cur->joint : h->cur->sigfeat; op.a = h->wc; op.d = INC_OUT;
@@ -900,11 +902,15 @@ int build_plan(ds_handle* h, int n, Plan* plan)
         Op op{};
         op.kind = OP_HEADF; op.stream = 0; op.stage = st;
         HeadFoldedArgs& a = op.ha;
+        if (bf) {
+            a.seg[0] = h->cur->joint; a.len[0] = h->J; a.nseg = 1; a.bf16_pitch = h->JP;
+        } else {
         if (h->is_rnn) {
             a.seg[a.nseg] = h->cur->hlast[0]; a.len[a.nseg++] = HID;
             a.seg[a.nseg] = h->cur->hlast[1]; a.len[a.nseg++] = HID;
         }
         if (h->is_cnn) { a.seg[a.nseg] = sig_rows; a.len[a.nseg++] = h->SF; }
+        }
         a.w = h->w12f; a.logits = h->cur->logits; a.act = h->cur->act; a.pred = h->cur->pred; a.n = n; a.C = h->C;
         op.flops = 2.0 * h->J * h->C * n;
         add_ew_op(tail, op);
@@ -1248,7 +1254,7 @@ static int ds_create_impl(const ds_config* cfg, ds_handle** out)
     const int32_t flags = cfg->reserved[2];
     h->no_fused = (flags & DS_TUNE_NO_FUSED) != 0;
     h->serial = (flags & DS_TUNE_SERIAL) != 0;
-    h->fold_fc = !(flags & DS_TUNE_NO_FOLD_FC) && cfg->precision == DS_PRECISION_FP32 && cfg->reserved[0] == 0 && cfg->class_num <= 16;
+    h->fold_fc = !(flags & DS_TUNE_NO_FOLD_FC) && cfg->reserved[0] == 0 && cfg->class_num <= 16;
     h->lstm_t = cfg->reserved[3] == DS_LSTM_TILING_NARROW ? 1 : cfg->reserved[3] == DS_LSTM_TILING_WIDE ? 0 : -1;
     h->lstm_variant = cfg->reserved[3];
     if (cfg->reserved[4] > 0) h->fuse_max_spt = cfg->reserved[4];

@@ -177,6 +177,7 @@ struct HeadFoldedArgs {
     int len[3];           // floats per site in the segment (multiple of 4)
     int nseg;
     const float* w;       // [sum len][C]
+    int bf16_pitch;       // > 0: ONE segment of bf16 rows (seg[0], len[0] values per site, this many bf16 per row): the bf16 modes' joint buffer
     float *logits, *act;
     int* pred;
     int n, C;

@@ -2216,6 +2216,21 @@ __global__ __launch_bounds__(256) void head_folded_kernel(const HeadFoldedArgs a
 #pragma unroll
     for (int c = 0; c < 16; ++c) accv[c] = 0.0f;
     int koff = 0;
+    if (a.bf16_pitch > 0) {                               // bf16 modes: [event | signal features] bf16 row, 8 values per 16 bytes
+        const float4* x8 = reinterpret_cast<const float4*>(reinterpret_cast<const unsigned short*>(a.seg[0]) + (size_t)site * a.bf16_pitch);
+        for (int k8 = tid; k8 < (a.len[0] >> 3); k8 += 256) {
+            const float4 raw = x8[k8];
+            const unsigned u[4] = {__float_as_uint(raw.x), __float_as_uint(raw.y), __float_as_uint(raw.z), __float_as_uint(raw.w)};
+            const float* w = a.w + (size_t)k8 * 8 * C;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float x0 = __uint_as_float(u[e] << 16), x1 = __uint_as_float(u[e] & 0xffff0000u);
+#pragma unroll
+                for (int c = 0; c < 16; ++c)
+                    if (c < C) accv[c] += x0 * w[(2 * e) * C + c] + x1 * w[(2 * e + 1) * C + c];
+            }
+        }
+    } else
     for (int sg = 0; sg < a.nseg; ++sg) {                 // uniform
         const int len = a.len[sg];
         const float4* x4 = reinterpret_cast<const float4*>(a.seg[sg] + (size_t)site * len);

@@ -16,7 +16,7 @@ dev = torch.device("cuda", 0)
 f = synth.synthetic_features(B, seed=1)
 keys = ("kmer", "means", "stds", "sanums", "signals")
 d = {k: torch.from_numpy(f[k]).to(dev) for k in keys}
-out = {"batch": B, "config": "configs[2]: bf16 conv+FC, fp32 BiLSTM, batch %d" % B}
+out = {"batch": B, "config": "configs[2]: bf16 conv (+ folded fp32 joint model), fp32 BiLSTM, batch %d" % B}
 acts = {}
 for prec in ("fp32", "bf16", "bf16_all"):
     e = Engine(device=0, max_batch=B, precision=prec); e.load_weights(w)
@@ -30,7 +30,8 @@ for prec in ("fp32", "bf16", "bf16_all"):
     e.sync(); dt = time.perf_counter() - t0
     acts[prec] = (act.cpu().numpy(), pred.cpu().numpy())
     r = {"ms_per_step": round(1e3 * dt / K, 4), "sites_per_s": round(K * B / dt, 1), "steps": K,
-         "tflops_algorithmic": round(K * B / dt * spec.FLOPS_PER_SITE / 1e12, 2)}
+         "tflops_executed": round(K * B / dt * sum(st["flops_per_site"] for st in e.stage_times()) / 1e12, 2),
+         "joint_model": "folded (W1 W2 -> 6032 x 2 in float64 at load%s)" % ("; avgpool folded too" if prec == "fp32" else "; bf16 joint row, fp32 matrix")}
     e.set_profiling(1); e.reset_stage_times()
     for _ in range(3): step()
     e.sync()
