@@ -445,7 +445,7 @@ def main():
         eng3.close()
     if rank == 0 and world == 1 and not args.no_host_path:
         result["pcie_inclusive"] = pcie_inclusive(eng, feats, max(K, 64), BATCH)
-        result["e2e_tsv"] = e2e_tsv(eng, feats, 40960, BATCH)
+        result["e2e_tsv"] = e2e_tsv(eng, feats, 163840, BATCH)
     eng.close()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(w)
