@@ -206,12 +206,17 @@ class _RowPipeline:
 
     With an engine that has the asynchronous boundary (submit / wait) batches are filled ACROSS queue items (a site's
     result does not depend on its batch mates), so the engine sees full batch_size forwards instead of one ragged tail
-    per item, and up to `engine.slots` batches are in flight while the caller parses the next item. Rows still leave in
-    file order, a read's rows together. `tag` travels with every row (the sharded path uses it to know which work unit
-    a row belongs to)."""
+    per item, and up to `engine.slots` batches are in flight while the caller parses the next item. A batch that
+    straddles items is handed over as row segments (`submit_parts`: gathered by the library straight into its pinned
+    staging buffer, no concatenated copy), and finished batches are formatted and sunk by ONE helper thread in
+    completion = feed order (the native formatter releases the GIL), so the feeding thread only submits and waits.
+    Rows still leave in file order, a read's rows together. `tag` travels with every row (the sharded path uses it to
+    know which work unit a row belongs to)."""
 
     def __init__(self, engine, batch_size, sink):
         import collections
+        import queue
+        import threading
         from . import fastio
         self.engine, self.batch_size, self.sink, self.fastio = engine, batch_size, sink, fastio
         self.pipelined = hasattr(engine, "submit") and hasattr(engine, "wait") and \
@@ -219,31 +224,76 @@ class _RowPipeline:
         self.inflight = collections.deque()
         self.segs, self.count = [], 0
         self.nsites = 0
+        self._outq = self._worker = self._error = None
+        self._queued, self._qlock = {}, threading.Lock()      # tag -> batches waited but not yet through the sink
+        if self.pipelined:
+            self._outq = queue.Queue(maxsize=4 * max(1, getattr(engine, "slots", 1)))
+            self._worker = threading.Thread(target=self._format_loop, daemon=True)
+            self._worker.start()
 
     def _emit(self, seg, act, pred):
         tag, it, s, e = seg
         self.sink(tag, self.fastio.format_rows(it.info, it.info_off[s:e + 1], act, pred, it.kmer[s:e]))
 
+    def _format_loop(self):
+        while True:
+            job = self._outq.get()
+            try:
+                if job is None:
+                    return
+                segs, act, pred = job
+                try:
+                    if self._error is None:
+                        o = 0
+                        for seg in segs:
+                            m = seg[3] - seg[2]
+                            self._emit(seg, act[o:o + m], pred[o:o + m])
+                            o += m
+                finally:
+                    with self._qlock:
+                        for seg in segs:
+                            self._queued[seg[0]] -= 1
+                            if not self._queued[seg[0]]:
+                                del self._queued[seg[0]]
+            except BaseException as exc:      # surfaced by the feeding thread (flush / next drain)
+                self._error = exc
+            finally:
+                self._outq.task_done()
+
+    def _check_worker(self):
+        if self._error is not None:
+            exc, self._error = self._error, None
+            raise exc
+
     def _drain(self, limit):
         while len(self.inflight) > limit:
             ticket, segs = self.inflight.popleft()
             act, pred = self.engine.wait(ticket)
-            o = 0
-            for seg in segs:
-                m = seg[3] - seg[2]
-                self._emit(seg, act[o:o + m], pred[o:o + m])
-                o += m
+            self._check_worker()
+            with self._qlock:
+                for seg in segs:
+                    self._queued[seg[0]] = self._queued.get(seg[0], 0) + 1
+            self._outq.put((segs, act, pred))
+
+    def live_tags(self):
+        """Tags with rows still inside the pipeline (being filled, in flight, or waiting for the formatter)."""
+        with self._qlock:
+            live = set(self._queued)
+        live.update(seg[0] for seg in self.segs)
+        live.update(seg[0] for _, segs in self.inflight for seg in segs)
+        return live
 
     def _submit(self):
         segs, self.segs, self.count = self.segs, [], 0
         self._drain(self.engine.slots - 1)
-        if len(segs) == 1:
-            _, it, s, e = segs[0]
-            arrs = (it.kmer[s:e], it.means[s:e], it.stds[s:e], it.lens[s:e], it.signals[s:e])
+        parts = [(it.kmer[s:e], it.means[s:e], it.stds[s:e], it.lens[s:e], it.signals[s:e]) for _, it, s, e in segs]
+        if len(parts) == 1:
+            ticket = self.engine.submit(*parts[0])
+        elif hasattr(self.engine, "submit_parts"):
+            ticket = self.engine.submit_parts(parts)
         else:
-            arrs = tuple(np.concatenate([getattr(it, k)[s:e] for _, it, s, e in segs])
-                         for k in ("kmer", "means", "stds", "lens", "signals"))
-        self.inflight.append((self.engine.submit(*arrs), segs))
+            ticket = self.engine.submit(*(np.concatenate([p[j] for p in parts]) for j in range(5)))
+        self.inflight.append((ticket, segs))
 
     def feed(self, item, tag=None):
         n = len(item.labels)
@@ -270,6 +320,15 @@ class _RowPipeline:
             if self.count:
                 self._submit()
             self._drain(0)
+            self._outq.join()
+            self._check_worker()
+
+    def close(self):
+        """Stop the helper thread (after a flush; idempotent)."""
+        if self._worker is not None:
+            self._outq.put(None)
+            self._worker.join()
+            self._worker = None
 
 
 def _prefetch(iterable, depth=3):
@@ -357,7 +416,7 @@ def _call_mods_sharded(input_path, engine, batch_size, result_file, kmer_len, ce
                 continue
             pending_done.append(c)
             # a chunk's rows have all drained when nothing of it is buffered in the pipeline any more
-            live = {seg[0] for seg in pipe.segs} | {seg[0] for _, segs in pipe.inflight for seg in segs}
+            live = pipe.live_tags()
             fed_all.update(x for x in pending_done if x not in live)
             pending_done = [x for x in pending_done if x in live]
             hand_over(fed_all)
@@ -371,6 +430,7 @@ def _call_mods_sharded(input_path, engine, batch_size, result_file, kmer_len, ce
         try:
             total, _ = gather.close(pipe.nsites, 0, failed=failed)
         finally:
+            pipe.close()
             reader.close()
     return total
 
@@ -416,9 +476,12 @@ def call_mods(input_path, model_path, result_file, kmer_len, cent_signals_len,
             reader = fastio.FeatureReader(input_path, kmer_len, cent_signals_len)
             with open(result_file, "wb") as wf:
                 pipe = _RowPipeline(engine, batch_size, lambda tag, data: wf.write(data))
-                for item in _prefetch(reader.items(f5.f5_batch_num)):
-                    pipe.feed(item)
-                pipe.flush()
+                try:
+                    for item in _prefetch(reader.items(f5.f5_batch_num)):
+                        pipe.feed(item)
+                    pipe.flush()
+                finally:
+                    pipe.close()
                 wf.flush()
             nsites = pipe.nsites
             reader.close()

@@ -1489,13 +1489,20 @@ static int ds_forward_impl(ds_handle* h, int32_t n, const int32_t* kmer, const f
 // enqueues H2D + forward + D2H on that slot's streams; ds_wait(ticket) blocks until that forward is done and hands
 // the results out. Up to `slots` forwards are in flight, so PCIe copies, the 19-launch LSTM chain of one batch and
 // the host's own work (parsing, formatting) overlap.
-static int ds_submit_impl(ds_handle* h, int32_t n, const int32_t* kmer, const float* means, const float* stds, const float* sanums,
-              const float* signals, int32_t* ticket)
+static int ds_submit_parts_impl(ds_handle* h, int32_t nparts, const int32_t* counts, const int32_t* const* kmer, const float* const* means,
+                                const float* const* stds, const float* const* sanums, const float* const* signals, int32_t* ticket)
 {
     if (!h || !ticket) return DS_ERR_INVALID;
     if (!h->finalized) return fail(h, DS_ERR_INVALID, "weights not loaded");
-    if (n <= 0 || n > h->B) return fail(h, DS_ERR_INVALID, "ds_submit: n must be in [1, max_batch]");
-    if (!kmer || !means || !stds || !sanums || !signals) return fail(h, DS_ERR_INVALID, "null buffer");
+    if (nparts <= 0 || !counts || !kmer || !means || !stds || !sanums || !signals) return fail(h, DS_ERR_INVALID, "null buffer");
+    int64_t n64 = 0;
+    for (int i = 0; i < nparts; ++i) {
+        if (counts[i] < 0) return fail(h, DS_ERR_INVALID, "ds_submit: negative segment length");
+        if (counts[i] > 0 && (!kmer[i] || !means[i] || !stds[i] || !sanums[i] || !signals[i])) return fail(h, DS_ERR_INVALID, "null buffer");
+        n64 += counts[i];
+    }
+    if (n64 <= 0 || n64 > h->B) return fail(h, DS_ERR_INVALID, "ds_submit: n must be in [1, max_batch]");
+    const int n = (int)n64;
     if (h->profiling) return fail(h, DS_ERR_INVALID, "ds_submit is not available while profiling is on");
     HIPCHK(h, hipSetDevice(h->cfg.device));
     const int si = (int)(h->next_slot % h->slots.size());
@@ -1512,8 +1519,17 @@ static int ds_submit_impl(ds_handle* h, int32_t n, const int32_t* kmer, const fl
     h->cur = &sl;
     const size_t nt = (size_t)n * T * 4;
     char* p = sl.pin_in;
-    memcpy(p, kmer, nt); memcpy(p + B * T * 4, means, nt); memcpy(p + 2 * B * T * 4, stds, nt);
-    memcpy(p + 3 * B * T * 4, sanums, nt); memcpy(p + 4 * B * T * 4, signals, (size_t)n * S * 4);
+    size_t row = 0;
+    for (int i = 0; i < nparts; ++i) {
+        const size_t c = (size_t)counts[i];
+        if (!c) continue;
+        memcpy(p + row * T * 4, kmer[i], c * T * 4);
+        memcpy(p + B * T * 4 + row * T * 4, means[i], c * T * 4);
+        memcpy(p + 2 * B * T * 4 + row * T * 4, stds[i], c * T * 4);
+        memcpy(p + 3 * B * T * 4 + row * T * 4, sanums[i], c * T * 4);
+        memcpy(p + 4 * B * T * 4 + row * S * 4, signals[i], c * S * 4);
+        row += c;
+    }
     HIPCHK(h, hipMemcpyAsync(sl.d_kmer, p, nt, hipMemcpyHostToDevice, sl.s0));
     HIPCHK(h, hipMemcpyAsync(sl.d_means, p + B * T * 4, nt, hipMemcpyHostToDevice, sl.s0));
     HIPCHK(h, hipMemcpyAsync(sl.d_stds, p + 2 * B * T * 4, nt, hipMemcpyHostToDevice, sl.s0));
@@ -1526,6 +1542,13 @@ static int ds_submit_impl(ds_handle* h, int32_t n, const int32_t* kmer, const fl
     sl.submitted_n = n;
     *ticket = si;
     return DS_OK;
+}
+
+static int ds_submit_impl(ds_handle* h, int32_t n, const int32_t* kmer, const float* means, const float* stds, const float* sanums,
+              const float* signals, int32_t* ticket)
+{
+    if (h && (!kmer || !means || !stds || !sanums || !signals)) return fail(h, DS_ERR_INVALID, "null buffer");
+    return ds_submit_parts_impl(h, 1, &n, &kmer, &means, &stds, &sanums, &signals, ticket);
 }
 
 static int ds_wait_impl(ds_handle* h, int32_t ticket, float* act, int32_t* pred)
@@ -1789,5 +1812,6 @@ int ds_load_weights(ds_handle* h, const char* path) { return guarded(h, [&] { re
 int ds_forward_device(ds_handle* h, int32_t n, const int32_t* d_kmer, const float* d_means, const float* d_stds, const float* d_sanums, const float* d_signals, float* d_act, int32_t* d_pred) { return guarded(h, [&] { return ds_forward_device_impl(h, n, d_kmer, d_means, d_stds, d_sanums, d_signals, d_act, d_pred); }); }
 int ds_forward(ds_handle* h, int32_t n, const int32_t* kmer, const float* means, const float* stds, const float* sanums, const float* signals, float* act, int32_t* pred) { return guarded(h, [&] { return ds_forward_impl(h, n, kmer, means, stds, sanums, signals, act, pred); }); }
 int ds_submit(ds_handle* h, int32_t n, const int32_t* kmer, const float* means, const float* stds, const float* sanums, const float* signals, int32_t* ticket) { return guarded(h, [&] { return ds_submit_impl(h, n, kmer, means, stds, sanums, signals, ticket); }); }
+int ds_submit_parts(ds_handle* h, int32_t nparts, const int32_t* counts, const int32_t* const* kmer, const float* const* means, const float* const* stds, const float* const* sanums, const float* const* signals, int32_t* ticket) { return guarded(h, [&] { return ds_submit_parts_impl(h, nparts, counts, kmer, means, stds, sanums, signals, ticket); }); }
 int ds_wait(ds_handle* h, int32_t ticket, float* act, int32_t* pred) { return guarded(h, [&] { return ds_wait_impl(h, ticket, act, pred); }); }
 }  // extern "C"

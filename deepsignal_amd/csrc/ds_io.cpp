@@ -17,7 +17,10 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <condition_variable>
 #include <cstring>
+#include <functional>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -27,6 +30,65 @@
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
+
+// A team of parser threads that lives as long as the reader: a queue item is ~1,000 rows (a millisecond of parsing on
+// 16 threads), so starting and joining 16 std::threads per item cost about as much as the parsing itself.
+struct ds_team {
+    std::vector<std::thread> th;
+    std::mutex m;
+    std::condition_variable cv_go, cv_done;
+    const std::function<void()>* job = nullptr;
+    uint64_t gen = 0;
+    int want = 0, running = 0;       // helpers asked to run this generation / still running it
+    bool stop = false;
+    explicit ds_team(int helpers)
+    {
+        for (int i = 0; i < helpers; ++i)
+            th.emplace_back([this, i] {
+                uint64_t seen = 0;
+                for (;;) {
+                    const std::function<void()>* j;
+                    {
+                        std::unique_lock<std::mutex> lk(m);
+                        cv_go.wait(lk, [&] { return stop || (gen != seen && i < want); });
+                        if (stop) return;
+                        seen = gen;
+                        j = job;
+                    }
+                    (*j)();
+                    {
+                        std::lock_guard<std::mutex> lk(m);
+                        if (--running == 0) cv_done.notify_one();
+                    }
+                }
+            });
+    }
+    // run `f` on the caller and on up to `helpers` team threads; returns when all of them are done
+    void run(int helpers, const std::function<void()>& f)
+    {
+        helpers = std::min<int>(helpers, (int)th.size());
+        if (helpers > 0) {
+            std::lock_guard<std::mutex> lk(m);
+            job = &f; want = helpers; running = helpers; ++gen;
+        }
+        if (helpers > 0) cv_go.notify_all();
+        f();
+        if (helpers > 0) {
+            std::unique_lock<std::mutex> lk(m);
+            cv_done.wait(lk, [&] { return running == 0; });
+            want = 0;
+        }
+    }
+    ~ds_team()
+    {
+        {
+            std::lock_guard<std::mutex> lk(m);
+            stop = true;
+        }
+        cv_go.notify_all();
+        for (auto& t : th) t.join();
+    }
+};
 
 struct ds_tsv {
     int fd = -1;
@@ -42,6 +104,7 @@ struct ds_tsv {
     std::vector<char> info;
     std::vector<int64_t> info_off;
     std::vector<std::pair<const char*, const char*>> lines;
+    ds_team* team = nullptr;   // nthreads - 1 helpers, started with the first item that needs them
 };
 
 namespace {
@@ -234,6 +297,7 @@ int ds_tsv_open(const char* path, int32_t kmer_len, int32_t signal_len, int32_t 
 void ds_tsv_close(ds_tsv* t)
 {
     if (!t) return;
+    delete t->team;
     if (t->data) munmap((void*)t->data, t->size);
     if (t->fd >= 0) close(t->fd);
     delete t;
@@ -299,9 +363,9 @@ int64_t ds_tsv_next(ds_tsv* t, int32_t max_reads)
     const int nt = (int)std::min<size_t>((size_t)t->nthreads, (n + 63) / 64);
     if (nt <= 1) work();
     else {
-        std::vector<std::thread> th;
-        for (int i = 0; i < nt; ++i) th.emplace_back(work);
-        for (auto& x : th) x.join();
+        if (!t->team) t->team = new ds_team(t->nthreads - 1);
+        const std::function<void()> f = work;
+        t->team->run(nt - 1, f);
     }
     if (bad.load() >= 0) {
         t->err = "row " + std::to_string(t->line_no + bad.load() + 1) + ": malformed feature row";

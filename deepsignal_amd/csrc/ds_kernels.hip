@@ -2222,12 +2222,22 @@ __global__ __launch_bounds__(256) void head_folded_kernel(const HeadFoldedArgs a
             const float4 raw = x8[k8];
             const unsigned u[4] = {__float_as_uint(raw.x), __float_as_uint(raw.y), __float_as_uint(raw.z), __float_as_uint(raw.w)};
             const float* w = a.w + (size_t)k8 * 8 * C;
+            if (C == 2) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float x0 = __uint_as_float(u[e] << 16), x1 = __uint_as_float(u[e] & 0xffff0000u);
+                for (int e = 0; e < 4; ++e) {
+                    const float x0 = __uint_as_float(u[e] << 16), x1 = __uint_as_float(u[e] & 0xffff0000u);
+                    const float4 wv = *reinterpret_cast<const float4*>(w + 4 * e);      // rows 2e, 2e + 1 of [k][2]
+                    accv[0] = fmaf(x0, wv.x, fmaf(x1, wv.z, accv[0]));
+                    accv[1] = fmaf(x0, wv.y, fmaf(x1, wv.w, accv[1]));
+                }
+            } else {
 #pragma unroll
-                for (int c = 0; c < 16; ++c)
-                    if (c < C) accv[c] += x0 * w[(2 * e) * C + c] + x1 * w[(2 * e + 1) * C + c];
+                for (int e = 0; e < 4; ++e) {
+                    const float x0 = __uint_as_float(u[e] << 16), x1 = __uint_as_float(u[e] & 0xffff0000u);
+#pragma unroll
+                    for (int c = 0; c < 16; ++c)
+                        if (c < C) accv[c] += x0 * w[(2 * e) * C + c] + x1 * w[(2 * e + 1) * C + c];
+                }
             }
         }
     } else

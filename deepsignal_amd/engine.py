@@ -23,7 +23,7 @@ EXPORTED_SYMBOLS = (
     "ds_create", "ds_destroy", "ds_last_error", "ds_version", "ds_load_weights", "ds_set_tensor",
     "ds_finalize_weights", "ds_forward", "ds_forward_device", "ds_sync", "ds_alloc_host", "ds_free_host",
     "ds_get_intermediate", "ds_set_profiling", "ds_num_stages", "ds_get_stage", "ds_reset_stage_times",
-    "ds_set_graph", "ds_num_kernels", "ds_get_kernel_stat", "ds_submit", "ds_wait", "ds_num_slots",
+    "ds_set_graph", "ds_num_kernels", "ds_get_kernel_stat", "ds_submit", "ds_submit_parts", "ds_wait", "ds_num_slots",
     # scope row f1 (host I/O)
     "ds_tsv_open", "ds_tsv_close", "ds_tsv_error", "ds_tsv_next", "ds_tsv_kmer", "ds_tsv_means", "ds_tsv_stds",
     "ds_tsv_lens", "ds_tsv_signals", "ds_tsv_labels", "ds_tsv_info", "ds_tsv_info_offsets", "ds_format_rows",
@@ -101,6 +101,7 @@ def load_library() -> ctypes.CDLL:
     lib.ds_forward_device.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp]
     lib.ds_sync.argtypes = [vp]
     lib.ds_submit.argtypes = [vp, i32, vp, vp, vp, vp, vp, ctypes.POINTER(i32)]
+    lib.ds_submit_parts.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, ctypes.POINTER(i32)]
     lib.ds_wait.argtypes = [vp, i32, vp, vp]
     lib.ds_alloc_host.argtypes = [ctypes.c_size_t, ctypes.POINTER(vp)]
     lib.ds_free_host.argtypes = [vp]
@@ -221,6 +222,19 @@ class Engine:
         t = ctypes.c_int32()
         self._check(self._lib.ds_submit(self._h, n, kmer.ctypes.data, *(a.ctypes.data for a in arrs), ctypes.byref(t)),
                     "ds_submit")
+        return (int(t.value), n)
+
+    def submit_parts(self, parts) -> Tuple[int, int]:
+        """submit() of one batch given as row segments: `parts` is a sequence of (kmer, means, stds, sanums, signals)
+        array tuples; the rows are gathered into the pinned staging buffer by the library (no concatenated copy)."""
+        k = len(parts)
+        keep = [(np.ascontiguousarray(p[0], dtype=np.int32),) + tuple(np.ascontiguousarray(a, dtype=np.float32) for a in p[1:5])
+                for p in parts]
+        counts = (ctypes.c_int32 * k)(*[int(p[0].shape[0]) for p in keep])
+        ptrs = [(ctypes.c_void_p * k)(*[p[j].ctypes.data for p in keep]) for j in range(5)]
+        n = int(sum(counts))
+        t = ctypes.c_int32()
+        self._check(self._lib.ds_submit_parts(self._h, k, counts, *ptrs, ctypes.byref(t)), "ds_submit_parts")
         return (int(t.value), n)
 
     def wait(self, ticket: Tuple[int, int]) -> Tuple[np.ndarray, np.ndarray]:

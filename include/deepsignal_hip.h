@@ -123,6 +123,13 @@ int ds_sync(ds_handle *h);
 int ds_submit(ds_handle *h, int32_t n, const int32_t *kmer, const float *means, const float *stds,
               const float *sanums, const float *signals, int32_t *ticket);
 int ds_wait(ds_handle *h, int32_t ticket, float *act, int32_t *pred);
+/* ds_submit with the batch given as `nparts` row segments (counts[i] rows from the i-th pointer of each array): the
+ * rows are gathered straight into the slot's pinned staging buffer, sum(counts) in [1, max_batch]. For callers whose
+ * batches straddle their own buffers — call_mods fills a batch from the tail of one queue item and the head of the
+ * next (call_modifications.py:157-166 cuts batches inside one item) — so that they need no concatenated copy. */
+int ds_submit_parts(ds_handle *h, int32_t nparts, const int32_t *counts, const int32_t *const *kmer,
+                    const float *const *means, const float *const *stds, const float *const *sanums,
+                    const float *const *signals, int32_t *ticket);
 /* Forwards that may be in flight at once (pipeline slots of this handle). */
 int ds_num_slots(ds_handle *h);
 

@@ -253,6 +253,13 @@ def test_submit_wait_matches_run(small_weights):
     assert np.array_equal(np.concatenate(got_act), ref_act) and np.array_equal(np.concatenate(got_pred), ref_pred)
     with pytest.raises(RuntimeError):          # nothing in flight any more
         eng.wait((0, 8))
+    # ds_submit_parts: the same batch as ragged row segments (empty ones included) gives the same bits
+    cuts = [0, 1, 1, 40, 77, 96]
+    parts = [tuple(feats[k][s:e] for k in keys) for s, e in zip(cuts[:-1], cuts[1:])]
+    a, p = eng.wait(eng.submit_parts(parts))
+    assert np.array_equal(a, ref_act[:96]) and np.array_equal(p, ref_pred[:96])
+    with pytest.raises(RuntimeError):          # more rows than max_batch
+        eng.submit_parts(parts + parts)
     eng.close()
 
 

@@ -150,6 +150,8 @@ def test_row_pipeline_fills_batches_across_items_with_identical_bits(small_weigh
     for tag, it in enumerate(items):
         pipe.feed(it, tag)
     pipe.flush()
+    assert not pipe.live_tags()
+    pipe.close()
     eng.close()
     assert pipe.nsites == n and [t for t, _ in got] == sorted(t for t, _ in got)
     rows = b"".join(d for _, d in got).decode().splitlines()

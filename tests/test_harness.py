@@ -196,3 +196,100 @@ def test_cli_builds_the_references_f5_args(monkeypatch):
     f5 = cm._unpack_f5_args(seen["args"][13])
     assert (f5.f5_batch_num, f5.reference_path, f5.position_file, f5.normalize_method, f5.methy_label) == \
         (9, "ref.fa", "p.txt", "zscore", 1)
+
+
+class _AsyncStandIn:
+    """CPU stand-in with the engine's asynchronous boundary (submit / submit_parts / wait, `slots` in flight): outputs
+    are a deterministic function of each site's own inputs, computed at wait() time."""
+    class_num, max_batch, slots = 2, 64, 3
+
+    def __init__(self):
+        self.pending, self.next, self.parts_calls, self.batches = {}, 0, 0, []
+
+    @staticmethod
+    def _f(means, signals):
+        p1 = (1.0 / (1.0 + np.exp(-(means.sum(axis=1) + signals[:, :7].sum(axis=1))))).astype(np.float32)
+        act = np.stack([1.0 - p1, p1], axis=1).astype(np.float32)
+        return act, np.argmax(act, axis=1).astype(np.int32)
+
+    def run(self, kmer, means, stds, sanums, signals):
+        return self._f(np.asarray(means, np.float32), np.asarray(signals, np.float32))
+
+    def submit(self, kmer, means, stds, sanums, signals):
+        assert len(self.pending) < self.slots, "more batches in flight than slots"
+        t = self.next; self.next += 1
+        self.pending[t] = (np.array(means, np.float32), np.array(signals, np.float32))
+        self.batches.append(len(kmer))
+        return (t, len(kmer))
+
+    def submit_parts(self, parts):
+        self.parts_calls += 1
+        return self.submit(*(np.concatenate([p[j] for p in parts]) for j in range(5)))
+
+    def wait(self, ticket):
+        assert ticket[0] == min(self.pending), "tickets must be waited in submission order"
+        means, signals = self.pending.pop(ticket[0])
+        return self._f(means, signals)
+
+
+def _items_for_pipeline(n, cuts):
+    from deepsignal_amd import fastio, synth
+    feats = synth.synthetic_features(n, seed=17)
+    items = []
+    for s0, e0 in zip(cuts[:-1], cuts[1:]):
+        m = e0 - s0
+        info = np.frombuffer(("r%04d" * m % tuple(range(s0, e0))).encode(), np.uint8).copy()
+        items.append(fastio.FeatureItem(info, np.arange(m + 1, dtype=np.int64) * 5, feats["kmer"][s0:e0], feats["means"][s0:e0],
+                                        feats["stds"][s0:e0], feats["sanums"][s0:e0], feats["signals"][s0:e0],
+                                        np.zeros(m, np.int32)))
+    return feats, items
+
+
+def test_row_pipeline_threads_keep_file_order_and_fill_batches_across_items():
+    """call_mods' row pipeline on a CPU stand-in: batches are filled across queue items (segments handed over with
+    submit_parts, no more than `slots` in flight, tickets waited in order), a helper thread formats and sinks the rows,
+    and the text is what the blocking per-item path writes."""
+    if not os.path.exists(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "deepsignal_amd",
+                                       "libdeepsignal_hip.so")):
+        pytest.skip("native library not built (row formatter)")
+    n, cuts = 333, [0, 5, 70, 71, 200, 333]
+    feats, items = _items_for_pipeline(n, cuts)
+    eng = _AsyncStandIn()
+    got = []
+    pipe = cm._RowPipeline(eng, 64, lambda tag, data: got.append((tag, data)))
+    assert pipe.pipelined
+    for tag, it in enumerate(items):
+        pipe.feed(it, tag)
+        assert pipe.live_tags() <= set(range(tag + 1))
+    pipe.flush()
+    assert not pipe.live_tags() and not eng.pending
+    pipe.close()
+    assert eng.batches == [64] * 5 + [13] and eng.parts_calls >= 3          # full batches; straddling ones as segments
+    assert [t for t, _ in got] == sorted(t for t, _ in got)
+    # the same items through the blocking path (an engine without submit / wait)
+    class Blocking:
+        class_num = 2
+        run = staticmethod(lambda *a: _AsyncStandIn._f(np.asarray(a[1], np.float32), np.asarray(a[4], np.float32)))
+    ref = []
+    pipe2 = cm._RowPipeline(Blocking(), 64, lambda tag, data: ref.append(data))
+    assert not pipe2.pipelined
+    for tag, it in enumerate(items):
+        pipe2.feed(it, tag)
+    pipe2.flush(); pipe2.close()
+    assert b"".join(d for _, d in got) == b"".join(ref) and b"".join(ref).count(b"\n") == n
+
+
+def test_row_pipeline_surfaces_a_failing_sink():
+    if not os.path.exists(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "deepsignal_amd",
+                                       "libdeepsignal_hip.so")):
+        pytest.skip("native library not built (row formatter)")
+    feats, items = _items_for_pipeline(200, [0, 100, 200])
+
+    def sink(tag, data):
+        raise IOError("disk full")
+    pipe = cm._RowPipeline(_AsyncStandIn(), 64, sink)
+    with pytest.raises(IOError):
+        for tag, it in enumerate(items):
+            pipe.feed(it, tag)
+        pipe.flush()
+    pipe.close()
