@@ -1115,6 +1115,17 @@ hipError_t launch_lstm_cells(int nt, const LstmLaunch& L, hipStream_t s)
 #ifndef DS_FUSED_WPS
 #define DS_FUSED_WPS 2
 #endif
+// Register stages of the fused module's P1 operand prefetch (weight fragments / input rows): 2 = one chunk ahead. Deeper
+// rings were measured (3, 4 stages each): the same P1 time -- the operands are not late -- and more registers. The
+// register count matters beyond spills: at 183 VGPRs two module waves leave room for one BiLSTM cell wave (136) on the
+// same SIMD, and a cell workgroup's 48 KB of LDS fits next to the module's 105 - 111 KB, so cell workgroups run in the
+// shadow of module workgroups (512-site bench 527 k -> 540 k sites/s; 532 k at 188, 529 k at 196 VGPRs).
+#ifndef DS_FUSED_BD
+#define DS_FUSED_BD 2
+#endif
+#ifndef DS_FUSED_VD
+#define DS_FUSED_VD 2
+#endif
 constexpr int F_LDA = KC + 4;   // staged chunk row stride (floats)
 constexpr int F_LD1 = 100;      // T1 row stride: 96 channels + 4 pad (25 x 16 B: odd -> conflict-free b128)
 constexpr int F_LD2 = 68;       // T2 row stride: 64 channels + 4 pad
@@ -1252,31 +1263,36 @@ __global__ __launch_bounds__(512, DS_FUSED_WPS) void inception_fused_kernel(cons
 
     const int nchunks = cin / KC;      // >= 15
 
-    // P1 main loop: same software pipeline as gemm_kernel (fragments of chunk c+1 are read into
-    // registers behind the second half of chunk c's MFMAs; one barrier per chunk).
+    // P1 main loop: one barrier per 16-channel chunk; fragments of chunk c+1 are read into registers behind the second
+    // half of chunk c's MFMAs; input rows and weight fragments are requested DS_FUSED_VD - 1 / DS_FUSED_BD - 1 chunks
+    // ahead. Fully unrolled over the 15 or 16 chunks, so every register-ring and LDS-buffer index is a literal (183
+    // instead of 247 VGPRs: see DS_FUSED_BD above).
+    __builtin_assume(nchunks >= 15 && nchunks <= 16);
     auto run_p1 = [&](auto pool_tag) {
         constexpr bool POOL = decltype(pool_tag)::value;
-        float4 vc[2];
-        float4 bq[2][2];
+        constexpr int VD = DS_FUSED_VD;
+        float4 vc[VD];
+        constexpr int BD = DS_FUSED_BD;                  // register stages of the weight fragments (chunk c's are requested BD - 1 steps ahead)
+        float4 bq[BD][2];
         float4 af[2][2][TM];
-        auto load_a = [&](int X) {
+        auto load_a = [&](int V) __attribute__((always_inline)) {
             if (stager) {
-                vc[X] = gload4(pc); pc += KC;
+                vc[V] = gload4(pc); pc += KC;
                 if (pooled_in) {       // wave-uniform per launch
-                    vc[X] = f4max(f4max(vc[X], gload4(pq)), gload4(pr));
+                    vc[V] = f4max(f4max(vc[V], gload4(pq)), gload4(pr));
                     pq += KC; pr += KC;
                 }
             }
         };
-        auto store_a = [&](int X) {
-            if (stager) *reinterpret_cast<float4*>(Ad + X * TR32 * F_LDA + sr * F_LDA + sq * 4) = vc[X];
+        auto store_a = [&](int X, int V) __attribute__((always_inline)) {
+            if (stager) *reinterpret_cast<float4*>(Ad + X * TR32 * F_LDA + sr * F_LDA + sq * 4) = vc[V];
         };
-        auto load_b = [&](int X) {
-            bq[X][0] = gload4(bp);
-            bq[X][1] = gload4(bp + 256);
+        auto load_b = [&](int Bi) __attribute__((always_inline)) {
+            bq[Bi][0] = gload4(bp);
+            bq[Bi][1] = gload4(bp + 256);
             bp += 512;
         };
-        auto read_frags = [&](int X) {
+        auto read_frags = [&](int X) __attribute__((always_inline)) {
 #pragma unroll
             for (int rs = 0; rs < 2; ++rs)
 #pragma unroll
@@ -1287,53 +1303,41 @@ __global__ __launch_bounds__(512, DS_FUSED_WPS) void inception_fused_kernel(cons
                     af[X][rs][mt] = v;
                 }
         };
-        auto mfma_rs = [&](int X, int rs) {
+        auto mfma_rs = [&](int X, int Bi, int rs) __attribute__((always_inline)) {
 #pragma unroll
             for (int mt = 0; mt < TM; ++mt) {
-                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(bq[X][rs].x, af[X][rs][mt].x, acc[mt], 0, 0, 0);
-                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(bq[X][rs].y, af[X][rs][mt].y, acc[mt], 0, 0, 0);
-                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(bq[X][rs].z, af[X][rs][mt].z, acc[mt], 0, 0, 0);
-                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(bq[X][rs].w, af[X][rs][mt].w, acc[mt], 0, 0, 0);
+                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(bq[Bi][rs].x, af[X][rs][mt].x, acc[mt], 0, 0, 0);
+                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(bq[Bi][rs].y, af[X][rs][mt].y, acc[mt], 0, 0, 0);
+                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(bq[Bi][rs].z, af[X][rs][mt].z, acc[mt], 0, 0, 0);
+                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(bq[Bi][rs].w, af[X][rs][mt].w, acc[mt], 0, 0, 0);
             }
         };
-#define DS_FSTEP(X, HAS1, HAS2)                                   \
-    do {                                                          \
-        if (HAS2) load_a(X);                                      \
-        if (HAS1) load_b((X) ^ 1);                                \
-        if (HAS1) store_a((X) ^ 1);                               \
-        mfma_rs(X, 0);                                            \
-        __builtin_amdgcn_sched_barrier(0);                        \
-        __syncthreads();                                          \
-        if (HAS1) read_frags((X) ^ 1);                            \
-        mfma_rs(X, 1);                                            \
-        __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);          \
-        if (HAS1) __builtin_amdgcn_sched_group_barrier(0x100, (POOL ? 6 : 2) * TM, 0); \
-        __builtin_amdgcn_sched_group_barrier(0x8, 4 * TM, 0);     \
-        __builtin_amdgcn_sched_barrier(0);                        \
-    } while (0)
-        load_a(0);
-        load_b(0);
-        store_a(0);
-        load_a(1);
+#pragma unroll
+        for (int i = 0; i < VD; ++i) load_a(i);                  // chunks 0 .. VD - 1 (nchunks >= 15)
+#pragma unroll
+        for (int i = 0; i < BD - 1; ++i) load_b(i);              // weight fragments of chunks 0 .. BD - 2
+        store_a(0, 0);
         __syncthreads();
         read_frags(0);
-        int c = 0;
-        while (c + 3 < nchunks) {
-            DS_FSTEP(0, true, true);
-            DS_FSTEP(1, true, true);
-            c += 2;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            if (c < nchunks) {                                    // wave-uniform; only c = 15 is really conditional
+                const int X = c & 1;
+                const bool has1 = c + 1 < nchunks;
+                if (c + VD < nchunks) load_a(c % VD);             // chunk c + VD into the stage chunk c left (written at step c - 1)
+                if (c + BD - 1 < nchunks) load_b((c + BD - 1) % BD);
+                if (has1) store_a(X ^ 1, (c + 1) % VD);
+                mfma_rs(X, c % BD, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                __syncthreads();
+                if (has1) read_frags(X ^ 1);
+                mfma_rs(X, c % BD, 1);
+                __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+                if (has1) __builtin_amdgcn_sched_group_barrier(0x100, (POOL ? 6 : 2) * TM, 0);
+                __builtin_amdgcn_sched_group_barrier(0x8, 4 * TM, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
-        if (nchunks - c == 3) {
-            DS_FSTEP(0, true, true);
-            DS_FSTEP(1, true, false);
-            DS_FSTEP(0, false, false);
-        } else if (nchunks - c == 2) {
-            DS_FSTEP(0, true, false);
-            DS_FSTEP(1, false, false);
-        } else {
-            DS_FSTEP(0, false, false);
-        }
-#undef DS_FSTEP
     };
     if (wave >= 6) run_p1(FusedTagT{}); else run_p1(FusedTagF{});     // wave-uniform
     DS_STAMP(1);
@@ -1495,6 +1499,7 @@ __global__ __launch_bounds__(512, DS_FUSED_WPS) void inception_fused_kernel(cons
 hipError_t launch_inception_fused(int tm, const FusedArgs& a, hipStream_t s)
 {
     if (a.n_sites <= 0) return hipSuccess;
+    if (a.cin != 240 && a.cin != 256) return hipErrorInvalidValue;      // P1 is unrolled over 15 or 16 chunks (every module of the model)
     const size_t lds = inception_fused_lds_bytes(tm, a.W, a.spt);
     const int grid = (a.n_sites + a.spt - 1) / a.spt;
     switch (tm) {
