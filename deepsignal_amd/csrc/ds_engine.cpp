@@ -116,6 +116,7 @@ struct Plan {
 struct Slot {
     hipStream_t s0 = nullptr, s1 = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    float* d_in = nullptr;               // [kmer | means | stds | sanums | signals] (the five pointers below point into it)
     int* d_kmer = nullptr;
     float *d_means = nullptr, *d_stds = nullptr, *d_sanums = nullptr, *d_signals = nullptr;
     float *stem_pool = nullptr, *conv2o = nullptr, *conv3o = nullptr;
@@ -518,8 +519,14 @@ int alloc_workspace(ds_handle* h)
     const size_t B = h->B;
     int rc = 0;
     auto A = [&](auto** p, size_t count) { if (!rc) rc = dalloc(h, p, count); };
-    A(&h->cur->d_kmer, B * h->T); A(&h->cur->d_means, B * h->T); A(&h->cur->d_stds, B * h->T); A(&h->cur->d_sanums, B * h->T);
-    A(&h->cur->d_signals, B * h->S);
+    // inputs of a forward: ONE block [kmer | means | stds | sanums | signals], every region sized for max_batch -- the image
+    // of the pinned staging buffer of ds_submit, so a full batch arrives with one H2D copy
+    A(&h->cur->d_in, B * (4 * h->T + h->S));
+    if (!rc) {
+        h->cur->d_kmer = reinterpret_cast<int*>(h->cur->d_in);
+        h->cur->d_means = h->cur->d_in + B * h->T; h->cur->d_stds = h->cur->d_in + 2 * B * h->T;
+        h->cur->d_sanums = h->cur->d_in + 3 * B * h->T; h->cur->d_signals = h->cur->d_in + 4 * B * h->T;
+    }
     A(&h->cur->stem_pool, B * h->wa * 64); A(&h->cur->conv2o, B * h->wa * 128); A(&h->cur->conv3o, B * h->wa * 256);
     A(&h->cur->pool2, B * h->wb * INC_OUT); A(&h->cur->pool3, B * h->wc * INC_OUT);
     A(&h->cur->tmpA, B * h->wa * 96); A(&h->cur->tmpS, B * h->wa * 48); A(&h->cur->tmpB, B * h->wa * 64);
@@ -528,7 +535,9 @@ int alloc_workspace(ds_handle* h)
         for (int l = 0; l < NLAYER; ++l) { A(&h->cur->H[d][l], (size_t)h->T * h->Bp32 * HID); A(&h->cur->Cst[d][l], (size_t)h->Bp32 * HID); }
     if (h->lstm_frag)
         for (int d = 0; d < 2; ++d) A(&h->cur->hlast[d], B * HID);
-    A(&h->cur->fc1o, B * h->J); A(&h->cur->logits, B * h->C); A(&h->cur->act, B * h->C); A(&h->cur->pred, B);
+    A(&h->cur->fc1o, B * h->J); A(&h->cur->logits, B * h->C);
+    A(&h->cur->act, B * h->C + B);            // [act | pred]: one block, one D2H copy
+    if (!rc) h->cur->pred = reinterpret_cast<int*>(h->cur->act + B * h->C);
     if (h->bf16) A(&h->cur->joint, B * (size_t)h->JP / 2);
     // module outputs: ping-pong pair normally; one buffer per module in debug mode (for taps)
     const int nbuf = h->debug ? NMOD : 2;
@@ -1310,8 +1319,7 @@ void ds_destroy(ds_handle* h)
             for (Op& op : kv.second.ops) { if (op.ev0) hipEventDestroy(op.ev0); if (op.ev1) hipEventDestroy(op.ev1); }
         }
         if (sl.pin_in) hipHostFree(sl.pin_in);
-        if (sl.pin_act) hipHostFree(sl.pin_act);
-        if (sl.pin_pred) hipHostFree(sl.pin_pred);
+        if (sl.pin_act) hipHostFree(sl.pin_act);       // pin_pred points into it
         if (sl.ev_fork) hipEventDestroy(sl.ev_fork);
         if (sl.ev_join) hipEventDestroy(sl.ev_join);
         if (sl.s0) hipStreamDestroy(sl.s0);
@@ -1395,16 +1403,11 @@ static int ds_forward_device_impl(ds_handle* h, int32_t n, const int32_t* d_kmer
     HIPCHK(h, hipSetDevice(h->cfg.device));
     // next pipeline slot (profiling runs stay on slot 0 so the event statistics are coherent)
     h->cur = &h->slots[h->profiling ? 0 : (h->next_slot++ % h->slots.size())];
-    const size_t nt = (size_t)n * h->T;
-    HIPCHK(h, hipMemcpyAsync(h->cur->d_kmer, d_kmer, nt * 4, hipMemcpyDeviceToDevice, h->cur->s0));
-    HIPCHK(h, hipMemcpyAsync(h->cur->d_means, d_means, nt * 4, hipMemcpyDeviceToDevice, h->cur->s0));
-    HIPCHK(h, hipMemcpyAsync(h->cur->d_stds, d_stds, nt * 4, hipMemcpyDeviceToDevice, h->cur->s0));
-    HIPCHK(h, hipMemcpyAsync(h->cur->d_sanums, d_sanums, nt * 4, hipMemcpyDeviceToDevice, h->cur->s0));
-    HIPCHK(h, hipMemcpyAsync(h->cur->d_signals, d_signals, (size_t)n * h->S * 4, hipMemcpyDeviceToDevice, h->cur->s0));
+    // one gather launch in, one scatter launch out (seven copy dispatches per forward before)
+    HIPCHK(h, launch_gather_inputs(d_kmer, d_means, d_stds, d_sanums, d_signals, h->cur->d_in, n, h->T, h->S, h->B, h->cur->s0));
     int rc = run_resident(h, n);
     if (rc) return rc;
-    HIPCHK(h, hipMemcpyAsync(d_act, h->cur->act, (size_t)n * h->C * 4, hipMemcpyDeviceToDevice, h->cur->s0));
-    HIPCHK(h, hipMemcpyAsync(d_pred, h->cur->pred, (size_t)n * 4, hipMemcpyDeviceToDevice, h->cur->s0));
+    HIPCHK(h, launch_scatter_outputs(h->cur->act, h->cur->pred, d_act, d_pred, n, h->C, h->cur->s0));
     return DS_OK;
 }
 
@@ -1512,8 +1515,8 @@ static int ds_submit_parts_impl(ds_handle* h, int32_t nparts, const int32_t* cou
     const size_t in_bytes = B * (4 * T * 4 + S * 4);
     if (!sl.pin_in) {
         HIPCHK(h, hipHostMalloc((void**)&sl.pin_in, in_bytes, hipHostMallocDefault));
-        HIPCHK(h, hipHostMalloc((void**)&sl.pin_act, B * h->C * 4, hipHostMallocDefault));
-        HIPCHK(h, hipHostMalloc((void**)&sl.pin_pred, B * 4, hipHostMallocDefault));
+        HIPCHK(h, hipHostMalloc((void**)&sl.pin_act, (B * h->C + B) * 4, hipHostMallocDefault));      // [act | pred]
+        sl.pin_pred = reinterpret_cast<int*>(sl.pin_act + B * h->C);
     }
     h->next_slot++;
     h->cur = &sl;
@@ -1530,15 +1533,19 @@ static int ds_submit_parts_impl(ds_handle* h, int32_t nparts, const int32_t* cou
         memcpy(p + 4 * B * T * 4 + row * S * 4, signals[i], c * S * 4);
         row += c;
     }
-    HIPCHK(h, hipMemcpyAsync(sl.d_kmer, p, nt, hipMemcpyHostToDevice, sl.s0));
-    HIPCHK(h, hipMemcpyAsync(sl.d_means, p + B * T * 4, nt, hipMemcpyHostToDevice, sl.s0));
-    HIPCHK(h, hipMemcpyAsync(sl.d_stds, p + 2 * B * T * 4, nt, hipMemcpyHostToDevice, sl.s0));
-    HIPCHK(h, hipMemcpyAsync(sl.d_sanums, p + 3 * B * T * 4, nt, hipMemcpyHostToDevice, sl.s0));
-    HIPCHK(h, hipMemcpyAsync(sl.d_signals, p + 4 * B * T * 4, (size_t)n * S * 4, hipMemcpyHostToDevice, sl.s0));
+    if ((size_t)n == B) {        // the staging buffer is the image of the device block: one copy
+        HIPCHK(h, hipMemcpyAsync(sl.d_in, p, in_bytes, hipMemcpyHostToDevice, sl.s0));
+    } else {
+        HIPCHK(h, hipMemcpyAsync(sl.d_kmer, p, nt, hipMemcpyHostToDevice, sl.s0));
+        HIPCHK(h, hipMemcpyAsync(sl.d_means, p + B * T * 4, nt, hipMemcpyHostToDevice, sl.s0));
+        HIPCHK(h, hipMemcpyAsync(sl.d_stds, p + 2 * B * T * 4, nt, hipMemcpyHostToDevice, sl.s0));
+        HIPCHK(h, hipMemcpyAsync(sl.d_sanums, p + 3 * B * T * 4, nt, hipMemcpyHostToDevice, sl.s0));
+        HIPCHK(h, hipMemcpyAsync(sl.d_signals, p + 4 * B * T * 4, (size_t)n * S * 4, hipMemcpyHostToDevice, sl.s0));
+    }
     int rc = run_resident(h, n);
     if (rc) return rc;
-    HIPCHK(h, hipMemcpyAsync(sl.pin_act, sl.act, (size_t)n * h->C * 4, hipMemcpyDeviceToHost, sl.s0));
-    HIPCHK(h, hipMemcpyAsync(sl.pin_pred, sl.pred, (size_t)n * 4, hipMemcpyDeviceToHost, sl.s0));
+    // [act (max_batch rows) | pred]: one copy back
+    HIPCHK(h, hipMemcpyAsync(sl.pin_act, sl.act, (B * h->C + (size_t)n) * 4, hipMemcpyDeviceToHost, sl.s0));
     sl.submitted_n = n;
     *ticket = si;
     return DS_OK;

@@ -183,6 +183,11 @@ struct HeadFoldedArgs {
     int n, C;
 };
 hipError_t launch_head_folded(const HeadFoldedArgs& a, hipStream_t s);
+// the caller's device arrays -> the slot's contiguous input block [kmer | means | stds | lens | signals] (regions sized for
+// max_batch B), and the slot's act / pred -> the caller's buffers
+hipError_t launch_gather_inputs(const int* kmer, const float* means, const float* stds, const float* lens, const float* signals,
+                                float* block, int n, int T, int S, int B, hipStream_t s);
+hipError_t launch_scatter_outputs(const float* act, const int* pred, float* act_out, int* pred_out, int n, int C, hipStream_t s);
 // table[v][c] = sum_e emb[v][e] * kernel[e][c]  (embedding folded into layer-0 W_x; model.py:61-69)
 hipError_t launch_embed_table(const float* emb, const float* kernel, float* table, int vocab, int esize, int ncol, hipStream_t s);
 

@@ -2295,6 +2295,52 @@ hipError_t launch_head_folded(const HeadFoldedArgs& a, hipStream_t s)
     return hipGetLastError();
 }
 
+// ds_forward_device: the caller's five device arrays into the slot's contiguous input block and the slot's outputs
+// back to the caller -- ONE small launch each way instead of five + two copy dispatches per forward (the captured graph
+// reads and writes the slot's own buffers).
+__global__ __launch_bounds__(256) void gather_inputs_kernel(const int* __restrict__ kmer, const float* __restrict__ means,
+                                                            const float* __restrict__ stds, const float* __restrict__ lens,
+                                                            const float* __restrict__ signals, float* __restrict__ block,
+                                                            int n, int T, int S, int B)
+{
+    const long nt = (long)n * T, ns = (long)n * S, total = 4 * nt + ns;
+    const long bt = (long)B * T;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        if (i < nt) reinterpret_cast<int*>(block)[i] = kmer[i];
+        else if (i < 2 * nt) block[bt + (i - nt)] = means[i - nt];
+        else if (i < 3 * nt) block[2 * bt + (i - 2 * nt)] = stds[i - 2 * nt];
+        else if (i < 4 * nt) block[3 * bt + (i - 3 * nt)] = lens[i - 3 * nt];
+        else block[4 * bt + (i - 4 * nt)] = signals[i - 4 * nt];
+    }
+}
+
+__global__ __launch_bounds__(256) void scatter_outputs_kernel(const float* __restrict__ act, const int* __restrict__ pred,
+                                                              float* __restrict__ act_out, int* __restrict__ pred_out, int n, int C)
+{
+    const int total = n * C + n;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        if (i < n * C) act_out[i] = act[i];
+        else pred_out[i - n * C] = pred[i - n * C];
+    }
+}
+
+hipError_t launch_gather_inputs(const int* kmer, const float* means, const float* stds, const float* lens, const float* signals,
+                                float* block, int n, int T, int S, int B, hipStream_t s)
+{
+    if (n <= 0) return hipSuccess;
+    const long total = (long)n * (4 * T + S);
+    const int grid = (int)std::min<long>((total + 1023) / 1024, 1024);
+    hipLaunchKernelGGL(gather_inputs_kernel, dim3(grid), dim3(256), 0, s, kmer, means, stds, lens, signals, block, n, T, S, B);
+    return hipGetLastError();
+}
+
+hipError_t launch_scatter_outputs(const float* act, const int* pred, float* act_out, int* pred_out, int n, int C, hipStream_t s)
+{
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(scatter_outputs_kernel, dim3((n * (C + 1) + 255) / 256), dim3(256), 0, s, act, pred, act_out, pred_out, n, C);
+    return hipGetLastError();
+}
+
 // ---- bf16-mode elementwise kernels: 8 channels (16 B) per thread ----
 __global__ __launch_bounds__(256) void maxpool_s2_bf16_kernel(const float4* __restrict__ in, float4* __restrict__ out,
                                                                long total, int win, int wout, int pad_l, int ch8)
