@@ -910,8 +910,8 @@ __global__ __launch_bounds__(256, NT == 1 ? 4 : 2) void lstm_cell_kernel(const L
 // (mi, nj) = (wave & 1, wave >> 1) take m-tile mi and the NT n-tiles of column group nj, so every activation
 // fragment feeds two waves and every weight fragment two waves -- half the global traffic per MFMA. Fragments are
 // 1 KiB images in global memory already, so they go global -> LDS by LDS-DMA (no VGPR round trip): a ring of three
-// stages of four k-groups, requests two stages ahead, ONE barrier per stage (16 * NT MFMAs per wave), a counted vmcnt
-// in front of it so the next stage's requests stay in flight across the barrier.
+// stages of KGS k-groups (1 at NT = 1, 2 at NT = 2), requests two stages ahead, ONE barrier per stage, a counted vmcnt in
+// front of it so the next stage's requests stay in flight across the barrier.
 // LDS-DMA of one 1 KiB wave fragment: lane i's 16 bytes at gsrc land at LDS byte address lds_dst + 16 i (lds_dst is
 // wave-uniform and goes through M0). Written as inline asm on purpose: with the builtin, hipcc (ROCm 7.2) tracks the
 // transfer as an LDS store and puts `s_waitcnt vmcnt(0)` in front of the next ds_read, which would drain the
@@ -939,14 +939,19 @@ __device__ __forceinline__ void glds16s(const void* gbase, unsigned lane_off, un
 template <int I> struct LdsSlot { static constexpr int value = I; };
 
 template <int NT>
-__global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void lstm_cell_lds_kernel(const LstmLaunch L_)
+__global__ __launch_bounds__(256, NT == 1 ? 5 : 2) void lstm_cell_lds_kernel(const LstmLaunch L_)
 {
     const LstmLaunch* const Lp = &L_;      // by-value kernel argument (see lstm_cell_kernel)
     constexpr int FR = 2 + 2 * NT;            // fragments per k-group: 2 m-tiles of h, 2 * NT n-tiles of weights
-    constexpr int KGS = 4;                    // k-groups per stage
-    constexpr int LPS = FR;                   // DMA requests per wave and stage (KGS * FR over 4 waves)
+    constexpr int KGS = NT == 1 ? 1 : 2;      // k-groups per stage (KGS * FR fragments, a multiple of the four waves)
+    constexpr int LPS = KGS * FR / 4;         // DMA requests per wave and stage
     constexpr int STAGE = KGS * FR * 256;     // floats
-    __shared__ __attribute__((aligned(16))) float ring[3 * STAGE];
+    // Dynamic on purpose: with a static array hipcc derives the register budget from the LDS-limited occupancy and ignores
+    // __launch_bounds__. Footprint per workgroup (NT = 1): 12 KB of LDS and 88 VGPRs per wave -- up to five workgroups per
+    // CU, and one of them fits next to a fused-module workgroup (2 x 184 + 88 VGPRs per SIMD, 105 + 12 KB). Measured at 512
+    // sites per forward (ring = 3 stages of KGS k-groups): KGS 4 / 136 VGPRs 545 k sites/s, KGS 2 / 88 VGPRs 554 k,
+    // KGS 1 / 88 VGPRs 561 k (one barrier per four MFMAs of a wave, but more waves per SIMD to hide it).
+    extern __shared__ __attribute__((aligned(16))) float ring[];      // [3 * STAGE]
 
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int mi = wave & 1, nj = wave >> 1;
@@ -1092,8 +1097,8 @@ hipError_t launch_lstm_cells(int nt, const LstmLaunch& L, hipStream_t s)
     if (ncell <= 0 || mtiles <= 0) return hipSuccess;
     const int mblocks = (mtiles + 3) / 4, mblocks2 = (mtiles + 1) / 2;
     switch (nt) {
-    case 101: hipLaunchKernelGGL(lstm_cell_lds_kernel<1>, dim3(ncell * mblocks2 * 16), dim3(256), 0, s, L); break;
-    case 102: hipLaunchKernelGGL(lstm_cell_lds_kernel<2>, dim3(ncell * mblocks2 * 8), dim3(256), 0, s, L); break;
+    case 101: hipLaunchKernelGGL(lstm_cell_lds_kernel<1>, dim3(ncell * mblocks2 * 16), dim3(256), 3 * 1 * 4 * 1024, s, L); break;      // 3 stages x KGS x FR KiB
+    case 102: hipLaunchKernelGGL(lstm_cell_lds_kernel<2>, dim3(ncell * mblocks2 * 8), dim3(256), 3 * 2 * 6 * 1024, s, L); break;
     case 1: hipLaunchKernelGGL(lstm_cell_kernel<1>, dim3(ncell * mblocks * 32), dim3(256), 0, s, L); break;
     case 2: hipLaunchKernelGGL(lstm_cell_kernel<2>, dim3(ncell * mblocks * 16), dim3(256), 0, s, L); break;
     case 4: hipLaunchKernelGGL(lstm_cell_kernel<4>, dim3(ncell * mblocks * 8), dim3(256), 0, s, L); break;
