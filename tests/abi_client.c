@@ -69,8 +69,19 @@ int main(int argc, char **argv)
                 CHECK(ds_wait(h, tickets[tail % 8], act2 + (size_t)off_wait * C, pred2 + off_wait));
                 off_wait += mw; ++tail;
             }
-            CHECK(ds_submit(h, m, kmer + (size_t)off * T, means + (size_t)off * T, stds + (size_t)off * T,
-                            sanums + (size_t)off * T, signals + (size_t)off * S, &tickets[head % 8]));
+            if ((head & 1) && m >= 3) {       /* every other batch as three row segments through ds_submit_parts: same bits */
+                const int32_t cnt[3] = {1, m / 2, m - 1 - m / 2};
+                const int32_t o1 = off + 1, o2 = off + 1 + m / 2;
+                const int32_t* pk[3] = {kmer + (size_t)off * T, kmer + (size_t)o1 * T, kmer + (size_t)o2 * T};
+                const float* pm[3] = {means + (size_t)off * T, means + (size_t)o1 * T, means + (size_t)o2 * T};
+                const float* ps[3] = {stds + (size_t)off * T, stds + (size_t)o1 * T, stds + (size_t)o2 * T};
+                const float* pl[3] = {sanums + (size_t)off * T, sanums + (size_t)o1 * T, sanums + (size_t)o2 * T};
+                const float* pg[3] = {signals + (size_t)off * S, signals + (size_t)o1 * S, signals + (size_t)o2 * S};
+                CHECK(ds_submit_parts(h, 3, cnt, pk, pm, ps, pl, pg, &tickets[head % 8]));
+            } else {
+                CHECK(ds_submit(h, m, kmer + (size_t)off * T, means + (size_t)off * T, stds + (size_t)off * T,
+                                sanums + (size_t)off * T, signals + (size_t)off * S, &tickets[head % 8]));
+            }
             ++head;
         }
         while (tail < head) {
