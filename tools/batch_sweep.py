@@ -18,5 +18,6 @@ for B in [int(x) for x in sys.argv[1:]] or [128, 256, 512, 1024, 2048, 4096]:
     e.sync(); t0 = time.perf_counter()
     for _ in range(K): step()
     e.sync(); dt = time.perf_counter() - t0
-    print("batch %5d: %.3f ms/step, %.0f sites/s, %.1f TFLOP/s" % (B, 1e3 * dt / K, K * B / dt, K * B / dt * 280.296e6 / 1e12))
+    flops = sum(st["flops_per_site"] for st in e.stage_times())          # FLOPs the engine executes per site
+    print("batch %5d: %.3f ms/step, %.0f sites/s, %.1f TFLOP/s executed" % (B, 1e3 * dt / K, K * B / dt, K * B / dt * flops / 1e12))
     e.close()
