@@ -1,0 +1,25 @@
+"""CPU (-m "not gpu"): register / scratch budget of the two kernels whose footprints let them share a CU (DESIGN.md 4,
+"Sharing a CU"): two fused-module waves (<= 184 VGPRs each) and one BiLSTM cell wave (<= 96) per SIMD. A change that
+pushes either over its budget costs 3 - 4 % of the 512-site throughput without failing any numerical test."""
+import os
+import shutil
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_cu_sharing_register_budgets():
+    if not shutil.which("/opt/rocm/bin/hipcc"):
+        pytest.skip("hipcc not available")
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import kernel_resources
+    res = kernel_resources.kernel_resources()
+    fused = [r for n, r in res.items() if "inception_fused_kernel<3>" in n]
+    cell = [r for n, r in res.items() if "lstm_cell_lds_kernel<1>" in n]
+    assert len(fused) == 1 and len(cell) == 1, sorted(res)
+    assert fused[0]["vgprs"] <= 184 and fused[0]["scratch_bytes"] == 0, fused[0]
+    assert cell[0]["vgprs"] <= 96 and cell[0]["scratch_bytes"] == 0 and cell[0]["static_lds_bytes"] == 0, cell[0]
+    # no kernel of the library may spill
+    assert all(r["scratch_bytes"] == 0 for r in res.values()), {n: r for n, r in res.items() if r["scratch_bytes"]}

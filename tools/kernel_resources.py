@@ -1,0 +1,35 @@
+"""VGPRs, scratch and static LDS of every kernel in deepsignal_amd/csrc/ds_kernels.hip (hipcc -S, device only, ~40 s).
+
+Two of the numbers carry a property the 512-site throughput depends on ("Sharing a CU"): the fused inception
+module must stay at <= 184 VGPRs and the BiLSTM cell kernel at <= 96 (88 today), so that two module waves and one cell
+wave fit a SIMD's 512 registers; tests/test_kernel_resources.py asserts them.
+
+usage: python tools/kernel_resources.py [name filter]"""
+import os, re, subprocess, sys, tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+
+def kernel_resources():
+    src = os.path.join(ROOT, "deepsignal_amd", "csrc", "ds_kernels.hip")
+    with tempfile.TemporaryDirectory() as tmp:
+        out = os.path.join(tmp, "k.s")
+        subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-unused-value", "--cuda-device-only", "-S",
+                        "-x", "hip", "-o", out, src], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        text = open(out).read()
+    res = {}
+    for m in re.finditer(r"\.amdhsa_kernel (\S+)\n(.*?)\.end_amdhsa_kernel", text, re.S):
+        body = m.group(2)
+        get = lambda key: int(re.search(r"\.amdhsa_%s (\d+)" % key, body).group(1))
+        name = subprocess.run(["c++filt", m.group(1)], capture_output=True, text=True).stdout.strip() or m.group(1)
+        res[name] = {"vgprs": get("next_free_vgpr"), "scratch_bytes": get("private_segment_fixed_size"),
+                     "static_lds_bytes": get("group_segment_fixed_size")}
+    return res
+
+
+if __name__ == "__main__":
+    flt = sys.argv[1] if len(sys.argv) > 1 else ""
+    for name, r in sorted(kernel_resources().items()):
+        if flt in name:
+            print("%4d VGPRs  %5d B scratch  %6d B static LDS  %s" % (r["vgprs"], r["scratch_bytes"], r["static_lds_bytes"], name[:110]))
