@@ -15,13 +15,20 @@ CPU-only box (tests/test_bench_launcher.py); its line carries "dry_run": true an
 The timed region is repeated `--windows` times (default 5), each window = EXACTLY K steps bracketed by barrier +
 synchronize on both sides, max over ranks; `value` / `ms_per_step` are the MEDIAN window, `windows` lists them all.
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with these extra objects:
-  roofline        the dominant kernel's achieved TFLOP/s (algorithmic 2*M*N*K per launch / HIP-event
-                  duration per launch) against the fp32 MFMA peak
-  cpu_baseline    the CPU oracle (oracle/ds_oracle.c, "port") timed on this box's host cores
-  pcie_inclusive  the same 512-site batches from HOST memory through ds_submit / ds_wait (H2D + kernels + D2H,
-                  SURVEY.md 8d's definition of the metric) -- reported beside `value`, never as it
-  e2e_tsv         feature TSV -> result TSV through call_mods (native reader + formatter + the engine)
+Prints ONE JSON line on rank 0 (contract in the task statement). `value` / `ms_per_step` / `roofline` are the
+REFERENCE GRAPH: the joint model runs as its three steps (avgpool kernel, dense 6032 x 6032, head; layers.py:233-238,
+257-263), 280.3 MFLOP/site of which 244.0 are executed (layer 0's embedding product is a table lookup).
+Extra objects:
+  roofline            the dominant kernel's achieved TFLOP/s (algorithmic 2*M*N*K per launch / HIP-event duration per
+                      launch) against the fp32 MFMA peak; fc_path = MFMA utilisation of the dense 6032 x 6032 GEMM,
+                      conv_path = HBM GB/s of the signal model's kernels (the two figures the north star names)
+  fast_mode_folded    the product's default engine (joint model folded into one 6032 x 2 matrix at weight load)
+  cpu_baseline        the CPU oracle (oracle/ds_oracle.c, "port") timed on this box's host cores
+  pcie_inclusive      the same 512-site batches from HOST memory through ds_submit / ds_wait (H2D + kernels + D2H,
+                      SURVEY.md 8d's definition of the metric) -- reported beside `value`, never as it
+  ds_forward_blocking the blocking call the reference makes (call_modifications.py:177-178; INTEGRATION.md binds it):
+                      host buffers in, results out, n = 512 and n = 8192 per call
+  e2e_tsv             feature TSV -> result TSV through call_mods (native reader + formatter + the default engine)
 """
 import argparse
 import json
@@ -34,6 +41,7 @@ sys.path.insert(0, ROOT)
 
 BATCH = 512
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+CONV_BYTES_PER_SITE_MODULE_GRANULAR = 1_651_680      # conv path, fp32, module-granular
 WORKLOAD = "configs[1]: 1xMI355X, batch=512, random-init CpG model weights, synthetic (17,360) features, fp32"
 
 
@@ -109,24 +117,59 @@ def cpu_baseline(weights, budget_s=12.0):
     return c_port
 
 
+def _latest_profile(pattern):
+    import glob
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)))
+    return cands[-1] if cands else None
+
+
+def _norm_kernel(s):
+    return s.replace(" ", "").replace(",false>", ">").replace(",true>", ",bf16>")
+
+
+def _recorded_commit(path):
+    """Commit that last touched a profiles/ file (so a reader can tell which build the constant belongs to)."""
+    import subprocess
+    try:
+        out = subprocess.run(["git", "log", "-1", "--format=%h", "--", path], cwd=ROOT, capture_output=True, text=True, timeout=10)
+        return out.stdout.strip() or None
+    except Exception:
+        return None
+
+
 def pmc_traffic(kernel_name):
     """HBM bytes per launch of `kernel_name` from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE are
     collected in separate runs of this same command and corrected as MI355X_MICROARCH.md prescribes; see
-    tools/pmc_traffic.py). Counters cannot be read from inside the process, so this is the recorded figure."""
-    import glob
-    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_traffic.json")))
-    path = cands[-1] if cands else os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    norm = lambda s: s.replace(" ", "").replace(",false>", ">").replace(",true>", ",bf16>")
+    tools/pmc_traffic.py). Counters cannot be read from inside the process: this is a COMMITTED CONSTANT of an earlier
+    run, not a measurement of this one, and `traffic_source` says so."""
+    path = _latest_profile("r[0-9][0-9]_pmc_traffic.json")
     try:
         rec = json.load(open(path))
         for name, v in rec["kernels"].items():
-            if norm(name) == norm(kernel_name):
+            if _norm_kernel(name) == _norm_kernel(kernel_name):
                 return {"traffic": round(v["hbm_bytes_per_launch"]), "traffic_unit": "B/launch",
                         "traffic_fetch": round(v["fetch_bytes_per_launch"]), "traffic_write": round(v["write_bytes_per_launch"]),
-                        "traffic_source": "profiles/" + os.path.basename(path) + " (" + rec["source"] + ")"}
-    except (OSError, ValueError, KeyError):
+                        "traffic_source": "committed constant, NOT measured in this run: profiles/%s (recorded at commit %s; %s)"
+                                          % (os.path.basename(path), _recorded_commit(path), rec["source"])}
+    except (OSError, ValueError, KeyError, TypeError):
         pass
     return {"traffic": None}
+
+
+def pmc_mfma_busy(kernel_name):
+    """MFMA-pipe busy share of `kernel_name` (SQ_VALU_MFMA_BUSY_CYCLES / duration at the in-kernel clock) from the committed
+    PMC pass -- a committed constant like pmc_traffic."""
+    path = _latest_profile("r[0-9][0-9]_pmc_mfma_util.json")
+    try:
+        rec = json.load(open(path))
+        for name, v in rec["kernels"].items():
+            if _norm_kernel(name) == _norm_kernel(kernel_name):
+                return {"mfma_busy_pmc": v["mfma_busy_frac_at_inkernel_clock"],
+                        "mfma_busy_source": "committed constant, NOT measured in this run: profiles/%s (recorded at commit %s)"
+                                            % (os.path.basename(path), _recorded_commit(path))}
+    except (OSError, ValueError, KeyError, TypeError):
+        pass
+    return {"mfma_busy_pmc": None}
 
 
 class _DryRunEngine:
@@ -188,6 +231,35 @@ def pcie_inclusive(eng, feats, steps, batch):
                         "(12 B/site), %d batches of %d sites per window, %d in flight" % (steps, batch, eng.slots)}
 
 
+def forward_blocking(eng, feats, batch):
+    """The call the reference makes (tf_sess.run, call_modifications.py:177-178) and INTEGRATION.md binds: blocking
+    ds_forward on host arrays, results back in host arrays. n = batch per call (ONE forward in flight: the latency of the
+    19-launch BiLSTM chain is exposed) and n = 16 batches per call (the library pipelines the passes over its slots)."""
+    keys = ("kmer", "means", "stds", "sanums", "signals")
+    out = {"boundary": "ds_forward(host arrays) -> (act, pred) host arrays, blocking; pinned staging + one H2D / one D2H copy per pass"}
+    for n in (batch, 16 * batch):
+        reps_arrays = [tuple(np_tile(feats[k], n, off) for k in keys) for off in (0, batch)]
+        eng.run(*reps_arrays[0])                                         # warm-up (plans, graphs, pinned staging)
+        rates = []
+        for rep in range(3):
+            calls = max(2, (64 * batch) // n)
+            t0 = time.perf_counter()
+            for c in range(calls):
+                eng.run(*reps_arrays[c & 1])
+            rates.append(calls * n / (time.perf_counter() - t0))
+        rates.sort()
+        out["n_%d" % n] = {"value": round(rates[1], 1), "unit": "sites/s", "min": round(rates[0], 1), "max": round(rates[2], 1),
+                           "ms_per_call": round(1e3 * n / rates[1], 4)}
+    return out
+
+
+def np_tile(a, n, off):
+    """n rows of `a` starting at row `off`, wrapping around (contiguous copy)."""
+    import numpy as np
+    idx = (np.arange(n) + off) % a.shape[0]
+    return np.ascontiguousarray(a[idx])
+
+
 def e2e_tsv(eng, feats, rows, batch):
     """Feature TSV -> result TSV through the product's call_mods (native reader on the usable host cores, engine through
     submit / wait, native row formatter): what a user's `deepsignal call_mods -i features.tsv` sustains on this box."""
@@ -237,7 +309,8 @@ def main():
                     help="skip pass C (every launch on one stream); used for the rocprofv3 cross-check, whose per-kernel "
                          "averages would otherwise blend co-resident and stand-alone launches")
     ap.add_argument("--no-host-path", action="store_true", help="skip the pcie_inclusive and e2e_tsv legs")
-    ap.add_argument("--no-three-step", action="store_true", help="skip the joint_three_step leg (unfolded joint model)")
+    ap.add_argument("--no-fast-mode", "--no-three-step", dest="no_fast_mode", action="store_true",
+                    help="skip the fast_mode_folded leg (the default engine with the folded joint model)")
     ap.add_argument("--lstm-tiling", default="auto", help="diagnostic: force a BiLSTM cell-kernel variant (Engine(lstm_tiling=...))")
     ap.add_argument("--slots", type=int, default=0, help="diagnostic: forwards in flight (0 = engine default, 8)")
     ap.add_argument("--dry-run", action="store_true",
@@ -270,13 +343,22 @@ def main():
 
     from deepsignal_amd import spec, synth, weights as W
 
+    launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ     # under torch.distributed.run, also with one rank
+    if dist is None and launched and world == 1 and not args.dry_run:
+        # one rank under the launcher: same code path as N > 1 (process group on RCCL, the gather inside the timed window)
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
     if args.dry_run:
         w = None
         eng = _DryRunEngine(torch)
     else:
         from deepsignal_amd.engine import Engine
         w = W.random_weights(seed=W.WEIGHT_SEED)          # TF-initializer style, randomised BN
-        eng = Engine(device=local_rank, max_batch=BATCH, lstm_tiling=args.lstm_tiling, slots=args.slots)
+        # the headline engine runs the REFERENCE GRAPH: joint model as avgpool + dense(6032, 6032) + dense(6032, 2)
+        # (layers.py:233-238,257-263); the folded default engine is timed beside it (fast_mode_folded)
+        eng = Engine(device=local_rank, max_batch=BATCH, lstm_tiling=args.lstm_tiling, slots=args.slots, fold_fc=False)
         eng.load_weights(w)
 
     # this rank's shard: its own reads (20 sites per read), NPOOL distinct batches resident in HBM
@@ -287,44 +369,58 @@ def main():
     out_act = torch.zeros((max(K, 1), BATCH, 2), dtype=torch.float32, device=dev)
     out_pred = torch.zeros((max(K, 1), BATCH), dtype=torch.int32, device=dev)
 
-    def step(i, slot):
-        b = (i % NPOOL) * BATCH
-        eng.run_device(BATCH, d["kmer"][b:b + BATCH].data_ptr(), d["means"][b:b + BATCH].data_ptr(),
-                       d["stds"][b:b + BATCH].data_ptr(), d["sanums"][b:b + BATCH].data_ptr(),
-                       d["signals"][b:b + BATCH].data_ptr(), out_act[slot].data_ptr(), out_pred[slot].data_ptr())
+    def make_step(e):
+        def step(i, slot):
+            b = (i % NPOOL) * BATCH
+            e.run_device(BATCH, d["kmer"][b:b + BATCH].data_ptr(), d["means"][b:b + BATCH].data_ptr(),
+                         d["stds"][b:b + BATCH].data_ptr(), d["sanums"][b:b + BATCH].data_ptr(),
+                         d["signals"][b:b + BATCH].data_ptr(), out_act[slot].data_ptr(), out_pred[slot].data_ptr())
+        return step
 
-    def fence():
-        eng.sync()
-        dev_sync()
-        if dist is not None:
-            dist.barrier()
+    gathered = {"bytes": 0}
+
+    def timed_windows(e, nwin):
+        """W untimed steps, then nwin windows of EXACTLY K steps, each bracketed by barrier + synchronize on both sides,
+        max over ranks; with a process group the result gather to rank 0 is inside the window."""
+        step = make_step(e)
+
+        def fence():
+            e.sync()
             dev_sync()
+            if dist is not None:
+                dist.barrier()
+                dev_sync()
 
-    for i in range(Wm):
-        step(i, 0)
-    windows = []
-    for rep in range(max(1, args.windows)):
-        fence()
-        t0 = time.perf_counter()
-        for i in range(K):
-            step(i, i)
-        eng.sync()
-        if dist is not None:
-            # the path's only exchange: gather f32[n,2] + i32[n] (12 B/site) to the writer rank over RCCL
-            from deepsignal_amd import sharding
-            # rank r owns the sites r, r + world, ...: the writer derives the indices, only the 12 B/site travel
-            g_act, g_pred = sharding.gather_results(
-                out_act.reshape(-1, 2), out_pred.reshape(-1), None, dist, dst=0, device=dev, as_numpy=False,
-                index_of_rank=lambda r, cnt: torch.arange(r, r + world * cnt, world, dtype=torch.int64, device=dev))
-            if rank == 0:
-                assert g_act.shape[0] == world * K * BATCH
-        fence()
-        el = time.perf_counter() - t0
-        if dist is not None:
-            t = torch.tensor([el], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            el = float(t.item())
-        windows.append(el)
+        for i in range(Wm):
+            step(i, 0)
+        wins = []
+        for rep in range(max(1, nwin)):
+            fence()
+            t0 = time.perf_counter()
+            for i in range(K):
+                step(i, i)
+            e.sync()
+            if dist is not None:
+                # the path's only exchange: gather f32[n,2] + i32[n] (12 B/site) to the writer rank over RCCL
+                from deepsignal_amd import sharding
+                # rank r owns the sites r, r + world, ...: the writer derives the indices, only the 12 B/site travel
+                g_act, g_pred = sharding.gather_results(
+                    out_act.reshape(-1, 2), out_pred.reshape(-1), None, dist, dst=0, device=dev, as_numpy=False,
+                    force_collective=True,
+                    index_of_rank=lambda r, cnt: torch.arange(r, r + world * cnt, world, dtype=torch.int64, device=dev))
+                if rank == 0:
+                    assert g_act.shape[0] == world * K * BATCH
+                    gathered["bytes"] = int(g_act.numel() * 4 + g_pred.numel() * 4)
+            fence()
+            el = time.perf_counter() - t0
+            if dist is not None:
+                t = torch.tensor([el], dtype=torch.float64, device=dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                el = float(t.item())
+            wins.append(el)
+        return wins
+
+    windows = timed_windows(eng, args.windows)
     assert bool(torch.isfinite(out_act).all())
     elapsed = sorted(windows)[len(windows) // 2]          # median window
 
@@ -336,14 +432,17 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": WORKLOAD, "batch": BATCH, "kmer_len": 17, "signal_len": 360,
-                   "joint_model": "folded: avgpool x dense(6032,6032) x dense(6032,2) -> one 6032 x 2 matrix (float64 at "
-                                  "weight load); the three-step form is timed in joint_three_step",
+                   "joint_model": "three-step, as the reference graph: avgpool(7) kernel, dense(6032, 6032) GEMM, dense(6032, 2) "
+                                  "+ sigmoid + argmax (layers.py:233-238,257-263); the folded engine is in fast_mode_folded",
                    "sharding": "by read, %d rank(s), full weight replica per GPU" % world},
         "windows": {"n": len(windows), "steps_each": K, "statistic": "median",
                     "sites_per_s": [round(world * K * BATCH / x, 1) for x in windows] if K else [],
                     "min": round(world * K * BATCH / max(windows), 1) if K else 0.0,
                     "max": round(world * K * BATCH / min(windows), 1) if K else 0.0},
     }
+    if dist is not None:
+        result["gather"] = {"backend": dist.get_backend(), "world": world, "bytes_per_window": gathered["bytes"],
+                            "what": "f32[n,2] + i32[n] of every rank to rank 0 (sharding.gather_results), inside every timed window"}
     if args.dry_run:
         result.update({"dry_run": True, "data": "none (launcher dry run: stub engine, gloo, no forward executed)",
                        "value": 0.0, "ms_per_step": 0.0})
@@ -355,6 +454,7 @@ def main():
             print(json.dumps(result))
         return
 
+    step = make_step(eng)
     if rank == 0 and not args.no_profile_pass:
         # HIP events on the engine's own streams, eager replay of the same K steps.
         # pass A (mode 2, one pair per launch): per-stage breakdown
@@ -395,9 +495,10 @@ def main():
             "kernel": dom["name"], "launches_per_step": dom["launches"] // max(KP, 1),
             "avg_launch_us": round(avg_ms * 1e3, 2), "flops_per_launch": per_launch_flops,
             "profiled_ms_per_step": round(prof_ms, 4),
-            # FLOPs the engine EXECUTES per site (layer-0 input projection = table lookup, joint model folded into
-            # one J x 2 matrix at weight load), not the reference graph's contract FLOPs
+            # FLOPs the engine EXECUTES per site (layer-0 input projection = table lookup) next to the reference
+            # graph's contract FLOPs; whole_path_tflops prices the executed ones
             "whole_path_tflops": round(exec_flops_per_site * result["value"] / world / 1e12, 2),
+            "whole_path_frac": round(exec_flops_per_site * result["value"] / world / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
             "flops_per_site": {"executed": exec_flops_per_site, "reference_graph": spec.FLOPS_PER_SITE},
         }
         if dom["name"] in alone:     # the same kernel with the GPU to itself (no signal-model kernels co-resident)
@@ -407,6 +508,28 @@ def main():
             result["roofline"]["standalone"] = {"avg_launch_us": round(a_ms * 1e3, 2), "achieved": round(a_tf, 2),
                                                 "frac": round(a_tf / PEAK_FP32_MFMA_TFLOPS, 4)}
         result["roofline"].update(pmc_traffic(dom["name"]))
+        # the two figures the north star names: MFMA utilisation on the FC path, HBM GB/s on the conv path
+        src = alone if alone else {k["name"]: k for k in ks}
+        fc = [k for n_, k in src.items() if n_.startswith("gemm_kernel<1,3,4,1")]        # dense(6032, 6032) of the joint model
+        if fc:
+            f_ms = fc[0]["total_ms"] / fc[0]["launches"]
+            f_tf = fc[0]["flops"] / fc[0]["launches"] / (f_ms * 1e-3) / 1e12
+            result["roofline"]["fc_path"] = dict(
+                {"kernel": fc[0]["name"], "avg_launch_us": round(f_ms * 1e3, 2), "achieved": round(f_tf, 2), "unit": "TFLOP/s",
+                 "mfma_utilisation": round(f_tf / PEAK_FP32_MFMA_TFLOPS, 4),
+                 "how": "2 * n * 6032 * 6032 FLOP per launch / HIP-event duration (%s) / fp32 MFMA peak"
+                        % ("every launch on one stream" if alone else "co-resident")}, **pmc_mfma_busy(fc[0]["name"]))
+        conv = [k for n_, k in src.items() if n_.startswith(("stem1_kernel", "stem23_kernel", "inception_fused_kernel", "avgpool7_kernel"))]
+        if conv:
+            c_ms = sum(k["total_ms"] for k in conv) / max(KP, 1)
+            c_bytes = CONV_BYTES_PER_SITE_MODULE_GRANULAR * BATCH
+            result["roofline"]["conv_path"] = {
+                "kernels": [k["name"] for k in conv], "us_per_step": round(c_ms * 1e3, 1),
+                "hbm_GBps": round(c_bytes / (c_ms * 1e-3) / 1e9, 1), "hbm_frac_of_8TBps": round(c_bytes / (c_ms * 1e-3) / 8e12, 4),
+                "tflops": round(sum(k["flops"] for k in conv) / max(KP, 1) / (c_ms * 1e-3) / 1e12, 2),
+                "how": "module-granular algorithmic bytes (SURVEY.md 8d: 1,651,680 B/site, every stem conv / pool / module reads "
+                       "its input and writes its output once) / summed HIP-event durations; fp32 modules are MFMA-bound, the "
+                       "HBM-bound form of the conv path is the bf16 mode (DESIGN.md section 9)"}
         result["kernels"] = {k["name"]: {"launches_per_step": k["launches"] // max(KP, 1),
                                           "us_per_step": round(1e3 * k["total_ms"] / max(KP, 1), 1),
                                           "tflops": round(k["flops"] / (k["total_ms"] * 1e-3) / 1e12, 2) if k["total_ms"] else 0,
@@ -414,40 +537,32 @@ def main():
                                           if k["name"] in alone else None}
                              for k in ks}
         result["stages_us_per_step"] = stages
-    if rank == 0 and world == 1 and not args.dry_run and not args.no_three_step:
-        # like-for-like leg: the reference's three joint-model steps (avgpool kernel, J x J GEMM, head) instead of
-        # the folded J x 2 matrix -- same inputs, same timed-region rules, 3 windows
-        eng3 = Engine(device=local_rank, max_batch=BATCH, lstm_tiling=args.lstm_tiling, slots=args.slots, fold_fc=False)
-        eng3.load_weights(w)
-        def step3(i, slot):
-            b = (i % NPOOL) * BATCH
-            eng3.run_device(BATCH, d["kmer"][b:b + BATCH].data_ptr(), d["means"][b:b + BATCH].data_ptr(),
-                            d["stds"][b:b + BATCH].data_ptr(), d["sanums"][b:b + BATCH].data_ptr(),
-                            d["signals"][b:b + BATCH].data_ptr(), out_act[slot].data_ptr(), out_pred[slot].data_ptr())
-        for i in range(Wm):
-            step3(i, 0)
-        w3 = []
-        for rep in range(3):
-            eng3.sync(); dev_sync()
-            t0 = time.perf_counter()
-            for i in range(K):
-                step3(i, i)
-            eng3.sync(); dev_sync()
-            w3.append(time.perf_counter() - t0)
-        el3 = sorted(w3)[1]
-        st3 = {s["name"]: s for s in eng3.stage_times()}
-        result["joint_three_step"] = {
-            "value": round(K * BATCH / el3, 1) if K else 0.0, "unit": "sites/s", "ms_per_step": round(1e3 * el3 / max(K, 1), 4),
-            "whole_path_tflops": round(sum(s["flops_per_site"] for s in st3.values()) * K * BATCH / el3 / 1e12, 2) if K else 0.0,
-            "note": "Engine(fold_fc=False) = DS_TUNE_NO_FOLD_FC: avgpool7_kernel + dense(6032, 6032) GEMM + head_kernel "
-                    "as the reference graph runs them; the default engine folds them into one 6032 x 2 matrix "
-                    "(float64 product at weight load; layers.py:75-77,233-238,257-263 have no bias / activation)"}
-        eng3.close()
-    if rank == 0 and world == 1 and not args.no_host_path:
+    solo = rank == 0 and world == 1 and not launched
+    if solo and not args.no_host_path:
         result["pcie_inclusive"] = pcie_inclusive(eng, feats, max(K, 64), BATCH)
-        result["e2e_tsv"] = e2e_tsv(eng, feats, 163840, BATCH)
+        result["ds_forward_blocking"] = forward_blocking(eng, feats, BATCH)
+    if solo and not args.no_fast_mode:
+        # the product's default engine: joint model folded into one 6032 x 2 matrix at weight load (float64 product;
+        # layers.py:75-77,233-238,257-263 have no bias / activation) -- same inputs, same timed-region rules, 3 windows
+        engf = Engine(device=local_rank, max_batch=BATCH, lstm_tiling=args.lstm_tiling, slots=args.slots)
+        engf.load_weights(w)
+        wf = timed_windows(engf, 3)
+        elf = sorted(wf)[len(wf) // 2]
+        stf = {s_["name"]: s_ for s_ in engf.stage_times()}
+        fm = {"value": round(K * BATCH / elf, 1) if K else 0.0, "unit": "sites/s", "ms_per_step": round(1e3 * elf / max(K, 1), 4),
+              "executed_flops_per_site": float(sum(s_["flops_per_site"] for s_ in stf.values())),
+              "note": "Engine() default: avgpool x dense(6032, 6032) x dense(6032, 2) -> one 6032 x 2 matrix; parity-tested against "
+                      "the three-step form and the oracle (tests/test_gpu_parity.py); NOT the headline (SURVEY.md K13)"}
+        fm["whole_path_tflops"] = round(fm["executed_flops_per_site"] * fm["value"] / 1e12, 2)
+        if not args.no_host_path:
+            fm["pcie_inclusive"] = pcie_inclusive(engf, feats, max(K, 64), BATCH)
+            fm["ds_forward_blocking"] = forward_blocking(engf, feats, BATCH)
+            fm["e2e_tsv"] = e2e_tsv(engf, feats, 163840, BATCH)
+            result["e2e_tsv"] = dict(fm["e2e_tsv"], engine="default (folded joint model), as `deepsignal call_mods` runs")
+        result["fast_mode_folded"] = fm
+        engf.close()
     eng.close()
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if solo and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(w)
     if dist is not None:
         dist.barrier()

@@ -332,30 +332,53 @@ class _RowPipeline:
 
 
 def _prefetch(iterable, depth=3):
-    """Run `iterable` on a helper thread (the native parser releases the GIL), a bounded queue ahead of the consumer."""
+    """Run `iterable` on a helper thread (the native parser releases the GIL), a bounded queue ahead of the consumer.
+    The producer has always EXITED when this generator is finished or closed -- also when the consumer stops early
+    (an engine or formatter error unwinds through the `for` loop and closes the generator): a stop flag is set, the
+    queue is drained so a blocked put() returns, and the thread is joined. Only then may the caller close what the
+    iterable reads from (the native reader unmaps its file and deletes its thread team)."""
     import queue
     import threading
     q = queue.Queue(maxsize=depth)
     done = object()
+    stop = threading.Event()
+
+    def put(x):
+        while not stop.is_set():
+            try:
+                q.put(x, timeout=0.05)
+                return True
+            except queue.Full:
+                pass
+        return False
 
     def produce():
         try:
             for x in iterable:
-                q.put(x)
-            q.put(done)
+                if not put(x):
+                    return
+            put(done)
         except BaseException as exc:          # surfaced on the consumer side
-            q.put(exc)
+            put(exc)
 
     th = threading.Thread(target=produce, daemon=True)
     th.start()
-    while True:
-        x = q.get()
-        if x is done:
-            break
-        if isinstance(x, BaseException):
-            raise x
-        yield x
-    th.join()
+    try:
+        while True:
+            x = q.get()
+            if x is done:
+                break
+            if isinstance(x, BaseException):
+                raise x
+            yield x
+    finally:
+        stop.set()
+        while th.is_alive():
+            try:
+                q.get_nowait()
+            except queue.Empty:
+                pass
+            th.join(timeout=0.05)
 
 
 # Sharded feature-file mode: the file is cut into byte ranges of whole reads of about this many bytes; range k belongs
@@ -408,9 +431,10 @@ def _call_mods_sharded(input_path, engine, batch_size, result_file, kmer_len, ce
             yield c, None
 
     failed = False
+    items = _prefetch(rows())
     try:
         pending_done = []                  # chunks fully fed, waiting for their rows to drain
-        for c, item in _prefetch(rows()):
+        for c, item in items:
             if item is not None:
                 pipe.feed(item, c)
                 continue
@@ -430,6 +454,7 @@ def _call_mods_sharded(input_path, engine, batch_size, result_file, kmer_len, ce
         try:
             total, _ = gather.close(pipe.nsites, 0, failed=failed)
         finally:
+            items.close()                  # the parser thread has exited (never inside ds_tsv_next when the reader closes)
             pipe.close()
             reader.close()
     return total
@@ -437,7 +462,7 @@ def _call_mods_sharded(input_path, engine, batch_size, result_file, kmer_len, ce
 
 def call_mods(input_path, model_path, result_file, kmer_len, cent_signals_len,
               batch_size, learning_rate, class_num, nproc, is_gpu, is_rnn, is_base, is_cnn,
-              f5_args, engine=None, f5_batch_num=None, native_io=True, precision="fp32", dist=None):
+              f5_args, engine=None, f5_batch_num=None, native_io=True, precision="fp32", dist=None, force_sharded=False):
     """The reference's call_mods (call_modifications.py:417-495), same signature and argument meaning.
 
     learning_rate / is_gpu are accepted for signature compatibility: inference ignores the learning rate
@@ -447,12 +472,14 @@ def call_mods(input_path, model_path, result_file, kmer_len, cent_signals_len,
     overrides its entry. A directory as input_path takes the fast5 route (features extracted on the host,
     deepsignal_amd/extract_features.py). With the native reader the engine is driven through its asynchronous boundary
     (submit / wait, several batches in flight) and, when launched by torch.distributed.run with WORLD_SIZE > 1, one
-    process per GPU takes its share of the reads."""
+    process per GPU takes its share of the reads. force_sharded=True takes that multi-process route (byte ranges, row
+    gather through the process group's collectives) even in a world of one: one rank under the launcher runs the same
+    RCCL calls as eight."""
     start = time.time()
     f5 = _unpack_f5_args(f5_args, f5_batch_num)
     dist, rank, world, local = _distributed_context(dist)
     device = None
-    if world > 1 and dist.get_backend() == "nccl":
+    if dist is not None and (world > 1 or force_sharded) and dist.get_backend() == "nccl":
         import torch
         device = torch.device("cuda", local)
     own = engine is None
@@ -463,7 +490,7 @@ def call_mods(input_path, model_path, result_file, kmer_len, cent_signals_len,
         if os.path.isdir(input_path):
             nsites = _call_mods_from_fast5s(input_path, result_file, kmer_len, cent_signals_len, batch_size, f5, engine,
                                             nproc=nproc, dist=dist, rank=rank, world=world, device=device)
-        elif world > 1:
+        elif world > 1 or (force_sharded and dist is not None):
             # launched as `python -m torch.distributed.run --nproc-per-node N -m deepsignal_amd.deepsignal call_mods ...`
             if not native_io:
                 raise ValueError("multi-GPU call_mods uses the native feature reader (native_io=True)")
@@ -474,17 +501,21 @@ def call_mods(input_path, model_path, result_file, kmer_len, cent_signals_len,
             # same items, same row text
             from . import fastio
             reader = fastio.FeatureReader(input_path, kmer_len, cent_signals_len)
-            with open(result_file, "wb") as wf:
-                pipe = _RowPipeline(engine, batch_size, lambda tag, data: wf.write(data))
-                try:
-                    for item in _prefetch(reader.items(f5.f5_batch_num)):
-                        pipe.feed(item)
-                    pipe.flush()
-                finally:
-                    pipe.close()
-                wf.flush()
-            nsites = pipe.nsites
-            reader.close()
+            try:
+                with open(result_file, "wb") as wf:
+                    pipe = _RowPipeline(engine, batch_size, lambda tag, data: wf.write(data))
+                    items = _prefetch(reader.items(f5.f5_batch_num))
+                    try:
+                        for item in items:
+                            pipe.feed(item)
+                        pipe.flush()
+                    finally:
+                        items.close()          # the parser thread has exited before the reader goes away
+                        pipe.close()
+                    wf.flush()
+                nsites = pipe.nsites
+            finally:
+                reader.close()
         else:
             nsites = 0
             with open(result_file, "w") as wf:

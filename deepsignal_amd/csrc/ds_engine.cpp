@@ -655,7 +655,7 @@ int build_plan(ds_handle* h, int n, Plan* plan)
         add_ew_op(cnn, op);
         if (first_plan) h->stages[st].flops_per_site += 2.0 * h->w1 * 7 * 64;
         const int M = n * h->wa;
-        if (!bf && !h->no_fused && h->wa <= 96) {
+        if (!bf && !h->no_fused && h->wa <= 96 && stem23_lds_bytes(h->wa, 1) <= STEM23_MAX_LDS) {
             // conv_layer2 + conv_layer3 in one kernel (stem23_kernel): tiles of whole sites, conv2's rows never leave LDS
             Op o2{};
             o2.kind = OP_STEM23; o2.stream = 0; o2.stage = st;
@@ -665,6 +665,9 @@ int build_plan(ds_handle* h, int n, Plan* plan)
             // sites per tile: as full as 96 rows allow, as long as every CU still gets a tile
             int spt = std::max(1, 96 / h->wa);
             while (spt > 1 && (n + spt - 1) / spt < 256) --spt;
+            // the T tile carries two halo rows per site: short sites (signal_len <= 128) at the full 96 rows pass the 80 KB the
+            // kernel may ask for at two workgroups per CU (configure_fused_kernels)
+            while (spt > 1 && stem23_lds_bytes(h->wa, spt) > STEM23_MAX_LDS) --spt;
             o2.sa.spt = spt;
             o2.flops = 2.0 * M * (64.0 * 128 + 384.0 * 256);
             add_ew_op(cnn, o2);
@@ -1222,7 +1225,7 @@ int guarded(ds_handle* h, F&& body)
 // ======================================= C ABI =======================================
 extern "C" {
 
-const char* ds_version(void) { return "deepsignal_amd 0.2 (gfx950, fp32 MFMA; optional bf16 conv+FC)"; }
+const char* ds_version(void) { return "deepsignal_amd 0.3 (gfx950; fp32 MFMA, bf16 conv + FC and bf16_all operand modes)"; }
 
 const char* ds_last_error(const ds_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
 
@@ -1375,9 +1378,13 @@ static int ds_load_weights_impl(ds_handle* h, const char* path)
         for (int i = 0; i < nd; ++i) { uint32_t d = 0; if (fread(&d, 4, 1, f) != 1) return bad("truncated header"); m.shape.push_back(d); }
         if (fread(&m.off, 8, 1, f) != 1 || fread(&m.nbytes, 8, 1, f) != 1) return bad("truncated header");
         // the header is untrusted: the payload must be exactly prod(shape) floats and lie inside the file
+        const uint64_t max_elems = (uint64_t)1 << 32;
         uint64_t cnt = 1;
-        for (int64_t d : m.shape) { if (d <= 0 || cnt > (uint64_t)1 << 40) return bad("bad tensor shape"); cnt *= (uint64_t)d; }
-        if (cnt > ((uint64_t)1 << 32) || m.nbytes != cnt * 4) return bad("tensor byte count does not match its shape");
+        for (int64_t d : m.shape) {       // divide before multiplying: the running product never wraps
+            if (d <= 0 || (uint64_t)d > max_elems / cnt) return bad("bad tensor shape");
+            cnt *= (uint64_t)d;
+        }
+        if (m.nbytes != cnt * 4) return bad("tensor byte count does not match its shape");
         if (m.off > fsize || m.nbytes > fsize - m.off) return bad("tensor payload lies outside the file");
     }
     for (auto& m : metas) {
@@ -1431,9 +1438,10 @@ static int ds_forward_impl(ds_handle* h, int32_t n, const int32_t* kmer, const f
     if (n == 0) return DS_OK;
     if (!kmer || !means || !stds || !sanums || !signals || !act || !pred) return fail(h, DS_ERR_INVALID, "null buffer");
     HIPCHK(h, hipSetDevice(h->cfg.device));
-    if (n > h->B && !h->profiling && h->slots.size() > 1) {
-        // more than one device pass: keep up to `slots` passes in flight through the asynchronous boundary
-        // (pinned staging per slot), results copied out in order
+    if (!h->profiling) {
+        // every pass goes through the asynchronous boundary: the batch is staged in the slot's pinned block (ONE H2D copy of
+        // a full batch, one D2H copy of [act | pred]; five pageable copies in and two out before), and a call of more than
+        // max_batch sites keeps up to `slots` passes in flight, results copied out in order
         for (Slot& sl : h->slots)
             if (sl.submitted_n >= 0) return fail(h, DS_ERR_INVALID, "ds_forward: ds_submit tickets are still in flight");
         const int nslots = (int)h->slots.size();
@@ -1469,6 +1477,7 @@ static int ds_forward_impl(ds_handle* h, int32_t n, const int32_t* kmer, const f
         }
         return rc;
     }
+    // profiling runs stay on slot 0 with plain copies, so that the event statistics are coherent
     for (int off = 0; off < n; off += h->B) {
         const int m = std::min(h->B, n - off);
         h->cur = &h->slots[0];

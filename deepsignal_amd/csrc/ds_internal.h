@@ -85,6 +85,7 @@ enum GemmCfg { CFG_CONV = 0, CFG_FC = 1, CFG_LSTM = 2, CFG_CONV_WIDE = 3, CFG_CO
 // lane feeds to four consecutive v_mfma_f32_32x32x2_f32 as the activation operand of the next step, so h goes
 // global -> VGPR -> MFMA with fully coalesced 1 KiB wave loads: no LDS, no barrier, no staging arithmetic.
 constexpr int LSTM_MAX_CELLS = 6;
+constexpr int DBG_MAX_WGS = 1024;       // workgroups per launch the diagnostic stamp buffers hold (later ones do not stamp)
 constexpr int LSTM_MT_FLOATS = 32 * 256;      // floats of one m-tile (32 sites x 256 units) in a fragment-major buffer
 struct LstmCell {
     const float* ax;      // x operand: h of the layer below at this step (fragment-major), nullptr for layer 0
@@ -110,7 +111,7 @@ struct LstmLaunch {
     LstmCell cell[LSTM_MAX_CELLS];
     int ncell, n, mtiles, T;
     int cls_tiles[2];          // workgroup tiles of the K = 512 cells and of the K = 256 cells (cells are sorted by K)
-    unsigned long long* dbg;   // diagnostic (DS_TUNE_DEBUG_STAMPS): [workgroup][8] time stamps of wave 0, null in normal runs
+    unsigned long long* dbg;   // diagnostic (DS_TUNE_DEBUG_STAMPS): [DBG_MAX_WGS workgroups][8] time stamps of wave 0, null in normal runs
 };
 // nt = 32-column n-tiles per wave (1, 2 or 4): the same bits for every nt (same K order per output element)
 hipError_t launch_lstm_cells(int nt, const LstmLaunch& L, hipStream_t s);      // L travels as a by-value kernel argument
@@ -154,6 +155,7 @@ struct Stem23Args {
 };
 hipError_t launch_stem23(const Stem23Args& a, hipStream_t s);
 size_t stem23_lds_bytes(int W, int spt);
+constexpr size_t STEM23_MAX_LDS = 80 * 1024;     // dynamic LDS stem23_kernel may ask for (two workgroups per CU)
 // stem conv1 (K=7, stride 2, Cin=1) + folded BN + ReLU + maxpool(3, stride 2)   layers.py:183-191
 hipError_t launch_stem1(const float* signals, const float* w7x64, const float* bias64, float* out,
                         int n, int signal_len, int w1, int pad_l_conv, int wa, int pad_l_pool, int out_bf16, hipStream_t s);

@@ -96,7 +96,8 @@ struct ds_tsv {
     size_t size = 0, pos = 0;
     size_t limit = 0;          // rows are read from [pos, limit): the whole file, or one rank's byte range (ds_tsv_set_range)
     int kmer_len = 17, signal_len = 360, nthreads = 1;
-    int64_t line_no = 0;
+    int64_t line_no = 0;       // rows handed out since the last rewind (ds_tsv_open / ds_tsv_set_range)
+    size_t range_begin = 0;    // first byte of the current range (0 for the whole file)
     std::string err;
     // current batch
     std::vector<int32_t> kmer, labels;
@@ -123,14 +124,14 @@ bool parse_list(const char* p, const char* e, int count, Out* out, bool as_int)
         if (p >= e) return false;
         if (as_int) {
             long v = 0;
-            if (*p == '+') ++p;
+            if (*p == '+') { ++p; if (p >= e || *p < '0' || *p > '9') return false; }     // int("+-5") raises in Python
             auto r = std::from_chars(p, e, v);
             if (r.ec != std::errc()) return false;
             out[i] = (Out)v;
             p = r.ptr;
         } else {
             double v = 0;
-            if (*p == '+') ++p;
+            if (*p == '+') { ++p; if (p >= e || *p == '-' || *p == '+') return false; }   // float("+-5") raises in Python
             auto r = std::from_chars(p, e, v);
             if (r.ec == std::errc::result_out_of_range) {
                 // Python's float() (the reference reader, call_modifications.py:78-85) gives +-inf for 1e400 and
@@ -305,6 +306,18 @@ void ds_tsv_close(ds_tsv* t)
 
 const char* ds_tsv_error(const ds_tsv* t) { return t ? t->err.c_str() : "null reader"; }
 
+namespace {
+// "row N" for the whole file; inside a byte range (sharded call_mods: ds_tsv_set_range) the row count is relative to the
+// range, so the message names the range and the absolute byte offset of the line -- `tail -c +OFFSET file | head -1`
+std::string row_where(const ds_tsv* t, int64_t index0, const char* line)
+{
+    std::string w = "row " + std::to_string(index0 + 1);
+    if (t->range_begin != 0 || t->limit != t->size)
+        w += " of the byte range [" + std::to_string(t->range_begin) + ", " + std::to_string(t->limit) + ")";
+    return w + " (line at byte offset " + std::to_string((long long)(line - t->data)) + ")";
+}
+}  // namespace
+
 // Next queue item: all rows of the next `max_reads` reads (a read = maximal run of consecutive rows with the
 // same column 5). Returns the number of sites, 0 at end of file, negative on a malformed row.
 int64_t ds_tsv_next(ds_tsv* t, int32_t max_reads)
@@ -326,7 +339,7 @@ int64_t ds_tsv_next(ds_tsv* t, int32_t max_reads)
         const char* c = p;
         int tabs = 0;
         while (tabs < 4 && c < ltrim) { c = find_tab(c, ltrim); if (c < ltrim) { ++c; ++tabs; } }
-        if (tabs < 4) { t->err = "row " + std::to_string(t->line_no + (int64_t)t->lines.size() + 1) + ": fewer than 5 columns"; return DS_ERR_IO; }
+        if (tabs < 4) { t->err = row_where(t, t->line_no + (int64_t)t->lines.size(), p) + ": fewer than 5 columns"; return DS_ERR_IO; }
         const char* ide = find_tab(c, ltrim);
         const size_t idl = (size_t)(ide - c);
         if (!prev_id || idl != prev_len || memcmp(c, prev_id, idl) != 0) {
@@ -368,7 +381,7 @@ int64_t ds_tsv_next(ds_tsv* t, int32_t max_reads)
         t->team->run(nt - 1, f);
     }
     if (bad.load() >= 0) {
-        t->err = "row " + std::to_string(t->line_no + bad.load() + 1) + ": malformed feature row";
+        t->err = row_where(t, t->line_no + bad.load(), t->lines[(size_t)bad.load()].first) + ": malformed feature row";
         return DS_ERR_IO;
     }
     t->info_off.resize(n + 1);
@@ -442,6 +455,7 @@ int ds_tsv_set_range(ds_tsv* t, int64_t begin, int64_t end)
     if (!t || begin < 0 || end < begin || (size_t)end > t->size) return DS_ERR_INVALID;
     t->pos = (size_t)begin;
     t->limit = (size_t)end;
+    t->range_begin = (size_t)begin;
     t->line_no = 0;
     t->err.clear();
     return DS_OK;

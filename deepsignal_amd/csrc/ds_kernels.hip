@@ -1,9 +1,10 @@
 // ds_kernels.hip — gfx950 (CDNA4 / MI355X) kernels of the call_mods forward pass.
 //
-// One fp32 MFMA implicit-GEMM template carries every matmul-shaped op of the path
-// (1-D convolutions as tap-segmented GEMMs over NWC activations, the LSTM cell matmuls with the
-// gate non-linearities fused into the epilogue, and the 6032x6032 joint FC); small elementwise
-// kernels do the pools, the Cin=1 stem conv and the 2-class head.
+// Kernels, by role (DESIGN.md section 4 has the table): a whole-module fused inception kernel (fp32 and bf16 operand
+// forms), a conv_layer2 + conv_layer3 kernel, dedicated BiLSTM cell kernels of one anti-diagonal per launch (operands
+// direct to registers, or shared through an LDS-DMA ring), an implicit-GEMM template (the 6032 x 6032 dense layer of
+// the three-step joint model, the bf16-mode stem convolutions, the layer-granular diagnostic path), and small kernels
+// for the Cin = 1 stem conv, the pools, the folded / two-class head and the input gather.
 //
 // Design notes (MI355X_MICROARCH.md / cdna_hip_programming.md):
 //  * v_mfma_f32_32x32x2_f32 is exact fp32 (an fmaf chain) at 64 FLOP/clk/SIMD and needs only ONE
@@ -808,7 +809,7 @@ __global__ __launch_bounds__(256, NT == 1 ? 4 : 2) void lstm_cell_kernel(const L
     // diagnostic stamps (wave 0, lane 0 of every workgroup; only when a debug buffer is attached):
     // [0] s_memrealtime at entry (100 MHz, comparable across CUs)  [1..4] s_memtime (shader clock) at entry / before the
     // K loop / after it / at exit  [5] s_memrealtime at exit  [6] HW_ID  [7] XCC_ID
-    unsigned long long* const sdst = Lp->dbg ? Lp->dbg + (size_t)blockIdx.x * 8 : nullptr;
+    unsigned long long* const sdst = (Lp->dbg && blockIdx.x < DBG_MAX_WGS) ? Lp->dbg + (size_t)blockIdx.x * 8 : nullptr;
     const bool stamp = sdst != nullptr && threadIdx.x == 0;
 #define DS_LSTAMP(i, v) do { if (stamp) sdst[i] = (v); } while (0)
     DS_LSTAMP(0, __builtin_amdgcn_s_memrealtime());
@@ -958,7 +959,7 @@ __global__ __launch_bounds__(256, NT == 1 ? 5 : 2) void lstm_cell_lds_kernel(con
     // diagnostic stamps (wave 0, lane 0 of every workgroup; only when a debug buffer is attached):
     // [0] s_memrealtime at entry (100 MHz, comparable across CUs)  [1..4] s_memtime (shader clock) at entry / before the
     // K loop / after it / at exit  [5] s_memrealtime at exit  [6] HW_ID  [7] XCC_ID
-    unsigned long long* const sdst = Lp->dbg ? Lp->dbg + (size_t)blockIdx.x * 8 : nullptr;
+    unsigned long long* const sdst = (Lp->dbg && blockIdx.x < DBG_MAX_WGS) ? Lp->dbg + (size_t)blockIdx.x * 8 : nullptr;
     const bool stamp = sdst != nullptr && threadIdx.x == 0;
 #define DS_LSTAMP(i, v) do { if (stamp) sdst[i] = (v); } while (0)
     DS_LSTAMP(0, __builtin_amdgcn_s_memrealtime());
@@ -1193,7 +1194,7 @@ __global__ __launch_bounds__(512, DS_FUSED_WPS) void inception_fused_kernel(cons
     const gptr1w Yg = (gptr1w)(a.Y + grow0 * 240);     // wave-uniform base; per-lane offsets stay 32-bit
 
     // diagnostic phase stamps (wave 0 and wave 7, lane 0): only when a debug buffer is attached
-    const bool stamp = a.dbg != nullptr && lane == 0 && (wave == 0 || wave == 7);
+    const bool stamp = a.dbg != nullptr && lane == 0 && (wave == 0 || wave == 7) && blockIdx.x < DBG_MAX_WGS;
     unsigned long long* sdst = a.dbg + ((size_t)blockIdx.x * 2 + (wave == 7)) * 8;
 #define DS_STAMP(i) do { if (stamp) sdst[i] = __builtin_amdgcn_s_memtime(); } while (0)
     DS_STAMP(0);
@@ -1586,7 +1587,7 @@ __global__ __launch_bounds__(512, DS_FUSEDB_WPS) void inception_fused_bf16_kerne
     const bool pooled_in = a.pool_win > 0;
     constexpr int NSLOT = TR32 * 32 / 512;    // 16-B slots of the input tile per thread: 2 * TM
 
-    const bool stamp = a.dbg != nullptr && lane == 0 && (wave == 0 || wave == 7) && blockIdx.x < 1024;
+    const bool stamp = a.dbg != nullptr && lane == 0 && (wave == 0 || wave == 7) && blockIdx.x < DBG_MAX_WGS;
     unsigned long long* sdst = a.dbg + ((size_t)blockIdx.x * 2 + (wave == 7)) * 8;
 #define DS_STAMP(i) do { if (stamp) sdst[i] = __builtin_amdgcn_s_memtime(); } while (0)
 
@@ -2021,7 +2022,7 @@ hipError_t configure_fused_kernels()
         const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
     }
-    return hipFuncSetAttribute((const void*)stem23_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    return hipFuncSetAttribute((const void*)stem23_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)STEM23_MAX_LDS);
 }
 
 hipError_t launch_inception_fused_bf16(int tm, const FusedArgs& a, hipStream_t s)

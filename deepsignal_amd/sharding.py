@@ -27,7 +27,8 @@ def shard_indices(read_ids: Sequence[str], world: int, rank: int) -> np.ndarray:
     return np.nonzero(assign_reads(read_ids, world) == rank)[0]
 
 
-def gather_results(act, pred, index, dist=None, dst: int = 0, device=None, as_numpy: bool = True, index_of_rank=None):
+def gather_results(act, pred, index, dist=None, dst: int = 0, device=None, as_numpy: bool = True, index_of_rank=None,
+                   force_collective: bool = False):
     """Gather (act float32[n_i,C], pred int32[n_i]) from all ranks to `dst`, re-ordered so that row j is the site with
     global index j; returns (act, pred) on dst and (None, None) elsewhere.
 
@@ -36,11 +37,12 @@ def gather_results(act, pred, index, dist=None, dst: int = 0, device=None, as_nu
     cannot derive them: with `index_of_rank(rank, count) -> int64 tensor` (the sharding rule, e.g. "rank r owns reads
     r, r + world, ...") nothing but the 12 B/site moves. `dist` = torch.distributed (already initialised) or None for
     single-process. as_numpy=False keeps the re-ordered results as tensors on `device` (no device-to-host copy inside the
-    call: what bench.py times is the RCCL exchange itself)."""
+    call: what bench.py times is the RCCL exchange itself). A world of one takes a shortcut without any collective unless
+    force_collective is set (one rank under the launcher: the same RCCL calls as N > 1, on one GPU)."""
     import torch
     act_t = torch.as_tensor(act, dtype=torch.float32)
     pred_t = torch.as_tensor(pred, dtype=torch.int32)
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+    if dist is None or not dist.is_initialized() or (dist.get_world_size() == 1 and not force_collective):
         idx_t = torch.as_tensor(index, dtype=torch.int64) if index is not None else index_of_rank(0, act_t.shape[0])
         order = torch.argsort(idx_t.cpu())
         return act_t.cpu()[order].numpy(), pred_t.cpu()[order].numpy()

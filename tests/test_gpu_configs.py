@@ -276,3 +276,28 @@ def test_cli_on_a_hand_assembled_tf_checkpoint(small_weights, tmp_path):
         a, b = a.split("\t"), b.split("\t")
         assert a[:6] == b[:6] and a[9] == b[9]
         assert abs(float(a[6]) - float(b[6])) <= 1e-4 and abs(float(a[7]) - float(b[7])) <= 1e-4
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# rows 8c / f3 against TensorFlow's own output (fixture of tests/golden/make_tf_golden.py; skipped loudly until it exists)
+# ------------------------------------------------------------------------------------------------------------------
+def test_tf_written_checkpoint_on_the_gpu():
+    """The HIP engine fed the checkpoint TensorFlow wrote (through deepsignal_amd.tf_checkpoint; from the seed when only
+    the npz is present) against TensorFlow's own activation_logits / prediction on the same feed: normalised
+    probabilities within the north star's 1e-4, labels equal wherever the margin exceeds 1e-3 -- both joint-model forms."""
+    import tf_golden_fixture as fx
+    from deepsignal_amd import tf_checkpoint
+    from deepsignal_amd.engine import Engine
+    g = fx.golden()
+    feats = fx.features_of(g)
+    prefix = os.path.join(fx.TF_DIR, "model.ckpt")
+    w = tf_checkpoint.checkpoint_to_weights(prefix) if tf_checkpoint.is_checkpoint(prefix) else fx.weights_of(g)
+    tf_act, tf_pred = g["act"], g["pred"]
+    decided = np.abs(tf_act[:, 1] - tf_act[:, 0]) > 1e-3
+    for fold in (True, False):
+        eng = Engine(max_batch=16, fold_fc=fold)
+        eng.load_weights(w)
+        act, pred = eng.run(*(feats[k] for k in KEYS))
+        eng.close()
+        assert np.abs(act - tf_act).max() <= 2e-5 and np.abs(_norm(act) - _norm(tf_act)).max() <= 1e-4
+        assert (pred[decided] == tf_pred[decided]).all()

@@ -230,6 +230,29 @@ def test_other_kmer_and_signal_lengths(geom, precision):
     eng.close()
 
 
+@pytest.mark.parametrize("geom,batch", [(dict(kmer_len=17, signal_len=128), 1024), (dict(kmer_len=17, signal_len=40), 2560),
+                                        (dict(kmer_len=17, signal_len=62), 1536)])
+def test_short_signals_at_big_batches(geom, batch):
+    """A non-default --cent_signals_len with a batch big enough for stem23_kernel's fullest tiles (spt = 96 // wa whole
+    sites): the T tile's halo rows pushed its LDS request past the 80 KB the kernel may ask for (wa = 32 at >= 770
+    sites, wa = 10 at >= 2300) and every forward failed at launch. The planner now shrinks the tile; sampled sites
+    against the oracle, and the bits of a site must not depend on the batch it travels in."""
+    from deepsignal_amd import weights as W
+    from oracle import oracle
+    w = W.random_weights(seed=35, lstm_bias_std=0.1, **geom)
+    feats = synth.synthetic_features(batch, seed=9, **geom)
+    keys = ("kmer", "means", "stds", "sanums", "signals")
+    eng = _engine(w, max_batch=batch, **geom)
+    act, pred = eng.run(*(feats[k] for k in keys))
+    assert np.isfinite(act).all()
+    sel = np.random.default_rng(1).choice(batch, 96, replace=False)
+    o_act, o_pred = oracle.forward(w, {k: v[sel] for k, v in feats.items()}, "f32", **geom)
+    _check_outputs(act[sel], pred[sel], o_act, o_pred)
+    a2, p2 = eng.run(*(feats[k][sel[:70]] for k in keys))
+    assert np.array_equal(a2, act[sel[:70]]) and np.array_equal(p2, pred[sel[:70]])
+    eng.close()
+
+
 def test_submit_wait_matches_run(small_weights):
     """Asynchronous host boundary (ds_submit / ds_wait): tickets waited in order give the bits of the blocking run();
     over-subscription and stale tickets are refused."""

@@ -31,4 +31,4 @@ for name, a in agg.items():
     print('%-44s n %4d  mean %8.1f us  GUI_ACTIVE/duration %.2f GHz  MFMA pipe busy %5.1f %% (of GUI_ACTIVE)  %5.1f %% (of duration x %.2f GHz)' % (
         name, a['n'], a['dur_us'] / a['n'], a['gui'] / a['dur_us'] / 1e3, 100 * util, 100 * util2, INKERNEL_CLOCK_GHZ))
 if len(sys.argv) > 2:
-    json.dump({'source': 'rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -- python3 tools/probe_engine.py fp32 512 (every launch on one stream)', 'kernels': out}, open(sys.argv[2], 'w'), indent=1)
+    json.dump({'source': 'rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -- python3 tools/probe_engine.py fp32 512 threestep (every launch on one stream)', 'kernels': out}, open(sys.argv[2], 'w'), indent=1)
