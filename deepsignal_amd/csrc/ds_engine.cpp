@@ -56,7 +56,8 @@ struct Op {
     const float* in = nullptr;
     float* out = nullptr;
     int a = 0, b = 0, c = 0, d = 0;
-    FusedArgs fa{};                       // OP_FUSED
+    FusedArgs fa{};                       // OP_FUSED (bf16 modes: the first module of the chain)
+    FusedChain fc{};                      // OP_FUSED, bf16 modes: consecutive modules of one width class in ONE launch
     Stem23Args sa{};                      // OP_STEM23
     HeadFoldedArgs ha{};                  // OP_HEADF
     int tm = 0;
@@ -157,6 +158,7 @@ struct ds_handle {
     bool no_fused = false;    // DS_TUNE_NO_FUSED: layer-granular inception modules instead of the fused kernel
     bool fold_fc = false;     // joint model folded into one J x class_num matrix (fp32, not DS_TUNE_NO_FOLD_FC, not debug)
     bool serial = false;      // DS_TUNE_SERIAL: every launch of a forward on ONE stream (stand-alone kernel times)
+    bool serial_modules = false;   // DS_TUNE_NO_CHAIN: bf16 modes, one launch per inception module instead of one per width class
     int fuse_max_spt = 8;     // sites per fused-module tile, upper bound
     int fuse_min_tiles = 128; // fused-module grids keep at least this many workgroups when the batch allows it
     bool lstm_bf16 = false;   // DS_PRECISION_BF16_ALL: additionally bf16 h / weight operands in the LSTM matmuls (fp32 accumulate,
@@ -540,10 +542,14 @@ int alloc_workspace(ds_handle* h)
     if (!rc) h->cur->pred = reinterpret_cast<int*>(h->cur->act + B * h->C);
     if (h->bf16) A(&h->cur->joint, B * (size_t)h->JP / 2);
     // module outputs: ping-pong pair normally; one buffer per module in debug mode (for taps)
-    const int nbuf = h->debug ? NMOD : 2;
+    // bf16 modes chain the modules of a width class inside one launch (ds_internal.h FusedChain): a workgroup that is already
+    // in module 5 must not write into the buffer a slower workgroup still reads module 4's (stride-2 pooled, differently
+    // tiled) input from, so a chain alternates between the two buffers that do NOT hold its first module's input: three buffers
+    const int nbuf = h->debug ? NMOD : (h->bf16 ? 3 : 2);
+    static const int kChainBuf[NMOD] = {0, 1, 0, /* reads 0 */ 1, 2, 1, 2, 1, /* reads 1 */ 0, 2, 0};
     float* bufs[NMOD] = {nullptr};
     for (int i = 0; i < nbuf; ++i) A(&bufs[i], B * h->wa * INC_OUT);
-    for (int m = 0; m < NMOD; ++m) h->cur->modout[m] = bufs[h->debug ? m : (m & 1)];
+    for (int m = 0; m < NMOD; ++m) h->cur->modout[m] = bufs[h->debug ? m : (h->bf16 ? kChainBuf[m] : (m & 1))];
     if (!rc && h->bf16) {
         // bf16 rows are [.., 256] with channels 240..255 (and the joint's tail) never written: they must read as zero
         hipError_t e = hipSuccess;
@@ -723,7 +729,18 @@ int build_plan(ds_handle* h, int n, Plan* plan)
             op.fa.dbg = h->dbg_stamps ? h->dbg_stamps + (size_t)m * 1024 * 16 : nullptr;
             op.flops = 2.0 * M * ((double)cin * 240 + 96 * 48 + 160 * 48 + 96 * 64 + 64 * 48);
             if (first_plan) h->stages[st].flops_per_site += op.flops / n;
-            add_ew_op(cnn, op);
+            // bf16 modes: a module joins the launch of the module before it when both tile the batch alike and it reads that
+            // module's rows as they are (no stride-2 pool in between): every workgroup then takes its sites through the whole
+            // chain (ds_internal.h FusedChain). Stage times of a chain are booked on its first module.
+            Op* prev = (bf && !cnn.empty() && cnn.back().kind == OP_FUSED) ? &cnn.back() : nullptr;
+            if (prev && prev->fc.nmod < FUSED_CHAIN_MAX && op.fa.pool_win == 0 && prev->fa.W == W && prev->fa.spt == best_spt &&
+                prev->tm == op.tm && prev->fc.m[prev->fc.nmod - 1].Y == op.fa.X && op.fa.Y != prev->fc.m[0].X && !h->serial_modules) {
+                prev->fc.m[prev->fc.nmod++] = op.fa;
+                prev->flops += op.flops;
+            } else {
+                op.fc.m[0] = op.fa; op.fc.nmod = 1;
+                add_ew_op(cnn, op);
+            }
         } else {
         {   // five 1x1 convs on the module input + branch1 (maxpool on load)   layers.py:90-101,103,112,121-126
             // bf16 mode: rows have a 256-channel pitch (cin = 240 inputs carry 16 zero channels, matched by zero weight rows)
@@ -1007,7 +1024,7 @@ int issue_op(ds_handle* h, Plan& plan, const Op& op, hipStream_t s)
         HIPCHK(h, launch_head_folded(op.ha, s));
         break;
     case OP_FUSED:
-        if (h->bf16) HIPCHK(h, launch_inception_fused_bf16(op.tm, op.fa, s));
+        if (h->bf16) HIPCHK(h, launch_inception_fused_bf16(op.tm, op.fc, s));
         else HIPCHK(h, launch_inception_fused(op.tm, op.fa, s));
         break;
     case OP_HEAD:
@@ -1266,6 +1283,7 @@ static int ds_create_impl(const ds_config* cfg, ds_handle** out)
     const int32_t flags = cfg->reserved[2];
     h->no_fused = (flags & DS_TUNE_NO_FUSED) != 0;
     h->serial = (flags & DS_TUNE_SERIAL) != 0;
+    h->serial_modules = (flags & DS_TUNE_NO_CHAIN) != 0;
     h->fold_fc = !(flags & DS_TUNE_NO_FOLD_FC) && cfg->reserved[0] == 0 && cfg->class_num <= 16;
     h->lstm_t = cfg->reserved[3] == DS_LSTM_TILING_NARROW ? 1 : cfg->reserved[3] == DS_LSTM_TILING_WIDE ? 0 : -1;
     h->lstm_variant = cfg->reserved[3];

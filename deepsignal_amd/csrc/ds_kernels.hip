@@ -1524,17 +1524,31 @@ hipError_t launch_inception_fused(int tm, const FusedArgs& a, hipStream_t s)
 // 32/64-channel intermediates live in LDS as bf16 (T1 row = 104, T2 row = 72 elements: odd numbers of 16-B
 // slots, conflict-free ds_read_b128), accumulation / bias / ReLU / residual are fp32 and every value is rounded
 // to bf16 (nearest even) exactly once, when it is stored. HBM traffic per module row: 512 B in, 480 B out.
+//
+// Roofline: HBM. A 96-row tile moves 93 KB for ~2 us of matrix-pipe time, so what matters is how many bytes a CU keeps
+// in flight, not its MFMA schedule. Round 3 form: TWO workgroups per CU (<= 128 VGPRs, <= 76 KB of LDS each), so one
+// tile's load / store phases run under the other's MFMAs:
+//   * the 3-tap max-pooled copy of the input tile (branch 1's operand, 50 KB) is gone: waves 6, 7 pool their fragments
+//     on the fly (three ds_read_b128 + v_pk_max_i16 per fragment), as the fp32 kernel does;
+//   * the P1 weights stream through a ring of four fragments per wave instead of sixteen resident ones;
+//   * EVERY output leaves through an LDS tile as whole 16-byte pieces of contiguous row segments (b1|b2: 192 B, then
+//     b3|b4|b5: 288 B) -- the direct form stored 8 bytes per lane into 32 different rows per instruction.
 #ifndef DS_FUSEDB_WPS
-#define DS_FUSEDB_WPS 2
+#define DS_FUSEDB_WPS 4
+#endif
+#ifndef DS_FUSEDB_RING
+#define DS_FUSEDB_RING 3      // register stages of a wave's P1 weight fragments (four spill at 128 VGPRs)
 #endif
 constexpr int B_LDA = 132;      // staged input row stride in units (256 channels + 8 pad: 33 x 16 B, odd)
-constexpr int B_LD1 = 52;       // T1 / output-tile row stride in units (96 channels + 8 pad)
+constexpr int B_LD1 = 52;       // T1 / b1|b2 output-tile row stride in units (96 channels + 8 pad)
 constexpr int B_LD2 = 36;       // T2 row stride in units (64 channels + 8 pad)
+constexpr int B_LDY = 76;       // b3|b4|b5 output-tile row stride in units (144 channels + 8 pad: 19 x 16 B, odd)
+constexpr int B_T2OFF = 96;     // T2 block starts B_T2OFF units per tile row into the (dead) input tile: B_LDY <= 96, 96 + B_LD2 <= B_LDA
 
 size_t inception_fused_bf16_lds_bytes(int tm, int W, int spt)
 {
     const int tr32 = tm * 32;
-    return (size_t)(2 * tr32 * B_LDA + (spt * (W + 4) + 5) * B_LD1 + tr32 + 192) * sizeof(float);    // input + pooled tile (T2, Ys alias the input tile) | T1 | rowmap | 3x64 biases
+    return (size_t)(tr32 * B_LDA + (spt * (W + 4) + 5) * B_LD1 + tr32 + 192) * sizeof(float);    // input tile (output tiles and T2 alias it) | T1 | rowmap | 3x64 biases
 }
 
 __device__ __forceinline__ floatx16 mfma_bf(float4 a, float4 b, floatx16 c)
@@ -1566,38 +1580,85 @@ __device__ __forceinline__ void fusedb_conv_unit(const float* T1, int rm, int co
 }
 
 template <int TM>
-__global__ __launch_bounds__(512, DS_FUSEDB_WPS) void inception_fused_bf16_kernel(const FusedArgs a)
+__global__ __launch_bounds__(512, TM >= 2 ? DS_FUSEDB_WPS : 2) void inception_fused_bf16_kernel(const FusedChain c)
 {
     constexpr int TR32 = TM * 32;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* As = smem;                         // [TR32][B_LDA] the WHOLE input tile (256 channels per row)
-    float* Ys = smem;                         // [TR32][B_LD1] b1|b2 output tile, aliases As once P1 is done
-    float* T2 = smem + TR32 * B_LD1;          // [TR32][B_LD2], aliases As too (behind Ys; B_LD1 + B_LD2 <= B_LDA)
-    float* Ap = smem + TR32 * B_LDA;          // [TR32][B_LDA] 3-tap max-pooled input tile (branch 1's operand)
-    float* T1 = Ap + TR32 * B_LDA;            // [spt*(W+4)+5][B_LD1]
+    float* const As = smem;                         // [TR32][B_LDA] the WHOLE input tile (256 channels per row); dead after P1, then:
+    float* const Ys = smem;                         //   [TR32][B_LD1] b1|b2 output tile (flushed before P2)
+    float* const Y2 = smem;                         //   [TR32][B_LDY] b3|b4|b5 output tile (over the flushed b1|b2 tile)
+    float* const T2 = smem + TR32 * B_T2OFF;        //   [TR32][B_LD2] branch 5's 64-channel intermediate
+    float* const T1 = smem + TR32 * B_LDA;          // [spt*(W+4)+5][B_LD1]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int W = a.W, spt = a.spt, cinu = a.cin;          // cin in units (128)
-    int* rowmap = reinterpret_cast<int*>(T1 + (spt * (W + 4) + 5) * B_LD1);
+    const int W = c.m[0].W, spt = c.m[0].spt, cinu = c.m[0].cin;          // cin in units (128); the same for every module of a chain
+    int* const rowmap = reinterpret_cast<int*>(T1 + (spt * (W + 4) + 5) * B_LD1);
     float* const Bs = reinterpret_cast<float*>(rowmap + TR32);                    // [3][64] biases of b5b | b3b | b4b
     unsigned short* const T1h = reinterpret_cast<unsigned short*>(T1);
     unsigned short* const T2h = reinterpret_cast<unsigned short*>(T2);
     unsigned short* const Ysh = reinterpret_cast<unsigned short*>(Ys);
-    const int ntiles = (a.n_sites + spt - 1) / spt;
+    unsigned short* const Y2h = reinterpret_cast<unsigned short*>(Y2);
     const int h4 = 4 * (lane >> 5), rlane = lane & 31;
-    const bool pooled_in = a.pool_win > 0;
     constexpr int NSLOT = TR32 * 32 / 512;    // 16-B slots of the input tile per thread: 2 * TM
 
-    const bool stamp = a.dbg != nullptr && lane == 0 && (wave == 0 || wave == 7) && blockIdx.x < DBG_MAX_WGS;
-    unsigned long long* sdst = a.dbg + ((size_t)blockIdx.x * 2 + (wave == 7)) * 8;
-#define DS_STAMP(i) do { if (stamp) sdst[i] = __builtin_amdgcn_s_memtime(); } while (0)
+    const int site0 = blockIdx.x * spt;
+    const int TRv = min(spt, c.m[0].n_sites - site0) * W;          // valid rows of this tile
+    typedef __attribute__((address_space(1))) unsigned short* gbf16w;
 
-    // Input rows of one tile -> registers. With bf16 MFMAs a K chunk is only ~200 matrix-pipe cycles, far too short to
-    // hide a global load behind, so nothing is pipelined per chunk: every thread requests its share of the WHOLE
-    // 96 x 512 B tile at once, the tile is parked in LDS and P1 runs its 16 k-steps back to back out of LDS.
+    // relu + round four consecutive channels to bf16 -> one 8-byte group
+    auto pack4 = [](float x0, float x1, float x2, float x3) -> uint2 {
+        return make_uint2((unsigned)f2bf(fmaxf(x0, 0.0f)) | ((unsigned)f2bf(fmaxf(x1, 0.0f)) << 16),
+                          (unsigned)f2bf(fmaxf(x2, 0.0f)) | ((unsigned)f2bf(fmaxf(x3, 0.0f)) << 16));
+    };
+
+    // static wave -> unit assignment of P2 (wave-uniform). kind: 0 none, 1 b5b, 2 b3b, 3 b4b
+    int a1k = 0, a1m = 0, a1n = 0, a2k = 0, a2m = 0, a2n = 0, a3m = -1;
+    int b1k = 0, b1m = 0, b1n = 0;
+    if (TM == 3) {
+        if (wave < 6) { a1k = 1; a1m = wave % 3; a1n = wave / 3; }
+        else { a1k = 2; a1m = 0; a1n = wave - 6; a2k = 2; a2m = 1; a2n = wave - 6; a3m = 2; }    // three m-tiles on one set of weights
+        if (wave >= 2) { b1k = 3; b1m = (wave - 2) % 3; b1n = (wave - 2) / 3; }
+    } else if (TM == 2) {
+        if (wave < 4) { a1k = 1; a1m = wave & 1; a1n = wave >> 1; }
+        else { a1k = 2; a1m = wave & 1; a1n = (wave - 4) >> 1; }
+        if (wave >= 2 && wave < 6) { b1k = 3; b1m = (wave - 2) & 1; b1n = (wave - 2) >> 1; }
+    } else {
+        if (wave < 2) { a1k = 1; a1n = wave; }
+        else if (wave < 4) { a1k = 2; a1n = wave - 2; }
+        else if (wave < 6) { a1k = 3; a1n = wave - 4; }
+    }
+
+    // once per workgroup: the tile's row map and the zero halo rows of T1 (every module of the chain rewrites T1's interior
+    // rows completely and never touches the halos)
+    for (int i = tid; i < (spt * (W + 4) + 5) * (B_LD1 / 4); i += 512)
+        reinterpret_cast<float4*>(T1)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (tid < TR32)
+        rowmap[tid] = tid < TRv ? (tid / W) * (W + 4) + 2 + tid % W : spt * (W + 4) + 2;
+
+    // ---- the modules of the chain, one after the other on THIS tile: module k + 1 reads the rows module k has just written
+    // (same workgroup, so the rows come back from this XCD's L2 instead of HBM and no launch boundary sits between them)
+    for (int mi = 0; mi < c.nmod; ++mi) {
+    const FusedArgs& a = c.m[mi];
+    // Every per-lane quantity of the body derives from this opaque copy of the thread index: hipcc otherwise hoists ~100
+    // loop-invariant per-lane addresses out of the module loop and spills them (the kernel lives on 128 VGPRs).
+    int tid_opaque = threadIdx.x, wave_opaque = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    asm volatile("" : "+v"(tid_opaque), "+s"(wave_opaque));
+    const int tid = tid_opaque, lane = tid & 63, h4 = 4 * (lane >> 5), rlane = lane & 31, wave = wave_opaque;
+    const bool pooled_in = a.pool_win > 0;
+    const bool stamp = a.dbg != nullptr && lane == 0 && (wave == 0 || wave == 7) && blockIdx.x < DBG_MAX_WGS;
+    // (the destination is recomputed at every stamp: a pointer held in VGPRs for the whole kernel costs two of the 128)
+#define DS_STAMP(i) do { if (stamp) (a.dbg + ((size_t)blockIdx.x * 2 + (wave == 7)) * 8)[i] = __builtin_amdgcn_s_memtime(); } while (0)
+    DS_STAMP(0);
+    // first output row of the tile; formed where it is used (a 64-bit value carried across P1 is a spill at 128 VGPRs)
+    auto out_rows = [&]() -> gbf16w {
+        return (gbf16w)(reinterpret_cast<unsigned short*>(a.Y) + (size_t)__builtin_amdgcn_readfirstlane(site0) * W * 256);
+    };
+    auto unit_Bp = [&](int k) { return k == 1 ? a.Bp5b : k == 2 ? a.Bp3b : a.Bp4b; };
+    auto unit_taps = [&](int k) { return k == 3 ? 5 : 3; };
+
+    // ---- the WHOLE input tile is requested at once (a bf16 K chunk is ~200 matrix-pipe cycles: nothing hides behind it;
+    // the other workgroup of the CU computes meanwhile)
     float4 st[NSLOT];
-    auto request_tile = [&](int tile) {
-        const int site0 = tile * spt;
-        const int TRv = min(spt, a.n_sites - site0) * W;
+    {
         const size_t grow0 = (size_t)site0 * W;
         if (!pooled_in) {
 #pragma unroll
@@ -1621,237 +1682,241 @@ __global__ __launch_bounds__(512, DS_FUSEDB_WPS) void inception_fused_bf16_kerne
                 st[i] = bf8max_nn(bf8max_nn(gload4(sb + (size_t)ia * cinu), gload4(sb + (size_t)ib * cinu)), gload4(sb + (size_t)ic * cinu));
             }
         }
-    };
-    if ((int)blockIdx.x < ntiles) request_tile(blockIdx.x);
-    if (tid < 192) Bs[tid] = gload((tid < 64 ? a.bias5b : tid < 128 ? a.bias3b : a.bias4b) + (tid & 63));
-    const float* const bp = a.Bp1 + ((size_t)wave * ((cinu + 31) / 32 * 4) * 64 + lane) * 4;
-
-    // relu + round four consecutive channels to bf16 -> one 8-byte group
-    auto pack4 = [](float x0, float x1, float x2, float x3) -> uint2 {
-        return make_uint2((unsigned)f2bf(fmaxf(x0, 0.0f)) | ((unsigned)f2bf(fmaxf(x1, 0.0f)) << 16),
-                          (unsigned)f2bf(fmaxf(x2, 0.0f)) | ((unsigned)f2bf(fmaxf(x3, 0.0f)) << 16));
-    };
-    typedef unsigned int u2v __attribute__((ext_vector_type(2)));
-
-    // static wave -> unit assignment of P2 (wave-uniform). kind: 0 none, 1 b5b, 2 b3b, 3 b4b
-    int a1k = 0, a1m = 0, a1n = 0, a2k = 0, a2m = 0, a2n = 0;
-    int b1k = 0, b1m = 0, b1n = 0, b2k = 0, b2m = 0, b2n = 0;
-    if (TM == 3) {
-        if (wave < 6) { a1k = 1; a1m = wave % 3; a1n = wave / 3; }
-        else { a1k = 2; a1m = 0; a1n = wave - 6; a2k = 2; a2m = 1; a2n = wave - 6; }
-        if (wave >= 2) { b1k = 3; b1m = (wave - 2) % 3; b1n = (wave - 2) / 3; }
-        if (wave == 2 || wave == 3) { b2k = 2; b2m = 2; b2n = wave - 2; }
-    } else if (TM == 2) {
-        if (wave < 4) { a1k = 1; a1m = wave & 1; a1n = wave >> 1; }
-        else { a1k = 2; a1m = wave & 1; a1n = (wave - 4) >> 1; }
-        if (wave >= 2 && wave < 6) { b1k = 3; b1m = (wave - 2) & 1; b1n = (wave - 2) >> 1; }
-    } else {
-        if (wave < 2) { a1k = 1; a1n = wave; }
-        else if (wave < 4) { a1k = 2; a1n = wave - 2; }
-        else if (wave < 6) { a1k = 3; a1n = wave - 4; }
     }
-    auto unit_Bp = [&](int k) { return k == 1 ? a.Bp5b : k == 2 ? a.Bp3b : a.Bp4b; };
-    auto unit_taps = [&](int k) { return k == 3 ? 5 : 3; };
-
-    float4 bv[4];       // this wave's P1 bias (register 4g+e of every accumulator), resident across tiles
+    // every other global request of the prologue goes out behind the tile's, before anything waits: the unit biases, this
+    // wave's P1 bias (+ the tail's BN shift on the b5 stem columns) -- written with per-g branches these were four serialized
+    // L2 round trips in front of every tile
+    const float bsv = tid < 192 ? gload((tid < 64 ? a.bias5b : tid < 128 ? a.bias3b : a.bias4b) + (tid & 63)) : 0.0f;
+    float4 bv[4], tv[4];
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-        bv[g] = gload4(a.bias1 + wave * 32 + 8 * g + h4);                  // bias1 is zero-padded to 256
-        if (wave < 2) {                                                     // b5 stem columns also carry the tail's BN shift
-            const float4 t = gload4(a.bias5c + wave * 32 + 8 * g + h4);     // (zero-padded to 64)
-            bv[g].x += t.x; bv[g].y += t.y; bv[g].z += t.z; bv[g].w += t.w;
+        bv[g] = gload4(a.bias1 + wave * 32 + 8 * g + h4);                               // bias1 is zero-padded to 256
+        tv[g] = gload4(a.bias5c + (wave < 2 ? wave : 0) * 32 + 8 * g + h4);             // zero-padded to 64; used by waves 0, 1 only
+    }
+    if (tid < 192) Bs[tid] = bsv;
+#pragma unroll
+    for (int i = 0; i < NSLOT; ++i) {
+        const int id = tid + i * 512, row = id >> 5, q = id & 31;
+        *reinterpret_cast<float4*>(As + row * B_LDA + q * 4) = st[i];
+    }
+    // P1 weights of this wave's n-tile (16 fragments, L2-resident) through a ring of DS_FUSEDB_RING; requested once the tile's
+    // staging registers are free (the kernel lives on <= 128 VGPRs)
+    // (wave-uniform base + one 32-bit lane offset: scalar address arithmetic, no 64-bit per-lane pointers in the loop)
+    const char* const bp_base = reinterpret_cast<const char*>(a.Bp1) + (size_t)wave * ((cinu + 31) / 32 * 4) * 1024;
+    const unsigned lane16 = (unsigned)lane * 16;
+    auto bfrag = [&](int g) __attribute__((always_inline)) { return gload4(reinterpret_cast<const float*>(bp_base + g * 1024 + lane16)); };
+    float4 bw[DS_FUSEDB_RING];
+#pragma unroll
+    for (int g = 0; g < DS_FUSEDB_RING; ++g) bw[g] = bfrag(g);
+    // Every MFMA of this kernel is issued TRANSPOSED: mfma(weight fragment, activation fragment) gives (X W)^T, so
+    // a lane ends up holding, for ONE activation row (lane & 31), 4 x 4 consecutive output channels
+    // (register 4g+e <-> channel 32*ntile + 8g + 4*(lane >> 5) + e). Results leave as packed 8-byte groups of four
+    // bf16 instead of 2-byte scalars, and the bias is simply the accumulator's initial value.
+    floatx16 acc[TM];
+    {
+        const float tsel = wave < 2 ? 1.0f : 0.0f;      // b5 stem columns also carry the tail's BN shift (exact: x + 1 * t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 b = make_float4(fmaf(tsel, tv[g].x, bv[g].x), fmaf(tsel, tv[g].y, bv[g].y), fmaf(tsel, tv[g].z, bv[g].z),
+                                         fmaf(tsel, tv[g].w, bv[g].w));
+#pragma unroll
+            for (int mt = 0; mt < TM; ++mt) {
+                acc[mt][4 * g + 0] = b.x; acc[mt][4 * g + 1] = b.y;
+                acc[mt][4 * g + 2] = b.z; acc[mt][4 * g + 3] = b.w;
+            }
         }
     }
+    __syncthreads();   // input tile, zeroed T1, rowmap, biases are in place
+    DS_STAMP(1);
 
-    {   // one tile per workgroup. (A persistent loop with next-tile prefetch was tried: hipcc hoists ~100 loop-invariant
-        // address registers out of it, spills them, and the scratch reloads cost more than the hidden latency.)
-        const int tile = blockIdx.x;
-        const int site0 = tile * spt;
-        const int TRv = min(spt, a.n_sites - site0) * W;
-        __attribute__((address_space(1))) unsigned short* const Yg =
-            (__attribute__((address_space(1))) unsigned short*)(reinterpret_cast<unsigned short*>(a.Y) + (size_t)site0 * W * 256);
-        DS_STAMP(0);
-        // P1 weights of this wave's n-tile (16 fragments, L2-resident): in flight while the tile is parked
-        float4 bw[16];
+    // ---- P1: [rows x 256] x [256 x 256], 16 k-steps back to back out of LDS. Waves 6, 7
+    // (branch 1) take the 3-tap max of their fragment and its two neighbour rows -- maxpool(3, stride 1, SAME), a missing
+    // neighbour at a site edge = the own row ("padded taps ignored")        layers.py:90-91
+    auto run_p1 = [&](auto pool_tag) __attribute__((always_inline)) {
+        constexpr bool POOL = decltype(pool_tag)::value;
+        const float* const src = As + rlane * B_LDA + h4;
+        if (!POOL) {
+            // ONE fragment buffer: the reads of k-step g + 1 are issued right behind the MFMAs of k-step g (which have
+            // taken their operands by then) and land while those run -- the look-ahead of a double buffer without its registers
+            float4 af[TM];
 #pragma unroll
-        for (int g = 0; g < 16; ++g) bw[g] = gload4(bp + g * 256);
-
-        // Every MFMA of this kernel is issued TRANSPOSED: mfma(weight fragment, activation fragment) gives (X W)^T, so
-        // a lane ends up holding, for ONE activation row (lane & 31), 4 x 4 consecutive output channels
-        // (register 4g+e <-> channel 32*ntile + 8g + 4*(lane >> 5) + e). Results leave as packed 8-byte groups of four
-        // bf16 (LDS and HBM) instead of 2-byte scalars, and the bias is simply the accumulator's initial value.
-        floatx16 acc[TM];
-        {
+            for (int mt = 0; mt < TM; ++mt) af[mt] = *reinterpret_cast<const float4*>(src + mt * 32 * B_LDA);
 #pragma unroll
-            for (int mt = 0; mt < TM; ++mt)
+            for (int g = 0; g < 16; ++g) {
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    acc[mt][4 * g + 0] = bv[g].x; acc[mt][4 * g + 1] = bv[g].y;
-                    acc[mt][4 * g + 2] = bv[g].z; acc[mt][4 * g + 3] = bv[g].w;
+                for (int mt = 0; mt < TM; ++mt) acc[mt] = mfma_bf(bw[g % DS_FUSEDB_RING], af[mt], acc[mt]);
+                if (g + DS_FUSEDB_RING < 16) bw[g % DS_FUSEDB_RING] = bfrag(g + DS_FUSEDB_RING);
+                if (g + 1 < 16) {
+#pragma unroll
+                    for (int mt = 0; mt < TM; ++mt) af[mt] = *reinterpret_cast<const float4*>(src + mt * 32 * B_LDA + (g + 1) * 8);
                 }
-        }
-
-        for (int i = tid; i < (spt * (W + 4) + 5) * B_LD1; i += 512) T1[i] = 0.0f;   // halos (and everything else) = 0
-        if (tid < TR32)
-            rowmap[tid] = tid < TRv ? (tid / W) * (W + 4) + 2 + tid % W : spt * (W + 4) + 2;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+            // pooled operand: raw[mt] = (own, previous, next) row fragments of k-step g, requested one k-step ahead; per
+            // m-tile: 3-tap max (8 x v_pk_max_i16) -> MFMA -> request the next k-step's three fragments into the registers
+            // just consumed. The max of m-tile mt + 1 issues under the MFMA of m-tile mt.
+            int om[TM], op[TM];
 #pragma unroll
-        for (int i = 0; i < NSLOT; ++i) {
-            const int id = tid + i * 512, row = id >> 5, q = id & 31;
-            *reinterpret_cast<float4*>(As + row * B_LDA + q * 4) = st[i];
-        }
-        __syncthreads();   // input tile, zeroed T1, rowmap (and, first time, the biases) are in place
-        // branch 1's maxpool(3, stride 1, SAME) of the tile, once, by everybody: pooled row = max(previous, own, next),
-        // a missing neighbour at a site edge = the own row ("padded taps ignored")        layers.py:90-91
+            for (int mt = 0; mt < TM; ++mt) {
+                const int row = mt * 32 + rlane, w = row % W;
+                om[mt] = (row < TRv && w > 0) ? -B_LDA : 0;
+                op[mt] = (row < TRv && w < W - 1) ? B_LDA : 0;
+            }
+            float4 raw[TM][3];
 #pragma unroll
-        for (int i = 0; i < NSLOT; ++i) {
-            const int id = tid + i * 512, row = id >> 5, q = id & 31;
-            const int w = row % W;
-            const int om = (row < TRv && w > 0) ? -B_LDA : 0, op = (row < TRv && w < W - 1) ? B_LDA : 0;
-            const float* src = As + row * B_LDA + q * 4;
-            *reinterpret_cast<float4*>(Ap + row * B_LDA + q * 4) =
-                bf8max_nn(bf8max_nn(*reinterpret_cast<const float4*>(src), *reinterpret_cast<const float4*>(src + om)),
-                          *reinterpret_cast<const float4*>(src + op));
-        }
-        __syncthreads();   // the pooled tile is complete
-        DS_STAMP(1);
-
-        {
-            const float* const src = (wave >= 6 ? Ap : As) + rlane * B_LDA + h4;      // wave-uniform choice
+            for (int mt = 0; mt < TM; ++mt) {
+                const float* q = src + mt * 32 * B_LDA;
+                raw[mt][0] = *reinterpret_cast<const float4*>(q);
+                raw[mt][1] = *reinterpret_cast<const float4*>(q + om[mt]);
+                raw[mt][2] = *reinterpret_cast<const float4*>(q + op[mt]);
+            }
 #pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {          // four k-steps at a time: bounds how many fragments are in flight
-                float4 af[4][TM];
+            for (int g = 0; g < 16; ++g) {
 #pragma unroll
-                for (int g = 0; g < 4; ++g)
-#pragma unroll
-                    for (int mt = 0; mt < TM; ++mt)
-                        af[g][mt] = *reinterpret_cast<const float4*>(src + mt * 32 * B_LDA + (g4 * 4 + g) * 8);
-#pragma unroll
-                for (int g = 0; g < 4; ++g)
-#pragma unroll
-                    for (int mt = 0; mt < TM; ++mt) acc[mt] = mfma_bf(bw[g4 * 4 + g], af[g][mt], acc[mt]);
+                for (int mt = 0; mt < TM; ++mt) {
+                    const float4 af = bf8max_nn(bf8max_nn(raw[mt][0], raw[mt][1]), raw[mt][2]);
+                    if (g + 1 < 16) {
+                        const float* q = src + mt * 32 * B_LDA + (g + 1) * 8;
+                        raw[mt][0] = *reinterpret_cast<const float4*>(q);
+                        raw[mt][1] = *reinterpret_cast<const float4*>(q + om[mt]);
+                        raw[mt][2] = *reinterpret_cast<const float4*>(q + op[mt]);
+                    }
+                    acc[mt] = mfma_bf(bw[g % DS_FUSEDB_RING], af, acc[mt]);
+                }
+                if (g + DS_FUSEDB_RING < 16) bw[g % DS_FUSEDB_RING] = bfrag(g + DS_FUSEDB_RING);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        DS_STAMP(2);
-        __syncthreads();   // all fragment reads of the input tile are done before the output tile aliases it
-        float4 pf[10];
-        if (a1k) fusedb_unit_prefetch(unit_Bp(a1k), unit_taps(a1k), a1n, lane, pf);
+    };
+    if (wave >= 6) run_p1(FusedTagT{}); else run_p1(FusedTagF{});     // wave-uniform
+    DS_STAMP(2);
+    __syncthreads();   // all fragment reads of the input tile are done before the output tile aliases it
+    float4 pf[10];
+    // (fragments 6..9 are only loaded for the five-tap unit; defined here so that their live range starts here and not, as an
+    // "undefined on some paths" value, in front of the module loop -- sixteen registers held across P1 otherwise)
+#pragma unroll
+    for (int g = 6; g < 10; ++g) pf[g] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (a1k) fusedb_unit_prefetch(unit_Bp(a1k), unit_taps(a1k), a1n, lane, pf);
 
-        // ---- P1 epilogue (bias already inside acc)
-        if (wave >= 3 && wave <= 5) {            // b3a | b4a | b5a -> T1 (bf16), through the row map (SAME-padding halos)
+    // ---- P1 epilogue (bias already inside acc)
+    if (wave >= 3 && wave <= 5) {            // b3a | b4a | b5a -> T1 (bf16), through the row map (SAME-padding halos)
 #pragma unroll
-            for (int mt = 0; mt < TM; ++mt) {
-                const int rm = rowmap[mt * 32 + rlane];
+        for (int mt = 0; mt < TM; ++mt) {
+            const int rm = rowmap[mt * 32 + rlane];
 #pragma unroll
-                for (int g = 0; g < 4; ++g)
-                    *reinterpret_cast<uint2*>(T1h + rm * (2 * B_LD1) + (wave * 32 - 96) + 8 * g + h4) =
+            for (int g = 0; g < 4; ++g)
+                *reinterpret_cast<uint2*>(T1h + rm * (2 * B_LD1) + (wave * 32 - 96) + 8 * g + h4) =
+                    pack4(acc[mt][4 * g], acc[mt][4 * g + 1], acc[mt][4 * g + 2], acc[mt][4 * g + 3]);
+        }
+    } else if (wave != 0) {                  // b5s tail | b2 and b1 | padding -> output tile
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int col = wave * 32 + 8 * g + h4;          // groups of 4 never straddle 48 / 240
+            if (col >= 48 && col < 240) {
+                const int ycol = col < 96 ? col : col - 192;
+#pragma unroll
+                for (int mt = 0; mt < TM; ++mt)
+                    *reinterpret_cast<uint2*>(Ysh + (mt * 32 + rlane) * (2 * B_LD1) + ycol) =
                         pack4(acc[mt][4 * g], acc[mt][4 * g + 1], acc[mt][4 * g + 2], acc[mt][4 * g + 3]);
             }
-        } else if (wave != 0) {                  // b5s tail | b2 and b1 | padding -> output tile
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int col = wave * 32 + 8 * g + h4;          // groups of 4 never straddle 48 / 240
-                if (col >= 48 && col < 240) {
-                    const int ycol = col < 96 ? col : col - 192;
-#pragma unroll
-                    for (int mt = 0; mt < TM; ++mt)
-                        *reinterpret_cast<uint2*>(Ysh + (mt * 32 + rlane) * (2 * B_LD1) + ycol) =
-                            pack4(acc[mt][4 * g], acc[mt][4 * g + 1], acc[mt][4 * g + 2], acc[mt][4 * g + 3]);
-                }
-            }
         }
-        __syncthreads();   // T1 and the b1|b2 tile complete
-        DS_STAMP(3);
-        for (int idx = tid; idx < TR32 * 12; idx += 512) {      // 96 channels = 12 x 16 B per row
-            const int row = idx / 12, q = idx - row * 12;
-            if (row < TRv) {
-                const float4 v = *reinterpret_cast<const float4*>(Ys + row * B_LD1 + q * 4);
-                v4f o = {v.x, v.y, v.z, v.w};
-                *(__attribute__((address_space(1))) v4f*)(Yg + (unsigned)(row * 256 + q * 8)) = o;
-            }
-        }
-        DS_STAMP(4);
-
-        auto run_unit = [&](int kind, int mt, int nt, const float4 (&pf)[10]) {
-            floatx16 u;
-            const float* bsrc = Bs + (kind == 1 ? 0 : kind == 2 ? 64 : 128) + nt * 32 + h4;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const float4 t = *reinterpret_cast<const float4*>(bsrc + 8 * g);
-                u[4 * g] = t.x; u[4 * g + 1] = t.y; u[4 * g + 2] = t.z; u[4 * g + 3] = t.w;
-            }
-            const int row = mt * 32 + rlane;
-            const int rm = rowmap[row];
-            if (kind == 1) {          // 1x3, 32 -> 64, ReLU, to T2                            layers.py:127-131
-                fusedb_conv_unit<3>(T1, rm, 32, lane, pf, u);          // b5a = channels 64..95 = units 32..47
-#pragma unroll
-                for (int g = 0; g < 4; ++g)
-                    *reinterpret_cast<uint2*>(T2h + row * (2 * B_LD2) + nt * 32 + 8 * g + h4) = pack4(u[4 * g], u[4 * g + 1], u[4 * g + 2], u[4 * g + 3]);
-            } else {
-                // kind 2: 1x3, 32 -> 48, ReLU, to Y[96,144)   layers.py:106-110 ; kind 3: 1x5, 32 -> 48, to Y[144,192)   layers.py:115-119
-                if (kind == 2) fusedb_conv_unit<3>(T1, rm, 0, lane, pf, u);       // b3a = channels 0..31
-                else fusedb_conv_unit<5>(T1, rm, 16, lane, pf, u);                // b4a = channels 32..63
-                const int ybase = kind == 2 ? 96 : 144;
-                if (row < TRv) {
-#pragma unroll
-                    for (int g = 0; g < 4; ++g)
-                        if (nt * 32 + 8 * g < 48) {      // wave-uniform: 48 output channels = n-tile 0 and half of n-tile 1
-                            const uint2 o = pack4(u[4 * g], u[4 * g + 1], u[4 * g + 2], u[4 * g + 3]);
-                            const u2v ov = {o.x, o.y};
-                            *(__attribute__((address_space(1))) u2v*)(Yg + (unsigned)(row * 256 + ybase + nt * 32 + 8 * g + h4)) = ov;
-                        }
-                }
-            }
-        };
-
-        // ---- P2a
-        if (a1k) run_unit(a1k, a1m, a1n, pf);
-        if (a2k) {
-            fusedb_unit_prefetch(unit_Bp(a2k), unit_taps(a2k), a2n, lane, pf);
-            run_unit(a2k, a2m, a2n, pf);
-        }
-        float4 b5c[4];
-        float4 pf2[10];
-        if (wave < 2) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) b5c[g] = gload4(a.Bp5c + ((size_t)(wave * 4 + g) * 64 + lane) * 4);
-        } else if (b1k) {
-            fusedb_unit_prefetch(unit_Bp(b1k), unit_taps(b1k), b1n, lane, pf);
-            if (b2k) fusedb_unit_prefetch(unit_Bp(b2k), unit_taps(b2k), b2n, lane, pf2);
-        }
-        DS_STAMP(5);
-        __syncthreads();   // T2 complete
-        DS_STAMP(6);
-
-        // ---- P2b
-        if (wave < 2) {
-            // branch 5 tail: 1x1 64 -> 48 (BN, no ReLU) accumulated on top of the stem conv held in acc, then relu(stem + tail)
-#pragma unroll
-            for (int mt = 0; mt < TM; ++mt) {
-                const float* base = T2 + (mt * 32 + rlane) * B_LD2 + h4;
-#pragma unroll
-                for (int g = 0; g < 4; ++g) acc[mt] = mfma_bf(b5c[g], *reinterpret_cast<const float4*>(base + g * 8), acc[mt]);
-            }
-#pragma unroll
-            for (int mt = 0; mt < TM; ++mt) {
-                const int row = mt * 32 + rlane;
-                if (row < TRv) {
-#pragma unroll
-                    for (int g = 0; g < 4; ++g)
-                        if (wave * 32 + 8 * g < 48) {
-                            const uint2 o = pack4(acc[mt][4 * g], acc[mt][4 * g + 1], acc[mt][4 * g + 2], acc[mt][4 * g + 3]);
-                            const u2v ov = {o.x, o.y};
-                            *(__attribute__((address_space(1))) u2v*)(Yg + (unsigned)(row * 256 + 192 + wave * 32 + 8 * g + h4)) = ov;
-                        }
-                }
-            }
-        } else {
-            if (b1k) run_unit(b1k, b1m, b1n, pf);
-            if (b2k) run_unit(b2k, b2m, b2n, pf2);
-        }
-        DS_STAMP(7);
     }
+    __syncthreads();   // T1 and the b1|b2 tile complete
+    DS_STAMP(3);
+    gbf16w Yg = out_rows();
+    for (int idx = tid; idx < TR32 * 12; idx += 512) {      // 96 channels = 12 x 16 B per row
+        const int row = idx / 12, q = idx - row * 12;
+        if (row < TRv) {
+            const float4 v = *reinterpret_cast<const float4*>(Ys + row * B_LD1 + q * 4);
+            v4f o = {v.x, v.y, v.z, v.w};
+            *(__attribute__((address_space(1))) v4f*)(Yg + (unsigned)(row * 256 + q * 8)) = o;
+        }
+    }
+    __syncthreads();   // the b1|b2 tile has been read out: the b3|b4|b5 tile may overwrite it
+    DS_STAMP(4);
+
+    // unit (kind, m-tile, n-tile) of the second-stage convs: 1 = 1x3 32 -> 64 of branch 5 (to T2, layers.py:127-131),
+    // 2 = 1x3 32 -> 48 of branch 3 (Y[96,144), layers.py:106-110), 3 = 1x5 32 -> 48 of branch 4 (Y[144,192), layers.py:115-119)
+    auto run_unit = [&](int kind, int mt, int nt) {
+        floatx16 u;
+        const float* bsrc = Bs + (kind == 1 ? 0 : kind == 2 ? 64 : 128) + nt * 32 + h4;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 t = *reinterpret_cast<const float4*>(bsrc + 8 * g);
+            u[4 * g] = t.x; u[4 * g + 1] = t.y; u[4 * g + 2] = t.z; u[4 * g + 3] = t.w;
+        }
+        const int row = mt * 32 + rlane;
+        const int rm = rowmap[row];
+        if (kind == 1) {
+            fusedb_conv_unit<3>(T1, rm, 32, lane, pf, u);          // b5a = channels 64..95 = units 32..47
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                *reinterpret_cast<uint2*>(T2h + row * (2 * B_LD2) + nt * 32 + 8 * g + h4) = pack4(u[4 * g], u[4 * g + 1], u[4 * g + 2], u[4 * g + 3]);
+        } else {
+            if (kind == 2) fusedb_conv_unit<3>(T1, rm, 0, lane, pf, u);       // b3a = channels 0..31
+            else fusedb_conv_unit<5>(T1, rm, 16, lane, pf, u);                // b4a = channels 32..63
+            const int ybase = kind == 2 ? 0 : 48;                             // channel inside the b3|b4|b5 tile
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                if (nt * 32 + 8 * g < 48)       // wave-uniform: 48 output channels = n-tile 0 and half of n-tile 1
+                    *reinterpret_cast<uint2*>(Y2h + row * (2 * B_LDY) + ybase + nt * 32 + 8 * g + h4) =
+                        pack4(u[4 * g], u[4 * g + 1], u[4 * g + 2], u[4 * g + 3]);
+        }
+    };
+
+    // ---- P2a
+    if (a1k) run_unit(a1k, a1m, a1n);
+    if (a2k) {
+        if (a2k != a1k || a2n != a1n) fusedb_unit_prefetch(unit_Bp(a2k), unit_taps(a2k), a2n, lane, pf);     // same n-tile: same weights
+        run_unit(a2k, a2m, a2n);
+        if (a3m >= 0) run_unit(a2k, a3m, a2n);
+    }
+    if (wave < 2) {       // the tail's four weight fragments travel in the (idle) unit-weight registers
+#pragma unroll
+        for (int g = 0; g < 4; ++g) pf[g] = gload4(a.Bp5c + ((size_t)(wave * 4 + g) * 64 + lane) * 4);
+    } else if (b1k) {
+        fusedb_unit_prefetch(unit_Bp(b1k), unit_taps(b1k), b1n, lane, pf);
+    }
+    DS_STAMP(5);
+    __syncthreads();   // T2 complete
+    DS_STAMP(6);
+
+    // ---- P2b
+    if (wave < 2) {
+        // branch 5 tail: 1x1 64 -> 48 (BN, no ReLU) accumulated on top of the stem conv held in acc, then relu(stem + tail)   layers.py:132-138
+#pragma unroll
+        for (int mt = 0; mt < TM; ++mt) {
+            const float* base = T2 + (mt * 32 + rlane) * B_LD2 + h4;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) acc[mt] = mfma_bf(pf[g], *reinterpret_cast<const float4*>(base + g * 8), acc[mt]);
+        }
+#pragma unroll
+        for (int mt = 0; mt < TM; ++mt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                if (wave * 32 + 8 * g < 48)
+                    *reinterpret_cast<uint2*>(Y2h + (mt * 32 + rlane) * (2 * B_LDY) + 96 + wave * 32 + 8 * g + h4) =
+                        pack4(acc[mt][4 * g], acc[mt][4 * g + 1], acc[mt][4 * g + 2], acc[mt][4 * g + 3]);
+    } else {
+        if (b1k) run_unit(b1k, b1m, b1n);
+    }
+    __syncthreads();   // the b3|b4|b5 tile is complete
+    Yg = out_rows();
+    for (int idx = tid; idx < TR32 * 18; idx += 512) {      // 144 channels = 18 x 16 B per row, Y[96, 240)
+        const int row = idx / 18, q = idx - row * 18;
+        if (row < TRv) {
+            const float4 v = *reinterpret_cast<const float4*>(Y2 + row * B_LDY + q * 4);
+            v4f o = {v.x, v.y, v.z, v.w};
+            *(__attribute__((address_space(1))) v4f*)(Yg + (unsigned)(row * 256 + 96 + q * 8)) = o;
+        }
+    }
+    DS_STAMP(7);
 #undef DS_STAMP
+    // the next module reads the rows this one has just stored (other waves' stores included) and overwrites the LDS tile the
+    // flush above is still reading: everybody's stores and LDS reads are complete behind this barrier
+    if (mi + 1 < c.nmod) __syncthreads();
+    }   // modules of the chain
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2025,15 +2090,19 @@ hipError_t configure_fused_kernels()
     return hipFuncSetAttribute((const void*)stem23_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)STEM23_MAX_LDS);
 }
 
-hipError_t launch_inception_fused_bf16(int tm, const FusedArgs& a, hipStream_t s)
+hipError_t launch_inception_fused_bf16(int tm, const FusedChain& c, hipStream_t s)
 {
-    if (a.n_sites <= 0) return hipSuccess;
+    if (c.nmod <= 0 || c.nmod > FUSED_CHAIN_MAX || c.m[0].n_sites <= 0) return c.nmod > 0 && c.nmod <= FUSED_CHAIN_MAX ? hipSuccess : hipErrorInvalidValue;
+    const FusedArgs& a = c.m[0];
+    for (int i = 1; i < c.nmod; ++i)      // one tiling for the whole chain; only its first module may pool its input
+        if (c.m[i].W != a.W || c.m[i].spt != a.spt || c.m[i].n_sites != a.n_sites || c.m[i].cin != a.cin || c.m[i].pool_win != 0 ||
+            c.m[i].X != c.m[i - 1].Y) return hipErrorInvalidValue;
     const size_t lds = inception_fused_bf16_lds_bytes(tm, a.W, a.spt);
     const int grid = (a.n_sites + a.spt - 1) / a.spt;
     switch (tm) {
-    case 1: hipLaunchKernelGGL(inception_fused_bf16_kernel<1>, dim3(grid), dim3(512), lds, s, a); break;
-    case 2: hipLaunchKernelGGL(inception_fused_bf16_kernel<2>, dim3(grid), dim3(512), lds, s, a); break;
-    case 3: hipLaunchKernelGGL(inception_fused_bf16_kernel<3>, dim3(grid), dim3(512), lds, s, a); break;
+    case 1: hipLaunchKernelGGL(inception_fused_bf16_kernel<1>, dim3(grid), dim3(512), lds, s, c); break;
+    case 2: hipLaunchKernelGGL(inception_fused_bf16_kernel<2>, dim3(grid), dim3(512), lds, s, c); break;
+    case 3: hipLaunchKernelGGL(inception_fused_bf16_kernel<3>, dim3(grid), dim3(512), lds, s, c); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

@@ -76,6 +76,9 @@ typedef struct ds_config {
    computed once per weight load in float64 — like the BN fold, exact in real arithmetic. This bit keeps the reference's
    three steps (avgpool kernel, J x J GEMM, head); debug mode (reserved[0]) implies it, so the fc1 / signal_feat taps exist. */
 #define DS_TUNE_NO_FOLD_FC 8
+/* diagnostic (same bits out): bf16 modes launch every inception module on its own instead of chaining the modules of one
+   width class (layers.py:205-232: 1-3, 4-8, 9-11) inside one launch */
+#define DS_TUNE_NO_CHAIN 16
 /* ds_config.reserved[3] */
 #define DS_LSTM_TILING_AUTO 0    /* by forward size */
 #define DS_LSTM_TILING_NARROW 1  /* one 32-column n-tile per wave  */

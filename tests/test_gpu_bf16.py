@@ -111,3 +111,28 @@ def test_bf16_against_oracle_small(small_weights):
     o_act, o_pred = oracle.forward(small_weights, feats, "f32")
     assert np.abs(act - o_act).max() <= FP32_ACT_ATOL
     eng.close()
+
+
+@pytest.mark.parametrize("precision", ["bf16", "bf16_all"])
+def test_module_chain_gives_the_bits_of_one_launch_per_module(small_weights, precision):
+    """The bf16 modes take a tile of whole sites through all modules of a width class inside ONE launch (modules 1-3,
+    4-8, 9-11); DS_TUNE_NO_CHAIN launches every module on its own. Same arithmetic, same bits -- also on a ragged batch
+    whose last tile is partial, and with the per-module tap buffers of debug mode."""
+    feats = synth.synthetic_features(1333, seed=812)
+    args = [feats[k] for k in ("kmer", "means", "stds", "sanums", "signals")]
+    chained = _engine(small_weights, max_batch=1333, slots=1, precision=precision)
+    a1, p1 = chained.run(*args)
+    a1s, p1s = chained.run(*(a[:77] for a in args))
+    chained.close()
+    single = _engine(small_weights, max_batch=1333, slots=1, precision=precision, chain_modules=False)
+    a2, p2 = single.run(*args)
+    a2s, p2s = single.run(*(a[:77] for a in args))
+    single.close()
+    assert np.array_equal(a1, a2) and np.array_equal(p1, p2)
+    assert np.array_equal(a1s, a2s) and np.array_equal(p1s, p2s) and np.array_equal(a1s, a1[:77])
+    dbg = _engine(small_weights, max_batch=160, debug=True, precision=precision)
+    a3, _ = dbg.run(*(a[:130] for a in args))
+    m11 = dbg.intermediate("module11", (130, 23, 240))
+    dbg.close()
+    # debug mode runs the three-step joint model (bf16-operand dense layer): the same sites, a rounding apart
+    assert np.isfinite(m11).all() and np.abs(a3 - a1[:130]).max() <= 2e-3
