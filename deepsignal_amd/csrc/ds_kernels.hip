@@ -47,6 +47,11 @@ __device__ __forceinline__ float4 gload4(const float* p)
     return make_float4(v.x, v.y, v.z, v.w);
 }
 __device__ __forceinline__ float gload(const float* p) { return *(gptr1)(p); }
+__device__ __forceinline__ float4 gload4_nt(const float* p)      // global_load_dwordx4 ... nt
+{
+    const v4f v = __builtin_nontemporal_load((gptr4)(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
 __device__ __forceinline__ void gstore(float* p, float v) { *(gptr1w)(p) = v; }
 
 // ---- bf16 helpers (mixed-precision mode: bf16 operands, fp32 accumulate) ----
@@ -1536,8 +1541,21 @@ hipError_t launch_inception_fused(int tm, const FusedArgs& a, hipStream_t s)
 #ifndef DS_FUSEDB_WPS
 #define DS_FUSEDB_WPS 4
 #endif
+// input rows are read exactly once: a non-temporal load does not keep them in the XCD's L2, which then holds the rows the
+// workgroups have just WRITTEN (the next module of the chain reads those)
+#ifndef DS_FUSEDB_NT
+#define DS_FUSEDB_NT 1
+#endif
+#if DS_FUSEDB_NT
+#define DS_FUSEDB_TILE_LOAD(p) gload4_nt(p)
+#else
+#define DS_FUSEDB_TILE_LOAD(p) gload4(p)
+#endif
+#ifndef DS_FUSEDB_POOLPRIO
+#define DS_FUSEDB_POOLPRIO 2
+#endif
 #ifndef DS_FUSEDB_RING
-#define DS_FUSEDB_RING 3      // register stages of a wave's P1 weight fragments (four spill at 128 VGPRs)
+#define DS_FUSEDB_RING 2      // register stages of a wave's P1 weight fragments (2, 3: same time on MI355X; 3 and 4 spill at 128 VGPRs)
 #endif
 constexpr int B_LDA = 132;      // staged input row stride in units (256 channels + 8 pad: 33 x 16 B, odd)
 constexpr int B_LD1 = 52;       // T1 / b1|b2 output-tile row stride in units (96 channels + 8 pad)
@@ -1665,7 +1683,7 @@ __global__ __launch_bounds__(512, TM >= 2 ? DS_FUSEDB_WPS : 2) void inception_fu
             for (int i = 0; i < NSLOT; ++i) {
                 const int id = tid + i * 512, row = id >> 5, q = id & 31;
                 const int rr = row < TRv ? row : TRv - 1;
-                st[i] = gload4(a.X + (grow0 + rr) * cinu + q * 4);
+                st[i] = DS_FUSEDB_TILE_LOAD(a.X + (grow0 + rr) * cinu + q * 4);      // read once: see DS_FUSEDB_NT
             }
         } else {
             // module right after maxpool_layer2/3: staged row (site s, w) = max of the input rows 2w - pad + {0,1,2} that exist
@@ -1789,7 +1807,10 @@ __global__ __launch_bounds__(512, TM >= 2 ? DS_FUSEDB_WPS : 2) void inception_fu
             }
         }
     };
-    if (wave >= 6) run_p1(FusedTagT{}); else run_p1(FusedTagF{});     // wave-uniform
+    // the two pooling waves carry ~2x the instructions of the others per k-step and everybody waits for them at the barrier
+    // below: they get the SIMD's issue priority while they are in P1
+    if (wave >= 6) { __builtin_amdgcn_s_setprio(DS_FUSEDB_POOLPRIO); run_p1(FusedTagT{}); __builtin_amdgcn_s_setprio(0); }
+    else run_p1(FusedTagF{});     // wave-uniform
     DS_STAMP(2);
     __syncthreads();   // all fragment reads of the input tile are done before the output tile aliases it
     float4 pf[10];
@@ -1824,6 +1845,8 @@ __global__ __launch_bounds__(512, TM >= 2 ? DS_FUSEDB_WPS : 2) void inception_fu
     }
     __syncthreads();   // T1 and the b1|b2 tile complete
     DS_STAMP(3);
+    // b1|b2 rows out (whole 192-byte row segments). No barrier behind this flush: nothing writes into the tile before the
+    // barrier at the end of P2a -- the second-stage units that run in P2a keep their results in registers until then
     gbf16w Yg = out_rows();
     for (int idx = tid; idx < TR32 * 12; idx += 512) {      // 96 channels = 12 x 16 B per row
         const int row = idx / 12, q = idx - row * 12;
@@ -1833,29 +1856,29 @@ __global__ __launch_bounds__(512, TM >= 2 ? DS_FUSEDB_WPS : 2) void inception_fu
             *(__attribute__((address_space(1))) v4f*)(Yg + (unsigned)(row * 256 + q * 8)) = o;
         }
     }
-    __syncthreads();   // the b1|b2 tile has been read out: the b3|b4|b5 tile may overwrite it
     DS_STAMP(4);
 
     // unit (kind, m-tile, n-tile) of the second-stage convs: 1 = 1x3 32 -> 64 of branch 5 (to T2, layers.py:127-131),
     // 2 = 1x3 32 -> 48 of branch 3 (Y[96,144), layers.py:106-110), 3 = 1x5 32 -> 48 of branch 4 (Y[144,192), layers.py:115-119)
-    auto run_unit = [&](int kind, int mt, int nt) {
-        floatx16 u;
+    auto unit_compute = [&](int kind, int mt, int nt, floatx16& u) __attribute__((always_inline)) {
         const float* bsrc = Bs + (kind == 1 ? 0 : kind == 2 ? 64 : 128) + nt * 32 + h4;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const float4 t = *reinterpret_cast<const float4*>(bsrc + 8 * g);
             u[4 * g] = t.x; u[4 * g + 1] = t.y; u[4 * g + 2] = t.z; u[4 * g + 3] = t.w;
         }
+        const int rm = rowmap[mt * 32 + rlane];
+        if (kind == 1) fusedb_conv_unit<3>(T1, rm, 32, lane, pf, u);          // b5a = channels 64..95 = units 32..47
+        else if (kind == 2) fusedb_conv_unit<3>(T1, rm, 0, lane, pf, u);      // b3a = channels 0..31
+        else fusedb_conv_unit<5>(T1, rm, 16, lane, pf, u);                    // b4a = channels 32..63
+    };
+    auto unit_store = [&](int kind, int mt, int nt, const floatx16& u) __attribute__((always_inline)) {
         const int row = mt * 32 + rlane;
-        const int rm = rowmap[row];
         if (kind == 1) {
-            fusedb_conv_unit<3>(T1, rm, 32, lane, pf, u);          // b5a = channels 64..95 = units 32..47
 #pragma unroll
             for (int g = 0; g < 4; ++g)
                 *reinterpret_cast<uint2*>(T2h + row * (2 * B_LD2) + nt * 32 + 8 * g + h4) = pack4(u[4 * g], u[4 * g + 1], u[4 * g + 2], u[4 * g + 3]);
         } else {
-            if (kind == 2) fusedb_conv_unit<3>(T1, rm, 0, lane, pf, u);       // b3a = channels 0..31
-            else fusedb_conv_unit<5>(T1, rm, 16, lane, pf, u);                // b4a = channels 32..63
             const int ybase = kind == 2 ? 0 : 48;                             // channel inside the b3|b4|b5 tile
 #pragma unroll
             for (int g = 0; g < 4; ++g)
@@ -1865,12 +1888,21 @@ __global__ __launch_bounds__(512, TM >= 2 ? DS_FUSEDB_WPS : 2) void inception_fu
         }
     };
 
-    // ---- P2a
-    if (a1k) run_unit(a1k, a1m, a1n);
-    if (a2k) {
-        if (a2k != a1k || a2n != a1n) fusedb_unit_prefetch(unit_Bp(a2k), unit_taps(a2k), a2n, lane, pf);     // same n-tile: same weights
-        run_unit(a2k, a2m, a2n);
-        if (a3m >= 0) run_unit(a2k, a3m, a2n);
+    // ---- P2a: branch 5's 1x3 units go to T2 (disjoint from the b1|b2 tile still being read out); branch 3 / 4 units that run
+    // here park their results in the accumulator registers P1 has left free (waves 0, 1 -- the stem accumulators -- run
+    // branch-5 units only) and write them into the output tile in P2b
+    const bool parked = a1k >= 2;
+    if (a1k == 1) {
+        floatx16 u;
+        unit_compute(1, a1m, a1n, u);
+        unit_store(1, a1m, a1n, u);
+    } else if (parked) {
+        unit_compute(a1k, a1m, a1n, acc[0]);
+        if (a2k) {
+            if (a2k != a1k || a2n != a1n) fusedb_unit_prefetch(unit_Bp(a2k), unit_taps(a2k), a2n, lane, pf);     // same n-tile: same weights
+            unit_compute(a2k, a2m, a2n, acc[1 % TM]);
+            if (a3m >= 0) unit_compute(a2k, a3m, a2n, acc[2 % TM]);
+        }
     }
     if (wave < 2) {       // the tail's four weight fragments travel in the (idle) unit-weight registers
 #pragma unroll
@@ -1879,10 +1911,17 @@ __global__ __launch_bounds__(512, TM >= 2 ? DS_FUSEDB_WPS : 2) void inception_fu
         fusedb_unit_prefetch(unit_Bp(b1k), unit_taps(b1k), b1n, lane, pf);
     }
     DS_STAMP(5);
-    __syncthreads();   // T2 complete
+    __syncthreads();   // T2 complete, b1|b2 tile read out: the b3|b4|b5 tile may overwrite it
     DS_STAMP(6);
 
     // ---- P2b
+    if (parked) {
+        unit_store(a1k, a1m, a1n, acc[0]);
+        if (a2k) {
+            unit_store(a2k, a2m, a2n, acc[1 % TM]);
+            if (a3m >= 0) unit_store(a2k, a3m, a2n, acc[2 % TM]);
+        }
+    }
     if (wave < 2) {
         // branch 5 tail: 1x1 64 -> 48 (BN, no ReLU) accumulated on top of the stem conv held in acc, then relu(stem + tail)   layers.py:132-138
 #pragma unroll
@@ -1898,8 +1937,10 @@ __global__ __launch_bounds__(512, TM >= 2 ? DS_FUSEDB_WPS : 2) void inception_fu
                 if (wave * 32 + 8 * g < 48)
                     *reinterpret_cast<uint2*>(Y2h + (mt * 32 + rlane) * (2 * B_LDY) + 96 + wave * 32 + 8 * g + h4) =
                         pack4(acc[mt][4 * g], acc[mt][4 * g + 1], acc[mt][4 * g + 2], acc[mt][4 * g + 3]);
-    } else {
-        if (b1k) run_unit(b1k, b1m, b1n);
+    } else if (b1k) {
+        floatx16 u;
+        unit_compute(b1k, b1m, b1n, u);
+        unit_store(b1k, b1m, b1n, u);
     }
     __syncthreads();   // the b3|b4|b5 tile is complete
     Yg = out_rows();

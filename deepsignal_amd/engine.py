@@ -16,7 +16,8 @@ from typing import Dict, List, Optional, Tuple
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdeepsignal_hip.so")
+# DS_HIP_LIBRARY: developer override (kernel A/B builds under tools/); the product path is always the in-tree library
+LIB_PATH = os.environ.get("DS_HIP_LIBRARY") or os.path.join(_HERE, "libdeepsignal_hip.so")
 
 # every symbol include/deepsignal_hip.h declares
 EXPORTED_SYMBOLS = (
