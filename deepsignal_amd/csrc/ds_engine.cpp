@@ -70,7 +70,7 @@ struct Op {
 
 // per-kernel accumulators (one entry per __global__ function / template instantiation)
 enum KernelClass { K_GEMM_CONV = 0, K_GEMM_FC, K_GEMM_LSTM, K_GEMM_CONV_WIDE, K_GEMM_CONV_POOL, K_GEMM_FC_DENSE, K_GEMM_LSTM_DENSE, K_FUSED1, K_FUSED2, K_FUSED3, K_STEM1, K_MAXPOOL, K_AVGPOOL, K_HEAD,
-                   K_GEMM_BCONV, K_GEMM_BCONV_POOL, K_GEMM_BFC, K_GEMM_BFC_DENSE, K_PACKEV, K_GEMM_BLSTM, K_GEMM_BLSTM_DENSE, K_FUSEDB1, K_FUSEDB2, K_FUSEDB3, K_GEMM_LSTM_T, K_GEMM_LSTM_T_DENSE, K_GEMM_BLSTM_T, K_GEMM_BLSTM_T_DENSE, K_LSTM_CELL1, K_LSTM_CELL2, K_LSTM_CELL4, K_LSTM_LDS1, K_LSTM_LDS2, K_STEM23, K_HEADF, K_COUNT };
+                   K_GEMM_BCONV, K_GEMM_BCONV_POOL, K_GEMM_BFC, K_GEMM_BFC_DENSE, K_PACKEV, K_GEMM_BLSTM, K_GEMM_BLSTM_DENSE, K_FUSEDB1, K_FUSEDB2, K_FUSEDB3, K_GEMM_LSTM_T, K_GEMM_LSTM_T_DENSE, K_GEMM_BLSTM_T, K_GEMM_BLSTM_T_DENSE, K_LSTM_CELL1, K_LSTM_CELL2, K_LSTM_CELL4, K_LSTM_LDS1, K_LSTM_LDS2, K_STEM23, K_HEADF, K_LSTM_B11, K_LSTM_B12, K_LSTM_B22, K_COUNT };
 const char* const kKernelNames[K_COUNT] = {"gemm_kernel<1,2,4,1,0,0,1,1>", "gemm_kernel<1,3,4,1,0,0,2,1>", "gemm_kernel<1,4,4,1,1,0,1,1>",
                                            "gemm_kernel<2,2,2,2,0,0,1,1>", "gemm_kernel<1,2,4,1,0,1,1,1>", "gemm_kernel<1,3,4,1,0,2,2,1>",
                                            "gemm_kernel<1,4,4,1,1,2,1,1>", "inception_fused_kernel<1>",
@@ -84,7 +84,8 @@ const char* const kKernelNames[K_COUNT] = {"gemm_kernel<1,2,4,1,0,0,1,1>", "gemm
                                            "gemm_kernel<1,1,4,1,2,0,1,1>", "gemm_kernel<1,1,4,1,2,2,1,1>",
                                            "gemm_kernel<1,1,4,1,2,0,3,1,bf16>", "gemm_kernel<1,1,4,1,2,2,3,1,bf16>",
                                            "lstm_cell_kernel<1>", "lstm_cell_kernel<2>", "lstm_cell_kernel<4>",
-                                           "lstm_cell_lds_kernel<1>", "lstm_cell_lds_kernel<2>", "stem23_kernel", "head_folded_kernel"};
+                                           "lstm_cell_lds_kernel<1>", "lstm_cell_lds_kernel<2>", "stem23_kernel", "head_folded_kernel",
+                                           "lstm_cell_bf16_kernel<1,1>", "lstm_cell_bf16_kernel<1,2>", "lstm_cell_bf16_kernel<2,2>"};
 struct KernelStat {
     int64_t launches = 0;
     double total_ms = 0;
@@ -423,27 +424,19 @@ int finalize_weights(ds_handle* h)
             // rows fed through the MFMA GEMM: layer 0 -> only the h rows (x part is table + 3 rank-1 terms)
             const int row0 = l == 0 ? in0 : 0;
             const int K = l == 0 ? HID : 2 * HID;
-            // packed n-tile p = ug*4 + g  <->  TF columns g*256 + ug*32 + [0,32)
-            auto wfun_wide = [&](int k, int pc) {
-                const int p = pc / 32, j = pc % 32, ug = p / 4, g = p % 4;
-                return kd[(size_t)(row0 + k) * 4 * HID + g * HID + ug * 32 + j];
-            };
             // CFG_LSTM_T: n-tile p holds units 8p..8p+7, column i of the tile = gate (i >> 3) of unit 8p + (i & 7)
             auto wfun_t = [&](int k, int pc) {
                 const int p = pc / 32, i = pc % 32;
                 return kd[(size_t)(row0 + k) * 4 * HID + (i >> 3) * HID + p * 8 + (i & 7)];
             };
-            // fp32 cells (lstm_cell_kernel) read the [gate][8 units] layout only; the bf16-operand cells keep both
-            // layouts (the planner picks the tiling per forward size)
-            for (int layout = h->lstm_frag ? 1 : 0; layout < 2; ++layout) {
-                PackedGemm& pg = layout == 0 ? h->lstm[d][l] : h->lstm_n[d][l];
-                std::function<float(int, int)> wfun = wfun_wide;
-                if (layout == 1) wfun = wfun_t;
+            // every cell kernel (fp32 and bf16 operands) reads the [gate][8 units] layout
+            {
+                PackedGemm& pg = h->lstm_n[d][l];
+                std::function<float(int, int)> wfun = wfun_t;
                 std::vector<float> packed = h->lstm_bf16 ? pack_b_bf16(K, 4 * HID, wfun) : pack_b(K, 4 * HID, wfun);
                 pg.K = h->lstm_bf16 ? K / 2 : K; pg.N = 4 * HID;
                 if ((rc = upload(h, &pg.Bp, packed))) return rc;
-                if (layout == 0 || h->lstm_frag) { if ((rc = upload(h, &pg.bias, bias->data))) return rc; }
-                else pg.bias = h->lstm[d][l].bias;
+                if ((rc = upload(h, &pg.bias, bias->data))) return rc;
             }
             if (l == 0) {
                 if (h->is_base) {
@@ -535,7 +528,7 @@ int alloc_workspace(ds_handle* h)
     A(&h->cur->sigfeat, B * h->SF);
     for (int d = 0; d < 2; ++d)
         for (int l = 0; l < NLAYER; ++l) { A(&h->cur->H[d][l], (size_t)h->T * h->Bp32 * HID); A(&h->cur->Cst[d][l], (size_t)h->Bp32 * HID); }
-    if (h->lstm_frag)
+    if (h->is_rnn)
         for (int d = 0; d < 2; ++d) A(&h->cur->hlast[d], B * HID);
     A(&h->cur->fc1o, B * h->J); A(&h->cur->logits, B * h->C);
     A(&h->cur->act, B * h->C + B);            // [act | pred]: one block, one D2H copy
@@ -819,30 +812,21 @@ int build_plan(ds_handle* h, int n, Plan* plan)
     // grouped launch; cell (l,s) depends only on (l-1,s) and (l,s-1), both on diagonal d-1.
     st = stage_id(h, "bilstm", 1);
     const int T = h->T;
-    // dense variants skip the per-row validity selects; legal when every tile row is a real site
     const bool lbf = h->lstm_bf16;
-    const bool dense = n % 128 == 0;
-    // Narrow (128 x 32) LSTM tiles pay when the 128 x 128 tiling cannot fill the GPU: measured on MI355X, fp32 cells
-    // gain 2.5 % end to end at 512 sites per forward (+10 % when the convolutions run in bf16) and 36 % at 128, lose
-    // 3 % at >= 1024 (4x the activation traffic); bf16 cells are a wash, so they stay wide. ds_config.reserved[3] forces one.
-    const bool narrow = h->lstm_t >= 0 ? h->lstm_t != 0 : (n <= 512 && !lbf);
-    const GemmCfg lstm_cfg = lbf ? (narrow ? (dense ? CFG_BLSTM_T_DENSE : CFG_BLSTM_T) : (dense ? CFG_BLSTM_DENSE : CFG_BLSTM))
-                                 : (narrow ? (dense ? CFG_LSTM_T_DENSE : CFG_LSTM_T) : (dense ? CFG_LSTM_DENSE : CFG_LSTM));
-    const int HU = lbf ? HID / 2 : HID;                 // row pitch / K of an h operand in 4-byte units
-    auto hptr = [&](int dir, int l, int t) {            // h(dir, l, t): [n][256] fp32, or bf16 when lbf
-        return h->cur->H[dir][l] + (size_t)t * h->B * HU;
-    };
+    const int HU = lbf ? HID / 2 : HID;                 // floats per site of one h vector (bf16 h: two units per float)
     const GemmCfg fc_cfg = bf ? (n % 128 == 0 ? CFG_BFC_DENSE : CFG_BFC) : (n % 128 == 0 ? CFG_FC_DENSE : CFG_FC);
-    if (h->is_rnn && h->lstm_frag) {
-        // fp32 cells: lstm_cell_kernel, h / c in MFMA-fragment-major buffers (ds_internal.h LstmCell). n-tiles per wave:
+    if (h->is_rnn) {
+        // dedicated cell kernels, h / c in MFMA-fragment-major buffers (ds_internal.h LstmCell). fp32 cells: n-tiles per wave
         // 1 fills the GPU at <= 768 sites per forward (768 workgroups per full diagonal at 512), wider tiles re-read the
-        // activation fragments less at bigger batches. Every width gives the same bits (same K order per element).
+        // activation fragments less at bigger batches; every width gives the same bits (same K order per element).
+        // bf16-operand cells (DS_PRECISION_BF16_ALL): lstm_cell_bf16_kernel, workgroup tile 64 x 64 .. 128 x 128 by batch.
         const int mtiles = (n + 31) / 32;
-        // kernel variant: direct-to-register (1, 2 or 4 n-tiles per wave) or operands shared through LDS (101 / 102)
-        const int nt = h->lstm_variant == DS_LSTM_TILING_NARROW ? 1 : h->lstm_variant == DS_LSTM_TILING_WIDE ? 4
+        const int nt = lbf ? (h->lstm_variant == DS_LSTM_TILING_NARROW ? 211 : h->lstm_variant == DS_LSTM_TILING_LDS1 ? 212
+                              : h->lstm_variant == DS_LSTM_TILING_WIDE ? 222 : n >= 2048 ? 222 : n > 768 ? 212 : 211)
+                       : h->lstm_variant == DS_LSTM_TILING_NARROW ? 1 : h->lstm_variant == DS_LSTM_TILING_WIDE ? 4
                        : h->lstm_variant == DS_LSTM_TILING_LDS1 ? 101 : h->lstm_variant == DS_LSTM_TILING_LDS2 ? 102
                        : (n <= 1024 ? 101 : 102);
-        const size_t step = (size_t)h->Bp32 * HID;                         // floats of one time step in H
+        const size_t step = (size_t)h->Bp32 * HU;                          // floats of one time step in H (bf16 h: half)
         for (int d = 0; d < T + NLAYER - 1; ++d) {
             LstmLaunch L;
             memset(&L, 0, sizeof L);
@@ -859,7 +843,8 @@ int build_plan(ds_handle* h, int n, Plan* plan)
                     C.ax = l > 0 ? h->cur->H[dir][l - 1] + (size_t)t * step : nullptr;
                     C.ah = sidx > 0 ? h->cur->H[dir][l] + (size_t)tprev * step : nullptr;
                     C.Bp = h->lstm_n[dir][l].Bp;
-                    C.kg_stride = (h->lstm_n[dir][l].K + 31) / 32 * 32 / 8;
+                    // fp32: k-groups of 8 per n-tile panel (K padded to 32); bf16: k-steps of 16 (K padded to 64 elements)
+                    C.kg_stride = lbf ? (2 * h->lstm_n[dir][l].K + 63) / 64 * 64 / 16 : (h->lstm_n[dir][l].K + 31) / 32 * 32 / 8;
                     C.bias = h->lstm_n[dir][l].bias;
                     C.table = l == 0 ? h->lstm_table[dir] : nullptr;
                     C.wfeat = h->lstm_wfeat[dir];
@@ -875,9 +860,9 @@ int build_plan(ds_handle* h, int n, Plan* plan)
             std::stable_sort(L.cell, L.cell + L.ncell, [](const LstmCell& a, const LstmCell& b) {
                 return (a.ax != nullptr) + (a.ah != nullptr) > (b.ax != nullptr) + (b.ah != nullptr);
             });
-            {   // tiles per work class, for lstm_logical_tile (workgroup tile = 64 sites x 64 nt columns, or 128 x 32 nt)
-                const int wg_nt = nt > 100 ? nt - 100 : nt;
-                const int per_cell = nt > 100 ? ((mtiles + 1) / 2) * (16 / wg_nt) : ((mtiles + 3) / 4) * (32 / wg_nt);
+            {   // workgroup tiles per work class, for lstm_logical_tile
+                const int per_cell = nt == 222 ? ((mtiles + 3) / 4) * 8 : nt == 212 ? ((mtiles + 1) / 2) * 8 : nt == 211 ? ((mtiles + 1) / 2) * 16
+                                     : nt > 100 ? ((mtiles + 1) / 2) * (16 / (nt - 100)) : ((mtiles + 3) / 4) * (32 / nt);
                 L.cls_tiles[0] = L.cls_tiles[1] = 0;
                 for (int i = 0; i < L.ncell; ++i) {
                     const int k = (L.cell[i].ax != nullptr) + (L.cell[i].ah != nullptr);
@@ -896,27 +881,6 @@ int build_plan(ds_handle* h, int n, Plan* plan)
                 h->stages[st].flops_per_site += flops / n;
             }
         }
-    }
-    for (int d = 0; h->is_rnn && !h->lstm_frag && d < T + NLAYER - 1; ++d) {
-        GemmLaunch L{};
-        for (int dir = 0; dir < 2; ++dir)
-            for (int l = 0; l < NLAYER; ++l) {
-                const int s = d - l;
-                if (s < 0 || s >= T) continue;
-                const int t = dir == 0 ? s : T - 1 - s;
-                const int tprev = dir == 0 ? t - 1 : t + 1;
-                GemmProblem P = base_problem(n, 4 * HID, n, narrow ? h->lstm_n[dir][l] : h->lstm[dir][l]);
-                if (l > 0) add_seg(P, hptr(dir, l - 1, t), HU, 0, HU);
-                if (s > 0) add_seg(P, hptr(dir, l, tprev), HU, 0, HU);
-                P.lstm.table = l == 0 ? h->lstm_table[dir] : nullptr;
-                P.lstm.wfeat = h->lstm_wfeat[dir];
-                P.lstm.codes = h->cur->d_kmer; P.lstm.means = h->cur->d_means; P.lstm.stds = h->cur->d_stds; P.lstm.lens = h->cur->d_sanums;
-                P.lstm.c = h->cur->Cst[dir][l];
-                P.lstm.h_out = hptr(dir, l, t);
-                P.lstm.t = t; P.lstm.T = T; P.lstm.c_zero = s == 0; P.lstm.use_feat = l == 0;
-                add_tiles(L, P, lstm_cfg, h->zero_seg);
-            }
-        add_gemm_op(rnn, 1, st, lstm_cfg, L);
     }
     if (bf && h->is_rnn) {     // the bf16 FC reads [bf16(h_fw(T-1)) | bf16(h_bw(0)) | signal features] from one buffer
         Op op{};
@@ -1008,11 +972,7 @@ int issue_op(ds_handle* h, Plan& plan, const Op& op, hipStream_t s)
         else HIPCHK(h, launch_avgpool7(op.in, op.out, n, op.a, op.d, s));
         break;
     case OP_PACKEV:
-        if (h->lstm_frag)
-            HIPCHK(h, launch_pack_event_feat_bf16(h->cur->hlast[0], h->cur->hlast[1], h->cur->joint, n, h->JP, 0, s));
-        else
-            HIPCHK(h, launch_pack_event_feat_bf16(h->cur->H[0][NLAYER - 1] + (size_t)(h->T - 1) * h->B * (HID / 2),
-                                                  h->cur->H[1][NLAYER - 1], h->cur->joint, n, h->JP, 1, s));
+        HIPCHK(h, launch_pack_event_feat_bf16(h->cur->hlast[0], h->cur->hlast[1], h->cur->joint, n, h->JP, 0, s));
         break;
     case OP_LSTM:
         HIPCHK(h, launch_lstm_cells(op.c, plan.lstm_launches[op.launch_index], s));
@@ -1119,7 +1079,8 @@ int kernel_class(const Op& op)
     case OP_AVGPOOL: return K_AVGPOOL;
     case OP_HEAD: return K_HEAD;
     case OP_PACKEV: return K_PACKEV;
-    case OP_LSTM: return op.c == 1 ? K_LSTM_CELL1 : op.c == 2 ? K_LSTM_CELL2 : op.c == 4 ? K_LSTM_CELL4 : op.c == 101 ? K_LSTM_LDS1 : K_LSTM_LDS2;
+    case OP_LSTM: return op.c == 1 ? K_LSTM_CELL1 : op.c == 2 ? K_LSTM_CELL2 : op.c == 4 ? K_LSTM_CELL4 : op.c == 101 ? K_LSTM_LDS1
+               : op.c == 211 ? K_LSTM_B11 : op.c == 212 ? K_LSTM_B12 : op.c == 222 ? K_LSTM_B22 : K_LSTM_LDS2;
     }
     return K_HEAD;
 }
@@ -1666,12 +1627,15 @@ int64_t ds_get_intermediate(ds_handle* h, const char* name, float* out, int64_t 
         const int64_t count = (int64_t)n * h->T * HID;
         if (count > capacity) return fail(h, DS_ERR_INVALID, "capacity too small");
         if (h->lstm_bf16) {
-            std::vector<uint16_t> tb((size_t)h->T * h->B * HID);
+            // bf16-operand cells keep h fragment-major in bf16: [T][m-tile][k-step s of 16 units][lane = 32 * half + r][8] holds
+            // units 16 s + 8 half .. + 7 of site 32 * mtile + r (lstm_cell_bf16_kernel)
+            std::vector<uint16_t> tb((size_t)h->T * h->Bp32 * HID);
             if (hipMemcpy(tb.data(), h->cur->H[d][l], tb.size() * 2, hipMemcpyDeviceToHost) != hipSuccess) return fail(h, DS_ERR_HIP, "hipMemcpy D2H");
             for (int i = 0; i < n; ++i)
                 for (int t = 0; t < h->T; ++t)
                     for (int c = 0; c < HID; ++c) {
-                        const uint32_t u = (uint32_t)tb[((size_t)t * h->B + i) * HID + c] << 16;
+                        const size_t idx = (size_t)t * h->Bp32 * HID + (size_t)(i / 32) * 32 * HID + ((size_t)(c / 16) * 64 + ((c % 16) / 8) * 32 + i % 32) * 8 + c % 8;
+                        const uint32_t u = (uint32_t)tb[idx] << 16;
                         memcpy(out + ((size_t)i * h->T + t) * HID + c, &u, 4);
                     }
             return count;

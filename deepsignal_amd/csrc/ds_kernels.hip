@@ -697,11 +697,7 @@ hipError_t launch_gemm(GemmCfg cfg, const GemmLaunch* d_launch, int total_tiles,
     case CFG_BCONV_POOL: hipLaunchKernelGGL((gemm_kernel<1, 2, 4, 1, 0, 1, 1, 1, true>), dim3(total_tiles), dim3(256), 0, s, d_launch); break;
     case CFG_BFC: hipLaunchKernelGGL((gemm_kernel<4, 2, 1, 4, 0, 0, 2, 1, true>), dim3(total_tiles), dim3(256), 0, s, d_launch); break;
     case CFG_BFC_DENSE: hipLaunchKernelGGL((gemm_kernel<4, 2, 1, 4, 0, 2, 2, 1, true>), dim3(total_tiles), dim3(256), 0, s, d_launch); break;
-    case CFG_BLSTM: hipLaunchKernelGGL((gemm_kernel<1, 4, 4, 1, 1, 0, 3, 1, true>), dim3(total_tiles), dim3(256), 0, s, d_launch); break;
-    case CFG_BLSTM_DENSE: hipLaunchKernelGGL((gemm_kernel<1, 4, 4, 1, 1, 2, 3, 1, true>), dim3(total_tiles), dim3(256), 0, s, d_launch); break;
-    case CFG_BLSTM_T: hipLaunchKernelGGL((gemm_kernel<1, 1, 4, 1, 2, 0, 3, 1, true>), dim3(total_tiles), dim3(256), 0, s, d_launch); break;
-    case CFG_BLSTM_T_DENSE: hipLaunchKernelGGL((gemm_kernel<1, 1, 4, 1, 2, 2, 3, 1, true>), dim3(total_tiles), dim3(256), 0, s, d_launch); break;
-    default: return hipErrorInvalidValue;      // fp32 LSTM cells run in lstm_cell_kernel, not through this template
+    default: return hipErrorInvalidValue;      // the BiLSTM cells run in their own kernels (lstm_cell_*), not through this template
     }
     return hipGetLastError();
 }
@@ -943,6 +939,10 @@ __device__ __forceinline__ void glds16s(const void* gbase, unsigned lane_off, un
                  : "memory");
 }
 template <int I> struct LdsSlot { static constexpr int value = I; };
+__device__ __forceinline__ floatx16 mfma_bf_early(float4 a, float4 b, floatx16 c)
+{
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
 
 template <int NT>
 __global__ __launch_bounds__(256, NT == 1 ? 5 : 2) void lstm_cell_lds_kernel(const LstmLaunch L_)
@@ -1097,6 +1097,192 @@ __global__ __launch_bounds__(256, NT == 1 ? 5 : 2) void lstm_cell_lds_kernel(con
 #undef DS_LSTAMP
 }
 
+// ---------------------------------------------------------------------------------------------
+// The same cells with bf16 OPERANDS (DS_PRECISION_BF16_ALL): h and the weights are bf16, products accumulate in fp32
+// (v_mfma_f32_32x32x16_bf16), the layer-0 table row / rank-1 terms, the gates and the cell state stay fp32.
+//
+// A bf16 MFMA does 16x the work of an fp32 one per cycle, so what bounds this kernel is operand delivery, not the matrix
+// pipe: a diagonal at 4096 sites per forward moves ~75 MB (c: 8 MB per cell read + written in fp32, h: 4 + 2 MB, weights
+// 1 MB) for 21 GFLOP -- ~20 us of memory against ~9 us of MFMA at peak. Design for bytes per MFMA:
+//   * workgroup tile = 64 MTW sites x 64 NTW columns, 4 waves as 2 x 2, each wave MTW x NTW tiles of 32 x 32: at 2 x 2 a
+//     k-step (16 k) needs 8 KB from L2 for 16 MFMAs -- 0.5 KB per MFMA (the round-1 template re-loaded every weight
+//     fragment in each of its four waves: 1.25 KB per MFMA) -- and 1 KB of LDS reads per MFMA;
+//   * operands are 1 KiB fragment images in global memory (weights packed so by the host; h because the previous cell's
+//     epilogue wrote it so) and go global -> LDS by LDS-DMA, ring of three stages of two k-steps, one barrier per stage
+//     behind a counted vmcnt -- the structure of lstm_cell_lds_kernel;
+//   * h lives FRAGMENT-MAJOR in bf16: [m-tile of 32 sites][k-step of 16 units][64 lanes][8 bf16], lane (r, half) holding
+//     units 16 s + 8 half .. + 7 of site 32 m + r. A lane of the epilogue owns four neighbouring units of one site
+//     (8 bytes): lanes (r, 0) and (r, 1) of an n-tile fill the two halves of one 16-byte slot, a wave store covers 512
+//     contiguous bytes. c keeps the fp32 kernels' fragment-major layout.
+// Roofline: HBM / L2 (operand delivery). Algorithmic FLOPs per launch = sum over cells of 2 * n * 1024 * K.
+constexpr int LSTM_MT_BYTES_BF16 = 32 * 256 * 2;      // one m-tile of a bf16 fragment-major h buffer
+template <int MTW, int NTW>
+__global__ __launch_bounds__(256, MTW * NTW >= 4 ? 2 : 3) void lstm_cell_bf16_kernel(const LstmLaunch L_)
+{
+    const LstmLaunch* const Lp = &L_;
+    constexpr int FRA = 2 * MTW, FRB = 2 * NTW, FR = FRA + FRB;     // 1 KiB fragments per k-step: m-tiles of h, n-tiles of weights
+    constexpr int KGS = 2;                                          // k-steps per ring stage
+    constexpr int NF = KGS * FR;                                    // fragments per stage (a multiple of the four waves)
+    static_assert(NF % 4 == 0, "fragments of a stage are dealt to four waves");
+    constexpr int LPS = NF / 4;                                     // DMA requests per wave and stage
+    constexpr int STAGE = NF * 256;                                 // floats
+    extern __shared__ __attribute__((aligned(16))) float ring[];    // [3 * STAGE]
+
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int mi = wave & 1, nj = wave >> 1;
+    unsigned long long* const sdst = (Lp->dbg && blockIdx.x < DBG_MAX_WGS) ? Lp->dbg + (size_t)blockIdx.x * 8 : nullptr;
+    const bool stamp = sdst != nullptr && threadIdx.x == 0;
+#define DS_LSTAMP(i, v) do { if (stamp) sdst[i] = (v); } while (0)
+    DS_LSTAMP(0, __builtin_amdgcn_s_memrealtime());
+    DS_LSTAMP(1, __builtin_amdgcn_s_memtime());
+    DS_LSTAMP(6, (unsigned long long)__builtin_amdgcn_s_getreg(63492));
+    DS_LSTAMP(7, (unsigned long long)__builtin_amdgcn_s_getreg(63508));
+    const int bid = lstm_logical_tile(blockIdx.x, gridDim.x, Lp->cls_tiles[0], Lp->cls_tiles[1]);
+    const int mtiles = Lp->mtiles;
+    const int mblocks = (mtiles + FRA - 1) / FRA;
+    constexpr int NGROUPS = 32 / FRB;
+    const int per_cell = mblocks * NGROUPS;
+    const int ci = bid / per_cell, rem = bid - ci * per_cell;
+    // n-groups of one m-block are neighbours (the fp32 kernels walk the m-blocks of one weight panel instead): the workgroups
+    // an XCD has resident at one time then cover a few m-blocks x ALL n-groups -- every h fragment is fetched into that L2
+    // once and used by eight workgroups, and the cell's whole weight matrix (1 MB in bf16) stays resident beside it
+    const int ng = rem % NGROUPS, mb = rem / NGROUPS;
+    const LstmCell& C = Lp->cell[ci];
+    const int half = lane >> 5, r31 = lane & 31;
+    const int n = Lp->n, T = Lp->T;
+    const unsigned lane16 = (unsigned)lane * 16, lane4 = (unsigned)lane * 4;
+
+    const bool has_x = C.ax != nullptr, has_h = C.ah != nullptr;
+    const int KS = (has_x ? 16 : 0) + (has_h ? 16 : 0);             // k-steps of 16: x rows first, then h rows (TF kernel order)
+    const int nstages = KS / KGS;
+    const char* const a0 = reinterpret_cast<const char*>(has_x ? C.ax : C.ah);
+    const long dseg = (has_x && has_h) ? (reinterpret_cast<const char*>(C.ah) - reinterpret_cast<const char*>(C.ax)) - 16 * 1024 : 0;
+    // request j of this wave = fragment q = wave + 4 j of a stage -> (k-step kgi inside the stage, fragment f of the k-step);
+    // sources are wave-uniform bases (scalar adds in the loop) + one loop-invariant lane offset
+    const char* src[LPS];
+    int kgi_[LPS];
+    bool is_a[LPS];
+#pragma unroll
+    for (int j = 0; j < LPS; ++j) {
+        const int q = wave + 4 * j, kgi = q / FR, f = q - kgi * FR;
+        kgi_[j] = kgi;
+        is_a[j] = f < FRA;
+        if (f < FRA) {
+            const int m = min(mb * FRA + f, mtiles - 1);
+            src[j] = a0 + (size_t)m * LSTM_MT_BYTES_BF16 + (size_t)kgi * 1024;
+        } else {
+            const int ntile = ng * FRB + (f - FRA);
+            src[j] = reinterpret_cast<const char*>(C.Bp) + ((size_t)ntile * C.kg_stride + kgi) * 1024;      // kg_stride: k-steps per n-tile panel
+        }
+    }
+    const unsigned ring_lds = (unsigned)(size_t)(__attribute__((address_space(3))) float*)ring;
+    auto request = [&](int st, int slot) __attribute__((always_inline)) {
+        const unsigned dst = __builtin_amdgcn_readfirstlane(ring_lds + (slot * STAGE + wave * 256) * 4);
+#pragma unroll
+        for (int j = 0; j < LPS; ++j) {
+            const int ks = st * KGS + kgi_[j];
+            const long off = (long)st * (KGS * 1024) + ((is_a[j] && ks >= 16) ? dseg : 0);
+            glds16s(src[j] + off, lane16, dst + j * 4096);
+        }
+    };
+    if (nstages > 0) request(0, 0);
+    if (nstages > 1) request(1, 1);
+
+    // ---- this wave's tiles: m-tiles mb * FRA + mi * MTW + i, n-tiles ng * FRB + nj * NTW + j
+    int mt[MTW];
+    bool valid[MTW];
+#pragma unroll
+    for (int i = 0; i < MTW; ++i) {
+        const int raw = mb * FRA + mi * MTW + i;
+        valid[i] = raw < mtiles;
+        mt[i] = valid[i] ? raw : mtiles - 1;
+    }
+    floatx16 acc[MTW][NTW];
+    float4 cp[MTW][NTW];
+#pragma unroll
+    for (int i = 0; i < MTW; ++i) {
+        const int row = mt[i] * 32 + r31;
+        const int rowc = row < n ? row : n - 1;
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) lstm_acc_init(C, (ng * FRB + nj * NTW + j) * 8 + 4 * half, rowc, T, acc[i][j]);
+    }
+    const bool c_zero = C.c_zero != 0;
+#pragma unroll
+    for (int i = 0; i < MTW; ++i)
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) {
+            cp[i][j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (!c_zero) cp[i][j] = gload4(C.c + (size_t)mt[i] * LSTM_MT_FLOATS + (unsigned)(ng * FRB + nj * NTW + j) * 256 + lane4);
+        }
+    // every compiler-visible load is retired here: the loop's vmcnt waits count the LDS-DMA requests only. (Leaving the
+    // cell-state loads in flight across the first stages, with the waits widened by their number, was tried: on MI355X two
+    // engines then disagreed in a few bits -- LDS-DMA requests and loads to registers do not retire strictly in issue order
+    // with respect to each other, so a count cannot tell which of the two kinds is still outstanding.)
+#pragma unroll
+    for (int i = 0; i < MTW; ++i)
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) {
+            asm volatile("" : "+v"(cp[i][j].x), "+v"(cp[i][j].y), "+v"(cp[i][j].z), "+v"(cp[i][j].w));
+            asm volatile("" : "+v"(acc[i][j]));
+        }
+    DS_LSTAMP(2, __builtin_amdgcn_s_memtime());
+
+    const float* const fa0 = ring + (mi * MTW) * 256 + lane4;
+    const float* const fb0 = ring + (FRA + nj * NTW) * 256 + lane4;
+    auto stage = [&](int st, auto slot_c) __attribute__((always_inline)) {
+        constexpr int SLOT = decltype(slot_c)::value;
+        if (st + 1 < nstages) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (st + 2 < nstages) request(st + 2, (SLOT + 2) % 3);
+#pragma unroll
+        for (int kgi = 0; kgi < KGS; ++kgi) {
+            float4 a[MTW], b[NTW];
+#pragma unroll
+            for (int i = 0; i < MTW; ++i) a[i] = *reinterpret_cast<const float4*>(fa0 + SLOT * STAGE + (kgi * FR + i) * 256);
+#pragma unroll
+            for (int j = 0; j < NTW; ++j) b[j] = *reinterpret_cast<const float4*>(fb0 + SLOT * STAGE + (kgi * FR + j) * 256);
+#pragma unroll
+            for (int i = 0; i < MTW; ++i)
+#pragma unroll
+                for (int j = 0; j < NTW; ++j) acc[i][j] = mfma_bf_early(b[j], a[i], acc[i][j]);     // transposed: (h W)^T
+        }
+    };
+    for (int st = 0; st < nstages;) {
+        stage(st, LdsSlot<0>{}); if (++st >= nstages) break;
+        stage(st, LdsSlot<1>{}); if (++st >= nstages) break;
+        stage(st, LdsSlot<2>{}); ++st;
+    }
+    DS_LSTAMP(3, __builtin_amdgcn_s_memtime());
+
+    // ---- gates (fp32), new state; c fragment-major fp32, h fragment-major bf16 (8 bytes per lane), optional row-major fp32 h
+    typedef unsigned int u2v __attribute__((ext_vector_type(2)));
+#pragma unroll
+    for (int i = 0; i < MTW; ++i) {
+        if (!valid[i]) continue;
+        const int row = mt[i] * 32 + r31;
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) {
+            const int ntile = ng * FRB + nj * NTW + j;
+            float4 cn, hn;
+            lstm_gates(acc[i][j], cp[i][j], cn, hn);
+            const v4f co = {cn.x, cn.y, cn.z, cn.w};
+            *(__attribute__((address_space(1))) v4f*)(C.c + (size_t)mt[i] * LSTM_MT_FLOATS + (unsigned)ntile * 256 + lane4) = co;
+            const u2v ho = {(unsigned)f2bf(hn.x) | ((unsigned)f2bf(hn.y) << 16), (unsigned)f2bf(hn.z) | ((unsigned)f2bf(hn.w) << 16)};
+            char* const hb = reinterpret_cast<char*>(C.h_out) + (size_t)mt[i] * LSTM_MT_BYTES_BF16 + (unsigned)(ntile >> 1) * 1024 +
+                             (unsigned)(((ntile & 1) * 32 + r31) * 16 + half * 8);
+            *(__attribute__((address_space(1))) u2v*)hb = ho;
+            if (C.h_row && row < n) {
+                const v4f hr = {hn.x, hn.y, hn.z, hn.w};
+                *(__attribute__((address_space(1))) v4f*)(C.h_row + (size_t)row * 256 + ntile * 8 + 4 * half) = hr;
+            }
+        }
+    }
+    DS_LSTAMP(4, __builtin_amdgcn_s_memtime());
+    DS_LSTAMP(5, __builtin_amdgcn_s_memrealtime());
+#undef DS_LSTAMP
+}
+
 hipError_t launch_lstm_cells(int nt, const LstmLaunch& L, hipStream_t s)
 {
     const int ncell = L.ncell, mtiles = L.mtiles;
@@ -1105,6 +1291,10 @@ hipError_t launch_lstm_cells(int nt, const LstmLaunch& L, hipStream_t s)
     switch (nt) {
     case 101: hipLaunchKernelGGL(lstm_cell_lds_kernel<1>, dim3(ncell * mblocks2 * 16), dim3(256), 3 * 1 * 4 * 1024, s, L); break;      // 3 stages x KGS x FR KiB
     case 102: hipLaunchKernelGGL(lstm_cell_lds_kernel<2>, dim3(ncell * mblocks2 * 8), dim3(256), 3 * 2 * 6 * 1024, s, L); break;
+    // bf16-operand cells (DS_PRECISION_BF16_ALL): 2MN = workgroup tile of 64 M sites x 64 N columns
+    case 211: hipLaunchKernelGGL((lstm_cell_bf16_kernel<1, 1>), dim3(ncell * ((mtiles + 1) / 2) * 16), dim3(256), 3 * 2 * 4 * 1024, s, L); break;
+    case 212: hipLaunchKernelGGL((lstm_cell_bf16_kernel<1, 2>), dim3(ncell * ((mtiles + 1) / 2) * 8), dim3(256), 3 * 2 * 6 * 1024, s, L); break;
+    case 222: hipLaunchKernelGGL((lstm_cell_bf16_kernel<2, 2>), dim3(ncell * ((mtiles + 3) / 4) * 8), dim3(256), 3 * 2 * 8 * 1024, s, L); break;
     case 1: hipLaunchKernelGGL(lstm_cell_kernel<1>, dim3(ncell * mblocks * 32), dim3(256), 0, s, L); break;
     case 2: hipLaunchKernelGGL(lstm_cell_kernel<2>, dim3(ncell * mblocks * 16), dim3(256), 0, s, L); break;
     case 4: hipLaunchKernelGGL(lstm_cell_kernel<4>, dim3(ncell * mblocks * 8), dim3(256), 0, s, L); break;
@@ -1615,7 +1805,6 @@ __global__ __launch_bounds__(512, TM >= 2 ? DS_FUSEDB_WPS : 2) void inception_fu
     unsigned short* const T2h = reinterpret_cast<unsigned short*>(T2);
     unsigned short* const Ysh = reinterpret_cast<unsigned short*>(Ys);
     unsigned short* const Y2h = reinterpret_cast<unsigned short*>(Y2);
-    const int h4 = 4 * (lane >> 5), rlane = lane & 31;
     constexpr int NSLOT = TR32 * 32 / 512;    // 16-B slots of the input tile per thread: 2 * TM
 
     const int site0 = blockIdx.x * spt;

@@ -7,7 +7,8 @@ from deepsignal_amd import synth, weights as W
 from deepsignal_amd.engine import Engine
 var = sys.argv[1] if len(sys.argv) > 1 else "lds1"
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 512
-e = Engine(max_batch=B, slots=1, serial=True, debug_stamps=True, lstm_tiling=var); e.load_weights(W.random_weights(seed=1))
+prec = sys.argv[3] if len(sys.argv) > 3 else "fp32"      # bf16_all: the bf16-operand cells (variant is ignored)
+e = Engine(max_batch=B, slots=1, serial=True, debug_stamps=True, lstm_tiling=var, precision=prec); e.load_weights(W.random_weights(seed=1))
 e.set_graph(False)
 f = synth.synthetic_features(B, seed=2)
 args = [f[k] for k in ("kmer", "means", "stds", "sanums", "signals")]
