@@ -40,7 +40,7 @@ def build_parser():
     parser = argparse.ArgumentParser(prog="deepsignal", description="call_mods on MI355X (gfx950)")
     sub = parser.add_subparsers(title="modules", dest="module")
     # `extract`: the step before the path -- fast5 -> feature TSV (reference deepsignal/deepsignal.py:155-234, same flags)
-    e = sub.add_parser("extract", description="extract features from fast5 files (host side, needs h5py)")
+    e = sub.add_parser("extract", description="extract features from fast5 files (host side; HDF5 through h5py, or deepsignal_amd.minihdf5 where h5py is absent)")
     g = e.add_argument_group("INPUT")
     g.add_argument("--fast5_dir", "-i", required=True)
     g.add_argument("--recursively", "-r", default="yes")

@@ -7,7 +7,8 @@ per-base event slices -> motif scan -> per-site k-mer, means, stds, lengths and 
 signal samples -> the 12-column feature row.
 
 The numeric core works on plain arrays (`extract_read_features`), so it is testable without HDF5;
-reading tombo-resquiggled single-read fast5 files needs `h5py`, imported lazily.
+tombo-resquiggled single-read fast5 files are opened with `h5py` where it exists and with deepsignal_amd.minihdf5
+(plain Python, read-only) where it does not -- the MI355X image.
 """
 from __future__ import annotations
 
@@ -133,10 +134,22 @@ def _features_to_str(features) -> str:
                       ",".join(str(x) for x in lens), ",".join(str(x) for x in cent), str(label)])
 
 
-# ------------------------------------------------------------------ fast5 (HDF5) access, needs h5py
-def _read_fast5(path: str, corrected_group: str, basecall_subgroup: str):
+# ------------------------------------------------------------------ fast5 (HDF5) access: h5py, or deepsignal_amd.minihdf5
+def _hdf5_module():
+    """h5py where it is installed (as the reference uses, extract_features.py:8), else the package's own read-only HDF5
+    reader (deepsignal_amd/minihdf5.py: the MI355X image has no h5py). Both open the real file; tests/test_minihdf5.py holds
+    them to the same arrays on the committed fast5 fixtures."""
+    try:
+        import h5py
+        return h5py
+    except ImportError:
+        from . import minihdf5
+        return minihdf5
+
+
+def _read_fast5(path: str, corrected_group: str, basecall_subgroup: str, hdf5=None):
     """Schema of SURVEY.md Appendix C.4 (extract_features.py:35-72,75-140,193-208)."""
-    import h5py      # only needed for real fast5 input
+    h5py = hdf5 if hdf5 is not None else _hdf5_module()
     with h5py.File(path, "r") as f:
         read = list(f["Raw/Reads"].values())[0]
         raw = read["Signal"][()]

@@ -184,6 +184,47 @@ def test_config5_fast5_arrays_to_rows_on_the_gpu(small_weights, tmp_path, monkey
             assert a[8] == b[8]
 
 
+@pytest.mark.parametrize("style", ["plain", "ont"])
+def test_config5_real_fast5_files_opened_on_the_gpu_box(small_weights, tmp_path, style):
+    """BASELINE configs[4] with the HDF5 access itself in the loop: `deepsignal call_mods -i <directory of .fast5 files>`
+    on the committed h5py-written tombo-style files (tests/golden/fast5: contiguous + fixed strings, and the ONT storage
+    form -- chunked + gzip + shuffle signal, variable-length strings). The box has no h5py: the files are opened by
+    deepsignal_amd.minihdf5. Rows against the oracle-driven harness on the same files (text byte for byte,
+    probabilities to 1e-4), and the features against the rows the REFERENCE extractor wrote for these reads."""
+    import shutil
+    from deepsignal_amd import call_modifications as cm, deepsignal as cli, extract_features as ef
+    g = json.load(open(os.path.join(GOLDEN, "extract_golden.json")))
+    case = g["cases"][1]                       # zscore, CG, no reference genome, k = 17, 360 samples
+    d = tmp_path / "f5"
+    shutil.copytree(os.path.join(GOLDEN, "fast5", style), str(d))
+    wfile = str(tmp_path / "model.dsw")
+    W.save_weights(wfile, small_weights)
+    out_gpu, out_cpu = str(tmp_path / "gpu.tsv"), str(tmp_path / "cpu.tsv")
+    random.seed(case["seed"])
+    rc_ = cli.main(["call_mods", "-i", str(d), "-m", wfile, "-o", out_gpu, "--normalize_method", "zscore", "--f5_batch_num", "2",
+                    "--batch_size", "16", "--is_gpu", "yes"])
+    assert rc_ in (0, None)
+    f5_args = (True, "RawGenomeCorrected_000", "BaseCalled_template", None, True, "zscore", "CG", 0, 1, 2, None)
+    random.seed(case["seed"])
+    n_cpu = cm.call_mods(str(d), wfile, out_cpu, 17, 360, 16, 0.001, 2, 1, True, True, True, True, f5_args,
+                         engine=OracleEngine(small_weights))
+    rg = [l.rstrip("\n").split("\t") for l in open(out_gpu)]
+    rcpu = [l.rstrip("\n").split("\t") for l in open(out_cpu)]
+    assert len(rg) == n_cpu == len(case["features_str"])
+    ref7 = ["\t".join(r.split("\t")[:7]) for r in case["features_str"]]
+    assert sorted("\t".join(r[:6] + [r[9]]) for r in rg) == sorted(ref7)
+    for a, b in zip(rg, rcpu):
+        assert len(a) == 10 and a[:6] == b[:6] and a[9] == b[9]
+        assert abs(float(a[6]) - float(b[6])) <= 1e-4 and abs(float(a[7]) - float(b[7])) <= 1e-4
+        if abs(float(b[6]) - float(b[7])) > 1e-3:
+            assert a[8] == b[8]
+    # which reader opened the files: the package's own one wherever h5py is absent (the MI355X image)
+    try:
+        import h5py  # noqa: F401
+    except ImportError:
+        assert ef._hdf5_module().__name__ == "deepsignal_amd.minihdf5"
+
+
 # ------------------------------------------------------------------------------------------------------------------
 # scope row f4
 # ------------------------------------------------------------------------------------------------------------------
