@@ -1805,6 +1805,9 @@ __global__ __launch_bounds__(512, TM >= 2 ? DS_FUSEDB_WPS : 2) void inception_fu
     unsigned short* const T2h = reinterpret_cast<unsigned short*>(T2);
     unsigned short* const Ysh = reinterpret_cast<unsigned short*>(Ys);
     unsigned short* const Y2h = reinterpret_cast<unsigned short*>(Y2);
+    // workgroup barrier for LDS traffic only: __syncthreads() also drains vmcnt, i.e. waits for the row stores that are meant
+    // to leave in the background (only the barrier at the end of a module needs them complete: the next module reads them)
+    auto lds_barrier = []() __attribute__((always_inline)) { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
     constexpr int NSLOT = TR32 * 32 / 512;    // 16-B slots of the input tile per thread: 2 * TM
 
     const int site0 = blockIdx.x * spt;
@@ -2100,7 +2103,7 @@ __global__ __launch_bounds__(512, TM >= 2 ? DS_FUSEDB_WPS : 2) void inception_fu
         fusedb_unit_prefetch(unit_Bp(b1k), unit_taps(b1k), b1n, lane, pf);
     }
     DS_STAMP(5);
-    __syncthreads();   // T2 complete, b1|b2 tile read out: the b3|b4|b5 tile may overwrite it
+    lds_barrier();     // T2 complete, b1|b2 tile read out: the b3|b4|b5 tile may overwrite it
     DS_STAMP(6);
 
     // ---- P2b
@@ -2131,7 +2134,7 @@ __global__ __launch_bounds__(512, TM >= 2 ? DS_FUSEDB_WPS : 2) void inception_fu
         unit_compute(b1k, b1m, b1n, u);
         unit_store(b1k, b1m, b1n, u);
     }
-    __syncthreads();   // the b3|b4|b5 tile is complete
+    lds_barrier();     // the b3|b4|b5 tile is complete
     Yg = out_rows();
     for (int idx = tid; idx < TR32 * 18; idx += 512) {      // 144 channels = 18 x 16 B per row, Y[96, 240)
         const int row = idx / 18, q = idx - row * 18;
