@@ -150,7 +150,7 @@ def pmc_traffic(kernel_name):
                 return {"traffic": round(v["hbm_bytes_per_launch"]), "traffic_unit": "B/launch",
                         "traffic_fetch": round(v["fetch_bytes_per_launch"]), "traffic_write": round(v["write_bytes_per_launch"]),
                         "traffic_source": "committed constant, NOT measured in this run: profiles/%s (recorded at commit %s; %s)"
-                                          % (os.path.basename(path), _recorded_commit(path), rec["source"])}
+                                          % (os.path.basename(path), rec.get("commit") or _recorded_commit(path), rec["source"])}
     except (OSError, ValueError, KeyError, TypeError):
         pass
     return {"traffic": None}
@@ -166,7 +166,7 @@ def pmc_mfma_busy(kernel_name):
             if _norm_kernel(name) == _norm_kernel(kernel_name):
                 return {"mfma_busy_pmc": v["mfma_busy_frac_at_inkernel_clock"],
                         "mfma_busy_source": "committed constant, NOT measured in this run: profiles/%s (recorded at commit %s)"
-                                            % (os.path.basename(path), _recorded_commit(path))}
+                                            % (os.path.basename(path), rec.get("commit") or _recorded_commit(path))}
     except (OSError, ValueError, KeyError, TypeError):
         pass
     return {"mfma_busy_pmc": None}

@@ -18,7 +18,19 @@ python3 tools/pmc_mfma_util.py $OUT/mfma $OUT/pmc_mfma_util.json > $OUT/pmc_mfma
 cp $(ls $OUT/fetch/*/*counter_collection.csv | head -1) $OUT/fetch_size_counter_collection.csv 2>/dev/null
 cp $(ls $OUT/write/*/*counter_collection.csv | head -1) $OUT/write_size_counter_collection.csv 2>/dev/null
 cp $(ls $OUT/mfma/*/*counter_collection.csv | head -1) $OUT/mfma_busy_counter_collection.csv 2>/dev/null
-rm -rf $OUT/trace $OUT/fetch $OUT/write $OUT/mfma
+# BASELINE configs[2] (bf16 modes, batch 4096 and 512): throughput + per-kernel times, and the conv path's HBM-side bytes
+python3 tools/config3.py 4096 $OUT/config3_batch4096.json > /dev/null 2> $OUT/config3.err
+python3 tools/config3.py 512 $OUT/config3_batch512.json > /dev/null 2>> $OUT/config3.err
+python3 tools/kernel_time.py bf16_all 4096 10 7 > $OUT/bf16_all_4096_kernel_times.json 2>> $OUT/config3.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/btrace -- python3 tools/probe_engine.py bf16_all 4096 > /dev/null 2> $OUT/btrace.err
+cp $(ls $OUT/btrace/*/*kernel_stats.csv | head -1) $OUT/bf16_all_4096_kernel_stats.csv 2>/dev/null
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/bfetch -- python3 tools/probe_engine.py bf16_all 4096 > /dev/null 2> $OUT/bfetch.err
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/bwrite -- python3 tools/probe_engine.py bf16_all 4096 > /dev/null 2> $OUT/bwrite.err
+python3 tools/pmc_traffic.py $OUT/bfetch $OUT/bwrite $OUT/bf16_all_4096_pmc_traffic.json > $OUT/bf16_all_4096_pmc_traffic.txt 2>&1
+cp $(ls $OUT/bfetch/*/*counter_collection.csv | head -1) $OUT/bf16_fetch_size_counter_collection.csv 2>/dev/null
+cp $(ls $OUT/bwrite/*/*counter_collection.csv | head -1) $OUT/bf16_write_size_counter_collection.csv 2>/dev/null
+rm -rf $OUT/trace $OUT/fetch $OUT/write $OUT/mfma $OUT/btrace $OUT/bfetch $OUT/bwrite
+cat $OUT/bf16_all_4096_pmc_traffic.txt | head -12
 ls -la $OUT
 cat $OUT/pmc_mfma_util.txt
 cat $OUT/pmc_traffic.txt | head -20
