@@ -70,7 +70,7 @@ struct Op {
 
 // per-kernel accumulators (one entry per __global__ function / template instantiation)
 enum KernelClass { K_GEMM_CONV = 0, K_GEMM_FC, K_GEMM_LSTM, K_GEMM_CONV_WIDE, K_GEMM_CONV_POOL, K_GEMM_FC_DENSE, K_GEMM_LSTM_DENSE, K_FUSED1, K_FUSED2, K_FUSED3, K_STEM1, K_MAXPOOL, K_AVGPOOL, K_HEAD,
-                   K_GEMM_BCONV, K_GEMM_BCONV_POOL, K_GEMM_BFC, K_GEMM_BFC_DENSE, K_PACKEV, K_GEMM_BLSTM, K_GEMM_BLSTM_DENSE, K_FUSEDB1, K_FUSEDB2, K_FUSEDB3, K_GEMM_LSTM_T, K_GEMM_LSTM_T_DENSE, K_GEMM_BLSTM_T, K_GEMM_BLSTM_T_DENSE, K_LSTM_CELL1, K_LSTM_CELL2, K_LSTM_CELL4, K_LSTM_LDS1, K_LSTM_LDS2, K_STEM23, K_HEADF, K_LSTM_B11, K_LSTM_B12, K_LSTM_B22, K_COUNT };
+                   K_GEMM_BCONV, K_GEMM_BCONV_POOL, K_GEMM_BFC, K_GEMM_BFC_DENSE, K_PACKEV, K_GEMM_BLSTM, K_GEMM_BLSTM_DENSE, K_FUSEDB1, K_FUSEDB2, K_FUSEDB3, K_GEMM_LSTM_T, K_GEMM_LSTM_T_DENSE, K_GEMM_BLSTM_T, K_GEMM_BLSTM_T_DENSE, K_LSTM_CELL1, K_LSTM_CELL2, K_LSTM_CELL4, K_LSTM_LDS1, K_LSTM_LDS2, K_STEM23, K_HEADF, K_LSTM_B11, K_LSTM_B12, K_LSTM_B22, K_STEM23B, K_COUNT };
 const char* const kKernelNames[K_COUNT] = {"gemm_kernel<1,2,4,1,0,0,1,1>", "gemm_kernel<1,3,4,1,0,0,2,1>", "gemm_kernel<1,4,4,1,1,0,1,1>",
                                            "gemm_kernel<2,2,2,2,0,0,1,1>", "gemm_kernel<1,2,4,1,0,1,1,1>", "gemm_kernel<1,3,4,1,0,2,2,1>",
                                            "gemm_kernel<1,4,4,1,1,2,1,1>", "inception_fused_kernel<1>",
@@ -85,7 +85,7 @@ const char* const kKernelNames[K_COUNT] = {"gemm_kernel<1,2,4,1,0,0,1,1>", "gemm
                                            "gemm_kernel<1,1,4,1,2,0,3,1,bf16>", "gemm_kernel<1,1,4,1,2,2,3,1,bf16>",
                                            "lstm_cell_kernel<1>", "lstm_cell_kernel<2>", "lstm_cell_kernel<4>",
                                            "lstm_cell_lds_kernel<1>", "lstm_cell_lds_kernel<2>", "stem23_kernel", "head_folded_kernel",
-                                           "lstm_cell_bf16_kernel<1,1>", "lstm_cell_bf16_kernel<1,2>", "lstm_cell_bf16_kernel<2,2>"};
+                                           "lstm_cell_bf16_kernel<1,1>", "lstm_cell_bf16_kernel<1,2>", "lstm_cell_bf16_kernel<2,2>", "stem23_bf16_kernel"};
 struct KernelStat {
     int64_t launches = 0;
     double total_ms = 0;
@@ -654,10 +654,10 @@ int build_plan(ds_handle* h, int n, Plan* plan)
         add_ew_op(cnn, op);
         if (first_plan) h->stages[st].flops_per_site += 2.0 * h->w1 * 7 * 64;
         const int M = n * h->wa;
-        if (!bf && !h->no_fused && h->wa <= 96 && stem23_lds_bytes(h->wa, 1) <= STEM23_MAX_LDS) {
+        if (!h->no_fused && h->wa <= 96 && (bf ? stem23_bf16_lds_bytes(h->wa, 1) : stem23_lds_bytes(h->wa, 1)) <= STEM23_MAX_LDS) {
             // conv_layer2 + conv_layer3 in one kernel (stem23_kernel): tiles of whole sites, conv2's rows never leave LDS
             Op o2{};
-            o2.kind = OP_STEM23; o2.stream = 0; o2.stage = st;
+            o2.kind = OP_STEM23; o2.stream = 0; o2.stage = st; o2.a = bf;
             o2.sa.X = h->cur->stem_pool; o2.sa.Y = h->cur->conv3o; o2.sa.C2 = h->debug ? h->cur->conv2o : nullptr;
             o2.sa.Bp2 = h->conv2.Bp; o2.sa.bias2 = h->conv2.bias; o2.sa.Bp3 = h->conv3.Bp; o2.sa.bias3 = h->conv3.bias;
             o2.sa.n_sites = n; o2.sa.W = h->wa;
@@ -666,7 +666,7 @@ int build_plan(ds_handle* h, int n, Plan* plan)
             while (spt > 1 && (n + spt - 1) / spt < 256) --spt;
             // the T tile carries two halo rows per site: short sites (signal_len <= 128) at the full 96 rows pass the 80 KB the
             // kernel may ask for at two workgroups per CU (configure_fused_kernels)
-            while (spt > 1 && stem23_lds_bytes(h->wa, spt) > STEM23_MAX_LDS) --spt;
+            while (spt > 1 && (bf ? stem23_bf16_lds_bytes(h->wa, spt) : stem23_lds_bytes(h->wa, spt)) > STEM23_MAX_LDS) --spt;
             o2.sa.spt = spt;
             o2.flops = 2.0 * M * (64.0 * 128 + 384.0 * 256);
             add_ew_op(cnn, o2);
@@ -978,7 +978,8 @@ int issue_op(ds_handle* h, Plan& plan, const Op& op, hipStream_t s)
         HIPCHK(h, launch_lstm_cells(op.c, plan.lstm_launches[op.launch_index], s));
         break;
     case OP_STEM23:
-        HIPCHK(h, launch_stem23(op.sa, s));
+        if (op.a) HIPCHK(h, launch_stem23_bf16(op.sa, s));
+        else HIPCHK(h, launch_stem23(op.sa, s));
         break;
     case OP_HEADF:
         HIPCHK(h, launch_head_folded(op.ha, s));
@@ -1073,7 +1074,7 @@ int kernel_class(const Op& op)
         if (op.fa.cin == 128) return op.tm == 1 ? K_FUSEDB1 : op.tm == 2 ? K_FUSEDB2 : K_FUSEDB3;   // bf16 rows: pitch in units
         return op.tm == 1 ? K_FUSED1 : op.tm == 2 ? K_FUSED2 : K_FUSED3;
     case OP_STEM1: return K_STEM1;
-    case OP_STEM23: return K_STEM23;
+    case OP_STEM23: return op.a ? K_STEM23B : K_STEM23;
     case OP_HEADF: return K_HEADF;
     case OP_MAXPOOL: return K_MAXPOOL;
     case OP_AVGPOOL: return K_AVGPOOL;

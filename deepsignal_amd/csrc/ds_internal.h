@@ -163,6 +163,9 @@ struct Stem23Args {
 };
 hipError_t launch_stem23(const Stem23Args& a, hipStream_t s);
 size_t stem23_lds_bytes(int W, int spt);
+// bf16 form (DS_PRECISION_BF16*): X / Y / C2 are bf16 rows (64 / 256 / 128 channels), Bp2 / Bp3 packed by pack_b_bf16
+hipError_t launch_stem23_bf16(const Stem23Args& a, hipStream_t s);
+size_t stem23_bf16_lds_bytes(int W, int spt);
 constexpr size_t STEM23_MAX_LDS = 80 * 1024;     // dynamic LDS stem23_kernel may ask for (two workgroups per CU)
 // stem conv1 (K=7, stride 2, Cin=1) + folded BN + ReLU + maxpool(3, stride 2)   layers.py:183-191
 hipError_t launch_stem1(const float* signals, const float* w7x64, const float* bias64, float* out,

@@ -1324,6 +1324,10 @@ hipError_t launch_lstm_cells(int nt, const LstmLaunch& L, hipStream_t s)
 #ifndef DS_FUSED_BD
 #define DS_FUSED_BD 2
 #endif
+// (s_setprio 2 for the fp32 pooling waves, as in the bf16 kernel, was measured: 625 against 586 us per step)
+#ifndef DS_FUSED_POOLPRIO
+#define DS_FUSED_POOLPRIO 0
+#endif
 #ifndef DS_FUSED_VD
 #define DS_FUSED_VD 2
 #endif
@@ -1540,7 +1544,10 @@ __global__ __launch_bounds__(512, DS_FUSED_WPS) void inception_fused_kernel(cons
             }
         }
     };
-    if (wave >= 6) run_p1(FusedTagT{}); else run_p1(FusedTagF{});     // wave-uniform
+    // the two pooling waves carry three LDS reads + eight v_max per fragment where the others carry one read: every chunk's
+    // barrier waits for them, so they get the SIMD's issue priority while P1 runs (DS_FUSED_POOLPRIO, measured)
+    if (wave >= 6) { __builtin_amdgcn_s_setprio(DS_FUSED_POOLPRIO); run_p1(FusedTagT{}); __builtin_amdgcn_s_setprio(0); }
+    else run_p1(FusedTagF{});     // wave-uniform
     DS_STAMP(1);
     __syncthreads();   // all fragment reads of the staging area are done before T2 aliases it
     DS_STAMP(2);
@@ -2309,6 +2316,161 @@ hipError_t launch_stem23(const Stem23Args& a, hipStream_t s)
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------
+// conv_layer2 + conv_layer3 with bf16 operands (DS_PRECISION_BF16*): the bf16 form of stem23_kernel.   layers.py:192-203
+// Rows are bf16 (64 channels in, 128 in LDS only, 256 out); v_mfma_f32_32x32x16_bf16, fp32 accumulate, bias = accumulator
+// init, ReLU and one rounding to bf16 when a value is stored. Two workgroups per CU (<= 128 VGPRs, 52 KB of LDS); the
+// 256-channel output rows leave through an LDS tile (over the dead input / conv2 tiles) as whole 512-byte rows.
+// Roofline: HBM. Algorithmic bytes per row: 128 in + 512 out (the two-launch GEMM form also wrote and re-read 256 + 768).
+constexpr int SB_LDX = 36;      // Xs row stride in 4-byte units: 64 channels + 8 pad (9 x 16 B, odd)
+constexpr int SB_LDT = 68;      // T row stride: 128 channels + 8 pad (17 x 16 B)
+constexpr int SB_LDO = 132;     // output tile row stride: 256 channels + 8 pad (33 x 16 B)
+size_t stem23_bf16_lds_bytes(int W, int spt)
+{
+    const size_t work = (size_t)96 * SB_LDX + (size_t)(spt * (W + 2) + 3) * SB_LDT;
+    const size_t outt = (size_t)96 * SB_LDO;
+    return ((work > outt ? work : outt) + 96) * sizeof(float);
+}
+
+__global__ __launch_bounds__(512, 4) void stem23_bf16_kernel(const Stem23Args a)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* const Xs = smem;                                   // [96][SB_LDX]
+    float* const T = smem + 96 * SB_LDX;                      // [spt * (W + 2) + 3][SB_LDT]
+    float* const Ot = smem;                                   // [96][SB_LDO] output tile, over Xs / T once conv3 has read them
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int W = a.W, spt = a.spt;
+    const int trows = spt * (W + 2) + 3;
+    const size_t work = (size_t)96 * SB_LDX + (size_t)trows * SB_LDT, outt = (size_t)96 * SB_LDO;
+    int* const rowmap = reinterpret_cast<int*>(smem + (work > outt ? work : outt));     // [96] tile row -> T row
+    const int site0 = blockIdx.x * spt;
+    const int TRv = min(spt, a.n_sites - site0) * W;
+    const size_t grow0 = (size_t)site0 * W;
+    const int h4 = 4 * (lane >> 5), rlane = lane & 31;
+    unsigned short* const Th = reinterpret_cast<unsigned short*>(T);
+    unsigned short* const Oh = reinterpret_cast<unsigned short*>(Ot);
+    auto pack4 = [](float x0, float x1, float x2, float x3) -> uint2 {
+        return make_uint2((unsigned)f2bf(fmaxf(x0, 0.0f)) | ((unsigned)f2bf(fmaxf(x1, 0.0f)) << 16),
+                          (unsigned)f2bf(fmaxf(x2, 0.0f)) | ((unsigned)f2bf(fmaxf(x3, 0.0f)) << 16));
+    };
+
+    // ---- stage: zero T (halo rows), row map, input rows (96 rows x 8 slots of 16 B: 768 slots)
+    for (int i = tid; i < trows * (SB_LDT / 4); i += 512) reinterpret_cast<float4*>(T)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (tid < 96) rowmap[tid] = tid < TRv ? (tid / W) * (W + 2) + 1 + tid % W : spt * (W + 2) + 1;
+    {
+        float4 v[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int idx = tid + 512 * i, row = idx >> 3, q = idx & 7;
+            const int rr = row < TRv ? row : TRv - 1;
+            if (idx < 768) v[i] = gload4(a.X + (grow0 + rr) * 32 + q * 4);      // 64 bf16 = 32 units per row
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int idx = tid + 512 * i, row = idx >> 3, q = idx & 7;
+            if (idx < 768) *reinterpret_cast<float4*>(Xs + row * SB_LDX + q * 4) = v[i];
+        }
+    }
+    // conv3 weights of this wave's n-tile: 24 k-steps (3 taps x 8), ring of four; both bias vectors
+    const char* const b3 = reinterpret_cast<const char*>(a.Bp3) + (size_t)wave * 24 * 1024;
+    const unsigned lane16 = (unsigned)lane * 16;
+    float4 bq[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) bq[i] = gload4(reinterpret_cast<const float*>(b3 + i * 1024 + lane16));
+    float4 bias3[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) bias3[g] = gload4(a.bias3 + wave * 32 + 8 * g + h4);
+    __syncthreads();
+
+    // ---- conv2: K = 64 (4 k-steps); unit (m, n): waves 0..3 take (0, w) and (2, w), waves 4..7 take (1, w - 4)
+    {
+        const int n2 = wave & 3;
+        float4 w2[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) w2[g] = gload4(a.Bp2 + ((size_t)(n2 * 4 + g) * 64 + lane) * 4);
+        float4 bias2[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) bias2[g] = gload4(a.bias2 + n2 * 32 + 8 * g + h4);
+        const int nunits = wave < 4 ? 2 : 1;
+        for (int ui = 0; ui < nunits; ++ui) {
+            const int m = wave < 4 ? 2 * ui : 1;
+            floatx16 u;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) { u[4 * g] = bias2[g].x; u[4 * g + 1] = bias2[g].y; u[4 * g + 2] = bias2[g].z; u[4 * g + 3] = bias2[g].w; }
+            const float* xr = Xs + (m * 32 + rlane) * SB_LDX + h4;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) u = mfma_bf(w2[g], *reinterpret_cast<const float4*>(xr + g * 8), u);
+            const int row = m * 32 + rlane;
+            unsigned short* const td = Th + rowmap[row] * (2 * SB_LDT) + n2 * 32 + h4;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const uint2 o = pack4(u[4 * g], u[4 * g + 1], u[4 * g + 2], u[4 * g + 3]);
+                *reinterpret_cast<uint2*>(td + 8 * g) = o;
+                if (a.C2 && row < TRv) {                       // diagnostic tap (debug mode): conv_layer2's output rows, bf16
+                    typedef unsigned int u2v __attribute__((ext_vector_type(2)));
+                    const u2v ov = {o.x, o.y};
+                    *(__attribute__((address_space(1))) u2v*)(reinterpret_cast<unsigned short*>(a.C2) + (grow0 + row) * 128 + n2 * 32 + 8 * g + h4) = ov;
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- conv3: wave w = output channels [32 w, 32 w + 32) of all three m-tiles; 24 k-steps out of T without a barrier
+    floatx16 acc[3];
+#pragma unroll
+    for (int m = 0; m < 3; ++m)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) { acc[m][4 * g] = bias3[g].x; acc[m][4 * g + 1] = bias3[g].y; acc[m][4 * g + 2] = bias3[g].z; acc[m][4 * g + 3] = bias3[g].w; }
+    const float* tb[3];
+#pragma unroll
+    for (int m = 0; m < 3; ++m) tb[m] = T + (rowmap[m * 32 + rlane] - 1) * SB_LDT + h4;     // tap t reads row + t - 1
+    float4 af[3];
+#pragma unroll
+    for (int m = 0; m < 3; ++m) af[m] = *reinterpret_cast<const float4*>(tb[m]);
+#pragma unroll
+    for (int ks = 0; ks < 24; ++ks) {
+        const int slot = ks & 3;
+#pragma unroll
+        for (int m = 0; m < 3; ++m) acc[m] = mfma_bf(bq[slot], af[m], acc[m]);
+        if (ks + 4 < 24) bq[slot] = gload4(reinterpret_cast<const float*>(b3 + (ks + 4) * 1024 + lane16));
+        if (ks + 1 < 24) {
+            const int t1 = (ks + 1) >> 3, g1 = (ks + 1) & 7;
+#pragma unroll
+            for (int m = 0; m < 3; ++m) af[m] = *reinterpret_cast<const float4*>(tb[m] + t1 * SB_LDT + g1 * 8);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();   // everybody has read T: the output tile may overwrite it
+
+    // ---- ReLU, bf16, output tile, whole rows out
+#pragma unroll
+    for (int m = 0; m < 3; ++m)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            *reinterpret_cast<uint2*>(Oh + (m * 32 + rlane) * (2 * SB_LDO) + wave * 32 + 8 * g + h4) =
+                pack4(acc[m][4 * g], acc[m][4 * g + 1], acc[m][4 * g + 2], acc[m][4 * g + 3]);
+    __syncthreads();
+    __attribute__((address_space(1))) unsigned short* const Yg =
+        (__attribute__((address_space(1))) unsigned short*)(reinterpret_cast<unsigned short*>(a.Y) + grow0 * 256);
+    for (int idx = tid; idx < 96 * 32; idx += 512) {           // 256 channels = 32 x 16 B per row
+        const int row = idx >> 5, q = idx & 31;
+        if (row < TRv) {
+            const float4 v = *reinterpret_cast<const float4*>(Ot + row * SB_LDO + q * 4);
+            v4f o = {v.x, v.y, v.z, v.w};
+            *(__attribute__((address_space(1))) v4f*)(Yg + (unsigned)(row * 256 + q * 8)) = o;
+        }
+    }
+}
+
+hipError_t launch_stem23_bf16(const Stem23Args& a, hipStream_t s)
+{
+    if (a.n_sites <= 0) return hipSuccess;
+    const int grid = (a.n_sites + a.spt - 1) / a.spt;
+    hipLaunchKernelGGL(stem23_bf16_kernel, dim3(grid), dim3(512), stem23_bf16_lds_bytes(a.W, a.spt), s, a);
+    return hipGetLastError();
+}
+
 // The fused kernels need more than the default 64 KB of dynamic LDS: opt in once per device (ds_create calls this
 // after hipSetDevice; function attributes are per device and must not be changed during stream capture).
 hipError_t configure_fused_kernels()
@@ -2320,6 +2482,8 @@ hipError_t configure_fused_kernels()
         const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
     }
+    const hipError_t e2 = hipFuncSetAttribute((const void*)stem23_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)STEM23_MAX_LDS);
+    if (e2 != hipSuccess) return e2;
     return hipFuncSetAttribute((const void*)stem23_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)STEM23_MAX_LDS);
 }
 
