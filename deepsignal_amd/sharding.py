@@ -141,31 +141,49 @@ class OrderedRowGather:
         return self.total_sites, self.total_errors
 
     def _run(self):
+        import warnings
         import torch
         try:
             dist, world, rank = self.dist, self.world, self.rank
             dev = self.device if self.device is not None else torch.device("cpu")
-            if dev.type == "cuda":
+            on_gpu = dev.type == "cuda"
+            if on_gpu:
                 torch.cuda.set_device(dev)
+            # staging reused across rounds (grown when a round is bigger): on a GPU the rows go host -> PINNED buffer ->
+            # device buffer -> RCCL, and on rank 0 back through one pinned buffer; one host sync per round for the lengths
+            cap = 0
+            pin = dbuf = gbuf = pin_out = None
+            lens_dev = torch.zeros(world, dtype=torch.int64, device=dev)
             for _ in range(self.nrounds):
                 data = self._q.get()
                 n_local = torch.tensor([len(data)], dtype=torch.int64, device=dev)
-                lens = [torch.zeros_like(n_local) for _ in range(world)]
-                dist.all_gather(lens, n_local)
-                lens = [int(x.item()) for x in lens]
+                dist.all_gather_into_tensor(lens_dev, n_local)
+                lens = [int(x) for x in lens_dev.cpu().tolist()]
                 nmax = max(lens)
                 if nmax == 0:
                     continue
-                buf = torch.zeros(nmax, dtype=torch.uint8)
+                if nmax > cap:
+                    cap = max(nmax, 2 * cap, 1 << 20)
+                    pin = torch.empty(cap, dtype=torch.uint8, pin_memory=on_gpu)
+                    dbuf = torch.empty(cap, dtype=torch.uint8, device=dev) if on_gpu else pin
+                    if rank == 0:
+                        gbuf = torch.empty(world * cap, dtype=torch.uint8, device=dev)
+                        pin_out = torch.empty(world * cap, dtype=torch.uint8, pin_memory=on_gpu)
                 if data:
-                    buf[:len(data)] = torch.frombuffer(bytearray(data), dtype=torch.uint8)
-                buf = buf.to(dev)
-                gl = [torch.empty_like(buf) for _ in range(world)] if rank == 0 else None
-                dist.gather(buf, gl, dst=0)
+                    with warnings.catch_warnings():       # bytes are immutable: a read-only view is all that is needed (one copy)
+                        warnings.simplefilter("ignore")
+                        pin[:len(data)] = torch.frombuffer(data, dtype=torch.uint8)
+                if on_gpu:
+                    dbuf[:nmax].copy_(pin[:nmax], non_blocking=True)
+                gl = [gbuf[r * nmax:(r + 1) * nmax] for r in range(world)] if rank == 0 else None
+                dist.gather(dbuf[:nmax], gl, dst=0)
                 if rank == 0:
+                    host = pin_out[:world * nmax]
+                    host.copy_(gbuf[:world * nmax])                                   # one D2H copy (synchronous into pinned memory)
+                    hv = host.numpy()
                     for r in range(world):
                         if lens[r]:
-                            self._wf.write(gl[r][:lens[r]].cpu().numpy().tobytes())
+                            self._wf.write(hv[r * nmax:r * nmax + lens[r]].tobytes())
                             self.bytes_gathered += lens[r] if r else 0
                     self._wf.flush()
             counts = self._q.get()
