@@ -154,7 +154,6 @@ struct ds_handle {
     bool is_cnn = true, is_rnn = true, is_base = true;   // model.py:28-29,59-75,89-95
     bool bf16 = false;    // DS_PRECISION_BF16: bf16 conv + FC operands (fp32 accumulate), fp32 BiLSTM
     int lstm_variant = 0;     // ds_config.reserved[3] as given (DS_LSTM_TILING_*)
-    int lstm_t = -1;          // LSTM cell tiling: 1 = always 128 x 32 (CFG_*LSTM_T), 0 = always 128 x 128, -1 = by forward size
     // per-handle tuning / diagnostic knobs, all from ds_config.reserved[2..5] (include/deepsignal_hip.h)
     bool no_fused = false;    // DS_TUNE_NO_FUSED: layer-granular inception modules instead of the fused kernel
     bool fold_fc = false;     // joint model folded into one J x class_num matrix (fp32, not DS_TUNE_NO_FOLD_FC, not debug)
@@ -180,8 +179,7 @@ struct ds_handle {
     PackedGemm conv2, conv3;
     PackedGemm m_f1[NMOD];   // fused-module stage 1: [b5s|b2|b3a|b4a|b5a|b1]
     PackedGemm m_s1[NMOD], m_b1[NMOD], m_b3b[NMOD], m_b4b[NMOD], m_b5b[NMOD], m_b5c[NMOD];
-    PackedGemm lstm[2][NLAYER];
-    PackedGemm lstm_n[2][NLAYER];   // the same cells packed for the 128 x 32 tiling ([gate][8 units] columns per n-tile)
+    PackedGemm lstm_n[2][NLAYER];   // LSTM kernels packed [gate][8 units] per n-tile (fp32 or bf16 fragments)
     float* lstm_table[2] = {nullptr, nullptr};
     float* lstm_wfeat[2] = {nullptr, nullptr};
     PackedGemm fc1;
@@ -572,8 +570,6 @@ void add_tiles(GemmLaunch& L, GemmProblem& P, GemmCfg cfg, const float* zero16)
     P.tiles_n = (P.N + g.bn - 1) / g.bn;
     P.ntiles32 = (P.N + 31) / 32;
     P.n_fast = (double)P.M > (double)P.N ? 1 : 0;      // A bytes (M*K) vs B bytes (K*N)
-    if (cfg == CFG_LSTM_T || cfg == CFG_LSTM_T_DENSE || cfg == CFG_BLSTM_T || cfg == CFG_BLSTM_T_DENSE)
-        P.n_fast = 1;                                   // 128 x 32 tiles: the activation tile is the big operand
     P.tile_start = L.total_tiles;
     L.total_tiles += P.tiles_m * P.tiles_n;
     L.prob[L.nprob++] = P;
@@ -627,7 +623,7 @@ int build_plan(ds_handle* h, int n, Plan* plan)
         Op op{};
         op.kind = OP_GEMM; op.stream = stream; op.stage = stage; op.cfg = cfg;
         op.launch_index = (int)LS.size(); op.total_tiles = L.total_tiles;
-        const bool bf_cfg = (cfg >= CFG_BCONV && cfg <= CFG_BLSTM_DENSE) || cfg == CFG_BLSTM_T || cfg == CFG_BLSTM_T_DENSE;
+        const bool bf_cfg = cfg >= CFG_BCONV && cfg <= CFG_BFC_DENSE;
         const double kelems = (bf_cfg ? 2.0 : 1.0) * kscale;   // bf16 problems count K in units; kscale removes zero pad
         for (int i = 0; i < L.nprob; ++i) op.flops += 2.0 * L.prob[i].M * (double)L.prob[i].N * L.prob[i].K * kelems;
         LS.push_back(L);
@@ -1062,14 +1058,10 @@ int kernel_class(const Op& op)
 {
     switch (op.kind) {
     case OP_GEMM:
-        return op.cfg == CFG_CONV ? K_GEMM_CONV : op.cfg == CFG_FC ? K_GEMM_FC : op.cfg == CFG_LSTM ? K_GEMM_LSTM
+        return op.cfg == CFG_CONV ? K_GEMM_CONV : op.cfg == CFG_FC ? K_GEMM_FC
                : op.cfg == CFG_CONV_POOL ? K_GEMM_CONV_POOL : op.cfg == CFG_FC_DENSE ? K_GEMM_FC_DENSE
-               : op.cfg == CFG_LSTM_DENSE ? K_GEMM_LSTM_DENSE : op.cfg == CFG_BCONV ? K_GEMM_BCONV
-               : op.cfg == CFG_BCONV_POOL ? K_GEMM_BCONV_POOL : op.cfg == CFG_BFC ? K_GEMM_BFC
-               : op.cfg == CFG_BFC_DENSE ? K_GEMM_BFC_DENSE : op.cfg == CFG_BLSTM ? K_GEMM_BLSTM
-               : op.cfg == CFG_BLSTM_DENSE ? K_GEMM_BLSTM_DENSE : op.cfg == CFG_LSTM_T ? K_GEMM_LSTM_T
-               : op.cfg == CFG_LSTM_T_DENSE ? K_GEMM_LSTM_T_DENSE : op.cfg == CFG_BLSTM_T ? K_GEMM_BLSTM_T
-               : op.cfg == CFG_BLSTM_T_DENSE ? K_GEMM_BLSTM_T_DENSE : K_GEMM_CONV_WIDE;
+               : op.cfg == CFG_BCONV ? K_GEMM_BCONV : op.cfg == CFG_BCONV_POOL ? K_GEMM_BCONV_POOL : op.cfg == CFG_BFC ? K_GEMM_BFC
+               : op.cfg == CFG_BFC_DENSE ? K_GEMM_BFC_DENSE : K_GEMM_CONV_WIDE;
     case OP_FUSED:
         if (op.fa.cin == 128) return op.tm == 1 ? K_FUSEDB1 : op.tm == 2 ? K_FUSEDB2 : K_FUSEDB3;   // bf16 rows: pitch in units
         return op.tm == 1 ? K_FUSED1 : op.tm == 2 ? K_FUSED2 : K_FUSED3;
@@ -1247,7 +1239,6 @@ static int ds_create_impl(const ds_config* cfg, ds_handle** out)
     h->serial = (flags & DS_TUNE_SERIAL) != 0;
     h->serial_modules = (flags & DS_TUNE_NO_CHAIN) != 0;
     h->fold_fc = !(flags & DS_TUNE_NO_FOLD_FC) && cfg->reserved[0] == 0 && cfg->class_num <= 16;
-    h->lstm_t = cfg->reserved[3] == DS_LSTM_TILING_NARROW ? 1 : cfg->reserved[3] == DS_LSTM_TILING_WIDE ? 0 : -1;
     h->lstm_variant = cfg->reserved[3];
     if (cfg->reserved[4] > 0) h->fuse_max_spt = cfg->reserved[4];
     if (cfg->reserved[5] > 0) h->fuse_min_tiles = cfg->reserved[5];

@@ -34,22 +34,6 @@ struct OSeg {
     int bf16;           // 1: base is a bf16 buffer (ld / col offsets in bf16 elements), values rounded to nearest even
 };
 
-// Fused LSTM-cell epilogue (TF-1.x LSTMCell, gate order i,j,f,o, forget_bias 1.0).
-struct LstmEp {
-    const float* table;   // [vocab][1024] embedding x W_x(layer 0), or nullptr
-    const float* wfeat;   // [3][1024] rows of W_x for (mean, std, len)
-    const int* codes;     // [n][T]
-    const float* means;   // [n][T]
-    const float* stds;
-    const float* lens;
-    float* c;             // [n][256] cell state (read-modify-write)
-    float* h_out;         // [n][256] (bf16 [n][256] in the bf16-operand instantiations)
-    int t;                // original time index this step consumes
-    int T;
-    int c_zero;           // 1: previous c is zero (first step)
-    int use_feat;         // 1: layer 0 — add mean/std/len rank-1 terms (and the table row when table != nullptr)
-};
-
 struct GemmProblem {
     int M, N, K, W;             // K = sum of the used segments' klen
     int a_mode;                 // informational: 1 = maxpool(3, stride 1, SAME) on load (kernel variant CFG_CONV_POOL)
@@ -60,8 +44,7 @@ struct GemmProblem {
     ASeg seg[MAX_SEG];
     OSeg out[MAX_OUT];
     const float* Bp;            // pre-packed weights [ntile][kgroup][64 lanes][4]
-    const float* bias;          // [N] (folded BN shift / LSTM bias in TF column order)
-    LstmEp lstm;
+    const float* bias;          // [N] (folded BN shift)
     int tiles_m, tiles_n, tile_start, ntiles32;   // ntiles32 = ceil(N/32)
 };
 
@@ -72,11 +55,10 @@ struct GemmLaunch {
     int pad_[2];
 };
 
-enum GemmCfg { CFG_CONV = 0, CFG_FC = 1, CFG_LSTM = 2, CFG_CONV_WIDE = 3, CFG_CONV_POOL = 4, CFG_FC_DENSE = 5, CFG_LSTM_DENSE = 6,
+// (the numbering keeps the gaps the BiLSTM configurations of rounds 1 - 2 left: the cells have their own kernels now)
+enum GemmCfg { CFG_CONV = 0, CFG_FC = 1, CFG_CONV_WIDE = 3, CFG_CONV_POOL = 4, CFG_FC_DENSE = 5,
                // bf16-operand variants (mixed-precision mode)
-               CFG_BCONV = 7, CFG_BCONV_POOL = 8, CFG_BFC = 9, CFG_BFC_DENSE = 10, CFG_BLSTM = 11, CFG_BLSTM_DENSE = 12,
-               // fp32 LSTM cell on 128 x 32 tiles (transposed MFMA, [gate][8 units] column order inside a tile)
-               CFG_LSTM_T = 13, CFG_LSTM_T_DENSE = 14, CFG_BLSTM_T = 15, CFG_BLSTM_T_DENSE = 16 };
+               CFG_BCONV = 7, CFG_BCONV_POOL = 8, CFG_BFC = 9, CFG_BFC_DENSE = 10 };
 
 // ---- fp32 BiLSTM cell launch (lstm_cell_kernel) ---------------------------------------------------------------
 // h and c of the fp32 BiLSTM live in MFMA-FRAGMENT-MAJOR buffers: [m-tile of 32 sites][k-group of 8 units][64 lanes][4]

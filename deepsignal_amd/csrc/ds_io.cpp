@@ -270,6 +270,18 @@ static int usable_cpus()
     return n;
 }
 
+namespace {
+// "row N" for the whole file; inside a byte range (sharded call_mods: ds_tsv_set_range) the row count is relative to the
+// range, so the message names the range and the absolute byte offset of the line -- `tail -c +OFFSET file | head -1`
+std::string row_where(const ds_tsv* t, int64_t index0, const char* line)
+{
+    std::string w = "row " + std::to_string(index0 + 1);
+    if (t->range_begin != 0 || t->limit != t->size)
+        w += " of the byte range [" + std::to_string(t->range_begin) + ", " + std::to_string(t->limit) + ")";
+    return w + " (line at byte offset " + std::to_string((long long)(line - t->data)) + ")";
+}
+}  // namespace
+
 extern "C" {
 
 int ds_tsv_open(const char* path, int32_t kmer_len, int32_t signal_len, int32_t nthreads, ds_tsv** out)
@@ -305,18 +317,6 @@ void ds_tsv_close(ds_tsv* t)
 }
 
 const char* ds_tsv_error(const ds_tsv* t) { return t ? t->err.c_str() : "null reader"; }
-
-namespace {
-// "row N" for the whole file; inside a byte range (sharded call_mods: ds_tsv_set_range) the row count is relative to the
-// range, so the message names the range and the absolute byte offset of the line -- `tail -c +OFFSET file | head -1`
-std::string row_where(const ds_tsv* t, int64_t index0, const char* line)
-{
-    std::string w = "row " + std::to_string(index0 + 1);
-    if (t->range_begin != 0 || t->limit != t->size)
-        w += " of the byte range [" + std::to_string(t->range_begin) + ", " + std::to_string(t->limit) + ")";
-    return w + " (line at byte offset " + std::to_string((long long)(line - t->data)) + ")";
-}
-}  // namespace
 
 // Next queue item: all rows of the next `max_reads` reads (a read = maximal run of consecutive rows with the
 // same column 5). Returns the number of sites, 0 at end of file, negative on a malformed row.

@@ -96,7 +96,7 @@ __device__ __forceinline__ float bf2f(unsigned short b) { return __uint_as_float
 // accumulators are exchanged through LDS at the end. It doubles the waves per SIMD for grids that
 // only have ~one workgroup per CU and halves the serial chunk chain of short-K problems.
 template <int MT, int NT, int WM, int WN, int EPI, int AMODE, int BD, int KS, bool BF = false>
-__global__ __launch_bounds__(64 * WM * WN * KS, EPI == 2 ? 3 : (EPI == 1 && KS == 1) ? 2 : 1) void gemm_kernel(const GemmLaunch* __restrict__ L)
+__global__ __launch_bounds__(64 * WM * WN * KS, 1) void gemm_kernel(const GemmLaunch* __restrict__ L)
 {
     constexpr int BM = WM * MT * 32;
     constexpr int LDA = KC + 4;
@@ -280,19 +280,8 @@ __global__ __launch_bounds__(64 * WM * WN * KS, EPI == 2 ? 3 : (EPI == 1 && KS =
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 if (BF) {
-                    if (EPI == 2)
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bq[J][nt][rs]),
-                                                                              __builtin_bit_cast(bf16x8, af[X][rs][mt]), acc[mt][nt], 0, 0, 0);
-                    else
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[X][rs][mt]),
-                                                                              __builtin_bit_cast(bf16x8, bq[J][nt][rs]), acc[mt][nt], 0, 0, 0);
-                    continue;
-                }
-                if (EPI == 2) {      // transposed product (X W)^T: a lane holds one row and 16 of the tile's columns
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(bq[J][nt][rs].x, af[X][rs][mt].x, acc[mt][nt], 0, 0, 0);
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(bq[J][nt][rs].y, af[X][rs][mt].y, acc[mt][nt], 0, 0, 0);
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(bq[J][nt][rs].z, af[X][rs][mt].z, acc[mt][nt], 0, 0, 0);
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(bq[J][nt][rs].w, af[X][rs][mt].w, acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[X][rs][mt]),
+                                                                          __builtin_bit_cast(bf16x8, bq[J][nt][rs]), acc[mt][nt], 0, 0, 0);
                     continue;
                 }
                 acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[X][rs][mt].x, bq[J][nt][rs].x, acc[mt][nt], 0, 0, 0);
@@ -517,147 +506,8 @@ __global__ __launch_bounds__(64 * WM * WN * KS, EPI == 2 ? 3 : (EPI == 1 && KS =
                     }
                 }
         }
-    } else if (EPI == 2) {
-        // LSTM cell on 128 x 32 tiles (MT = NT = 1): the 32 columns of n-tile p are [gate 0..3][8 units] of units
-        // 8p .. 8p+7 (weights packed so) and the product is transposed, so register 4g+e of a lane is gate g of unit
-        // 8p + 4*(lane >> 5) + e for ONE site (lane & 31): all four gates of four neighbouring units sit in one lane,
-        // and c / h / bias / table rows move as float4. Same arithmetic (and rounding) as the 128 x 128 variant; the
-        // point of the narrow tile is occupancy: 768 workgroups per full diagonal at 512 sites, three per CU.
-        const LstmEp E = P.lstm;
-        const int p8 = (tn * WN + wn) * 8 + 4 * (lane >> 5);            // first of this lane's four units
-        const int row = m0 + wm * 32 + (lane & 31);
-        if (nvalid[0] && (AMODE == 2 || row < M)) {
-            const bool has_table = E.table != nullptr, has_feat = E.use_feat != 0;
-            float4 z[4];                                                 // z[g] = pre-activations of gate g, units p8..p8+3
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                float4 b = gload4(P.bias + g * 256 + p8);
-                if (g == 2) { b.x += 1.0f; b.y += 1.0f; b.z += 1.0f; b.w += 1.0f; }     // forget_bias folded into the bias, as in EPI 1
-                z[g] = make_float4(acc[0][0][4 * g] + b.x, acc[0][0][4 * g + 1] + b.y, acc[0][0][4 * g + 2] + b.z, acc[0][0][4 * g + 3] + b.w);
-            }
-            if (has_feat) {
-                const unsigned it = (unsigned)row * E.T + E.t;
-                const float f0 = gload(E.means + it), f1 = gload(E.stds + it), f2 = gload(E.lens + it);
-                // codes index the folded [vocab = 1024][1024] table; a non-Python client may pass anything: clamp
-                const int code = has_table ? min(max(*(const __attribute__((address_space(1))) int*)(E.codes + it), 0), 1023) : 0;
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const float4 w0 = gload4(E.wfeat + g * 256 + p8), w1 = gload4(E.wfeat + 1024 + g * 256 + p8),
-                                 w2 = gload4(E.wfeat + 2048 + g * 256 + p8);
-                    float4 x = make_float4(fmaf(f2, w2.x, fmaf(f1, w1.x, f0 * w0.x)), fmaf(f2, w2.y, fmaf(f1, w1.y, f0 * w0.y)),
-                                           fmaf(f2, w2.z, fmaf(f1, w1.z, f0 * w0.z)), fmaf(f2, w2.w, fmaf(f1, w1.w, f0 * w0.w)));
-                    if (has_table) {
-                        const float4 tb = gload4(E.table + (size_t)code * 1024 + g * 256 + p8);
-                        x.x += tb.x; x.y += tb.y; x.z += tb.z; x.w += tb.w;
-                    }
-                    z[g].x += x.x; z[g].y += x.y; z[g].z += x.z; z[g].w += x.w;
-                }
-            }
-            const size_t off = (size_t)row * 256 + p8;
-            float4 cp = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (!E.c_zero) cp = gload4(E.c + off);
-            float4 cn, hn;
-            cn.x = fmaf(fast_sigmoid(z[2].x), cp.x, fast_sigmoid(z[0].x) * fast_tanh(z[1].x));
-            cn.y = fmaf(fast_sigmoid(z[2].y), cp.y, fast_sigmoid(z[0].y) * fast_tanh(z[1].y));
-            cn.z = fmaf(fast_sigmoid(z[2].z), cp.z, fast_sigmoid(z[0].z) * fast_tanh(z[1].z));
-            cn.w = fmaf(fast_sigmoid(z[2].w), cp.w, fast_sigmoid(z[0].w) * fast_tanh(z[1].w));
-            hn.x = fast_sigmoid(z[3].x) * fast_tanh(cn.x);
-            hn.y = fast_sigmoid(z[3].y) * fast_tanh(cn.y);
-            hn.z = fast_sigmoid(z[3].z) * fast_tanh(cn.z);
-            hn.w = fast_sigmoid(z[3].w) * fast_tanh(cn.w);
-            v4f co = {cn.x, cn.y, cn.z, cn.w};
-            *(__attribute__((address_space(1))) v4f*)(E.c + off) = co;
-            if (BF) {
-                typedef unsigned int u2v __attribute__((ext_vector_type(2)));
-                const u2v ho = {(unsigned)f2bf(hn.x) | ((unsigned)f2bf(hn.y) << 16), (unsigned)f2bf(hn.z) | ((unsigned)f2bf(hn.w) << 16)};
-                *(__attribute__((address_space(1))) u2v*)(reinterpret_cast<unsigned short*>(E.h_out) + off) = ho;
-            } else {
-                v4f ho = {hn.x, hn.y, hn.z, hn.w};
-                *(__attribute__((address_space(1))) v4f*)(E.h_out + off) = ho;
-            }
-        }
-    } else {
-        // NT == 4: the wave's four n-tiles are gates i,j,f,o of unit group ug (weights packed so).
-        // Uniform (SGPR) base pointers + 32-bit per-lane offsets keep the address math off the VALU;
-        // each half of the rows issues all its loads before any gate math or store.
-        const LstmEp E = P.lstm;
-        const int ug = tn * WN + wn;
-        const unsigned u = ug * 32 + (lane & 31);
-        if (nvalid[0]) {
-            const gptr1 biasg = (gptr1)P.bias;
-            const float bi = biasg[u], bj = biasg[256 + u], bf = biasg[512 + u] + 1.0f, bo = biasg[768 + u];   // forget_bias folded
-            const bool has_table = E.table != nullptr;     // is_base: embedding folded into a [vocab][1024] table
-            const bool has_feat = E.use_feat != 0;         // layer 0: (mean, std, len) rank-1 terms
-            float wi[3] = {0, 0, 0}, wj[3] = {0, 0, 0}, wf[3] = {0, 0, 0}, wo[3] = {0, 0, 0};
-            if (has_feat) {
-                const gptr1 wg = (gptr1)E.wfeat;
-#pragma unroll
-                for (int q = 0; q < 3; ++q) {
-                    wi[q] = wg[q * 1024 + u];
-                    wj[q] = wg[q * 1024 + 256 + u];
-                    wf[q] = wg[q * 1024 + 512 + u];
-                    wo[q] = wg[q * 1024 + 768 + u];
-                }
-            }
-            const gptr1 cg = (gptr1)E.c;
-            const gptr1w cgw = (gptr1w)E.c;
-            const gptr1w hg = (gptr1w)E.h_out;
-            __attribute__((address_space(1))) unsigned short* const hbg = (__attribute__((address_space(1))) unsigned short*)E.h_out;   // BF: h is stored as bf16
-            const gptr1 tabg = (gptr1)E.table;
-            const gptr1 meang = (gptr1)E.means, stdg = (gptr1)E.stds, leng = (gptr1)E.lens;
-            const __attribute__((address_space(1))) int* codeg = (const __attribute__((address_space(1))) int*)E.codes;
-            const bool c_zero = E.c_zero != 0;
-            const unsigned Tt = E.T, tt = E.t;
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                for (int hb = 0; hb < 2; ++hb) {
-                    if (hb * 8 < r_lo || hb * 8 >= r_hi) continue;      // rows owned by the other K-lane
-                    float cp[8], xi[8], xj[8], xf[8], xo[8];
-                    unsigned off[8];
-                    bool ok[8];
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) {
-                        const int r = hb * 8 + k;
-                        const int row = rbase + mt * 32 + (r & 3) + 8 * (r >> 2);
-                        ok[k] = AMODE == 2 || row < M;
-                        const unsigned rowc = ok[k] ? row : 0;
-                        off[k] = rowc * 256u + u;
-                        cp[k] = c_zero ? 0.0f : cg[off[k]];
-                        xi[k] = xj[k] = xf[k] = xo[k] = 0.0f;
-                        if (has_feat) {
-                            const unsigned it = rowc * Tt + tt;
-                            const float f0 = meang[it], f1 = stdg[it], f2 = leng[it];
-                            // explicit fma chains: every instantiation of this template (dense / masked rows) must
-                            // round identically, so a site's result does not depend on the batch it travels in
-                            xi[k] = fmaf(f2, wi[2], fmaf(f1, wi[1], f0 * wi[0]));
-                            xj[k] = fmaf(f2, wj[2], fmaf(f1, wj[1], f0 * wj[0]));
-                            xf[k] = fmaf(f2, wf[2], fmaf(f1, wf[1], f0 * wf[0]));
-                            xo[k] = fmaf(f2, wo[2], fmaf(f1, wo[1], f0 * wo[0]));
-                            if (has_table) {
-                                const unsigned tb = (unsigned)min(max(codeg[it], 0), 1023) * 1024u + u;
-                                xi[k] += tabg[tb];
-                                xj[k] += tabg[tb + 256];
-                                xf[k] += tabg[tb + 512];
-                                xo[k] += tabg[tb + 768];
-                            }
-                        }
-                    }
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) {
-                        const int r = hb * 8 + k;
-                        const float zi = (acc[mt][0 % NT][r] + bi) + xi[k], zj = (acc[mt][1 % NT][r] + bj) + xj[k];
-                        const float zf = (acc[mt][2 % NT][r] + bf) + xf[k], zo = (acc[mt][3 % NT][r] + bo) + xo[k];
-                        const float cn = fmaf(fast_sigmoid(zf), cp[k], fast_sigmoid(zi) * fast_tanh(zj));
-                        const float hn = fast_sigmoid(zo) * fast_tanh(cn);
-                        if (ok[k]) {
-                            cgw[off[k]] = cn;
-                            if (BF) hbg[off[k]] = f2bf(hn); else hg[off[k]] = hn;
-                        }
-                    }
-                }
-        }
     }
+    static_assert(EPI == 0, "the BiLSTM epilogues left this template in round 3 (lstm_cell_*kernel)");
 }
 
 TileGeom gemm_geom(GemmCfg cfg)
@@ -665,21 +515,13 @@ TileGeom gemm_geom(GemmCfg cfg)
     switch (cfg) {
     case CFG_CONV: return {128, 64, 256, 1};        // MT1 NT2 WM4 WN1
     case CFG_FC: return {128, 96, 256, 1};          // MT1 NT3 WM4 WN1, weights prefetched 2 chunks ahead
-    case CFG_LSTM: return {128, 128, 256, 1};       // MT1 NT4 WM4 WN1 (one 32-unit gate group per block)
     case CFG_CONV_WIDE: return {128, 128, 256, 1};  // MT2 NT2 WM2 WN2
     case CFG_CONV_POOL: return {128, 64, 256, 1};   // CFG_CONV with maxpool(3,s1) fused into the A load
-    case CFG_FC_DENSE: return {128, 96, 256, 1};    // CFG_FC / CFG_LSTM for M % 128 == 0 (no row masks)
-    case CFG_LSTM_DENSE: return {128, 128, 256, 1};
+    case CFG_FC_DENSE: return {128, 96, 256, 1};    // CFG_FC for M % 128 == 0 (no row masks)
     case CFG_BCONV: return {128, 64, 256, 1};       // bf16 operands, same staging as CFG_CONV
     case CFG_BCONV_POOL: return {128, 64, 256, 1};
     case CFG_BFC: return {128, 256, 256, 1};        // MT4 NT2 WM1 WN4: every wave owns all 128 rows x 64 columns, so a
     case CFG_BFC_DENSE: return {128, 256, 256, 1};  // weight fragment is loaded by exactly one wave of the workgroup
-    case CFG_BLSTM: return {128, 128, 256, 1};      // CFG_LSTM with bf16 h / weight operands (fp32 accumulate, gates, cell state)
-    case CFG_BLSTM_DENSE: return {128, 128, 256, 1};
-    case CFG_LSTM_T: return {128, 32, 256, 1};      // transposed, unit-major LSTM cell: MT1 NT1 WM4 WN1
-    case CFG_LSTM_T_DENSE: return {128, 32, 256, 1};
-    case CFG_BLSTM_T: return {128, 32, 256, 1};     // the same with bf16 h / weight operands
-    case CFG_BLSTM_T_DENSE: return {128, 32, 256, 1};
     }
     return {0, 0, 0, 1};
 }
@@ -1804,7 +1646,7 @@ __global__ __launch_bounds__(512, TM >= 2 ? DS_FUSEDB_WPS : 2) void inception_fu
     float* const Y2 = smem;                         //   [TR32][B_LDY] b3|b4|b5 output tile (over the flushed b1|b2 tile)
     float* const T2 = smem + TR32 * B_T2OFF;        //   [TR32][B_LD2] branch 5's 64-channel intermediate
     float* const T1 = smem + TR32 * B_LDA;          // [spt*(W+4)+5][B_LD1]
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int W = c.m[0].W, spt = c.m[0].spt, cinu = c.m[0].cin;          // cin in units (128); the same for every module of a chain
     int* const rowmap = reinterpret_cast<int*>(T1 + (spt * (W + 4) + 5) * B_LD1);
     float* const Bs = reinterpret_cast<float*>(rowmap + TR32);                    // [3][64] biases of b5b | b3b | b4b

@@ -87,6 +87,50 @@ def test_reader_edge_cases(tmp_path):
         fastio.FeatureReader(str(tmp_path / "missing.tsv"))
 
 
+def test_signs_follow_pythons_int_and_float(tmp_path):
+    """The reference reader is int() / float() on every token (call_modifications.py:78-85): a leading '+' is a sign
+    ("+5", "+0.25"), a doubled one ("+-5", "++1") is an error -- not a '+' to skip in front of a negative number."""
+    rows = _synthetic_rows(2, 2, seed=2)
+    cols = rows[0].split("\t")
+    lens, means = cols[9].split(","), cols[7].split(",")
+    ok = str(tmp_path / "ok.tsv")
+    _write(ok, ["\t".join(cols[:7] + [",".join(["+" + means[0].lstrip("-")] + means[1:]), cols[8], ",".join(["+" + lens[0]] + lens[1:])] + cols[10:]), rows[1]])
+    item = list(fastio.FeatureReader(ok).items(50))[0]
+    assert item.lens[0, 0] == float(int(lens[0])) and item.means[0, 0] == np.float32(float("+" + means[0].lstrip("-")))
+    for col, tok in ((9, "+-5"), (9, "++5"), (7, "+-0.5"), (7, "++0.5")):
+        c = list(cols)
+        parts = c[col].split(",")
+        c[col] = ",".join([tok] + parts[1:])
+        bad = str(tmp_path / "bad.tsv")
+        _write(bad, ["\t".join(c), rows[1]])
+        with pytest.raises(ValueError):
+            list(fastio.FeatureReader(bad).items(50))
+        with pytest.raises(ValueError):            # what Python does with the same token
+            (int if col == 9 else float)(tok)
+
+
+def test_error_names_the_byte_range_and_the_lines_offset(tmp_path):
+    """Sharded call_mods restricts a rank's reader to byte ranges: a malformed row must be findable in the FILE (absolute
+    byte offset of the line), not only counted relative to the range."""
+    rows = _synthetic_rows(12, 3, seed=3)
+    rows[7] = rows[7].replace(",", ";", 1)
+    p = str(tmp_path / "f.tsv")
+    _write(p, rows)
+    off7 = sum(len(r) + 1 for r in rows[:7])
+    rd = fastio.FeatureReader(p)
+    with pytest.raises(ValueError) as e:
+        list(rd.items(50))
+    assert "row 8 (line at byte offset %d)" % off7 in str(e.value)
+    cut = rd.align(sum(len(r) + 1 for r in rows[:5]))          # a read boundary at or behind row 6 (reads of 3 rows): row 7
+    assert cut == sum(len(r) + 1 for r in rows[:6])
+    rd.set_range(cut, rd.size)
+    with pytest.raises(ValueError) as e:
+        list(rd.items(50))
+    msg = str(e.value)
+    assert "row 2 of the byte range [%d, %d)" % (cut, rd.size) in msg and "byte offset %d" % off7 in msg
+    rd.close()
+
+
 def test_float32_text_matches_numpy():
     rng = np.random.default_rng(0)
     vals = np.concatenate([

@@ -21,5 +21,11 @@ def test_cu_sharing_register_budgets():
     assert len(fused) == 1 and len(cell) == 1, sorted(res)
     assert fused[0]["vgprs"] <= 184 and fused[0]["scratch_bytes"] == 0, fused[0]
     assert cell[0]["vgprs"] <= 96 and cell[0]["scratch_bytes"] == 0 and cell[0]["static_lds_bytes"] == 0, cell[0]
+    # round 3: the bf16 fused chain and the bf16 conv_layer2/3 kernel run TWO 512-thread workgroups per CU (4 waves per SIMD:
+    # <= 128 VGPRs), the 128 x 128 bf16 BiLSTM tile three 256-thread workgroups (<= 168)
+    for name, cap in (("inception_fused_bf16_kernel<3>", 128), ("inception_fused_bf16_kernel<2>", 128), ("stem23_bf16_kernel", 128),
+                      ("lstm_cell_bf16_kernel<2, 2>", 168), ("lstm_cell_bf16_kernel<1, 1>", 96)):
+        hit = [r for n, r in res.items() if name in n]
+        assert len(hit) == 1 and hit[0]["vgprs"] <= cap, (name, hit)
     # no kernel of the library may spill
     assert all(r["scratch_bytes"] == 0 for r in res.values()), {n: r for n, r in res.items() if r["scratch_bytes"]}
