@@ -136,3 +136,21 @@ def test_module_chain_gives_the_bits_of_one_launch_per_module(small_weights, pre
     dbg.close()
     # debug mode runs the three-step joint model (bf16-operand dense layer): the same sites, a rounding apart
     assert np.isfinite(m11).all() and np.abs(a3 - a1[:130]).max() <= 2e-3
+
+
+def test_bf16_lstm_tile_shapes_give_the_same_bits(small_weights):
+    """lstm_cell_bf16_kernel runs 64 x 64, 64 x 128 or 128 x 128 workgroup tiles by forward size (<= 768, <= 2047, more):
+    every shape accumulates a unit's K in the same order, so a site's bits do not depend on the batch it travels in --
+    also with an odd number of 32-site m-tiles (2100 sites = 66 m-tiles: the last 128-site block is half empty)."""
+    feats = synth.synthetic_features(2100, seed=905)
+    args = [feats[k] for k in ("kmer", "means", "stds", "sanums", "signals")]
+    eng = _engine(small_weights, max_batch=2100, slots=1, precision="bf16_all")
+    a_big, p_big = eng.run(*args)                          # 128 x 128 tiles
+    a_mid, p_mid = eng.run(*(a[:1000] for a in args))      # 64 x 128
+    a_small, p_small = eng.run(*(a[:700] for a in args))   # 64 x 64
+    a_one, p_one = eng.run(*(a[2099:2100] for a in args))
+    eng.close()
+    assert np.isfinite(a_big).all()
+    assert np.array_equal(a_mid, a_big[:1000]) and np.array_equal(p_mid, p_big[:1000])
+    assert np.array_equal(a_small, a_big[:700]) and np.array_equal(p_small, p_big[:700])
+    assert np.array_equal(a_one, a_big[2099:2100]) and np.array_equal(p_one, p_big[2099:2100])
