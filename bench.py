@@ -29,6 +29,7 @@ Extra objects:
   ds_forward_blocking the blocking call the reference makes (call_modifications.py:177-178; INTEGRATION.md binds it):
                       host buffers in, results out, n = 512 and n = 8192 per call
   e2e_tsv             feature TSV -> result TSV through call_mods (native reader + formatter + the default engine)
+  configs2_bf16_batch4096   BASELINE configs[2]: bf16_all / bf16 throughput at batch 4096 and the conv path's HBM fraction
 """
 import argparse
 import json
@@ -253,6 +254,62 @@ def forward_blocking(eng, feats, batch):
     return out
 
 
+def configs2_leg(Engine, w, torch, dev, local_rank):
+    """BASELINE configs[2] inside the driver-run line: bf16 conv + FC with fp32 BiLSTM accumulate, batch 4096 (`bf16_all`: bf16
+    operands everywhere, fp32 accumulate / gates / cell state; `bf16`: fp32 BiLSTM operands as well), resident inputs, 3
+    windows of 30 steps, plus the stand-alone time of the fused inception kernel -> the conv path against the HBM roofline
+    (module-granular bytes: 992 B per module row, 564 module rows per site)."""
+    from deepsignal_amd import synth
+    B, steps = 4096, 30
+    keys = ("kmer", "means", "stds", "sanums", "signals")
+    feats = synth.synthetic_features(B, seed=synth.FEATURE_SEED + 7)
+    d = {k: torch.from_numpy(feats[k]).to(dev) for k in keys}
+    act = torch.zeros((B, 2), dtype=torch.float32, device=dev)
+    pred = torch.zeros((B,), dtype=torch.int32, device=dev)
+    out = {"batch": B, "workload": "configs[2]: 1xMI355X, bf16 conv+FC with fp32 BiLSTM accumulate, batch=4096 (tolerance vs fp32: "
+                                   "tests/test_gpu_bf16.py, profiles/r03_config3_batch4096.json)"}
+    for prec in ("bf16_all", "bf16"):
+        e = Engine(device=local_rank, max_batch=B, precision=prec)
+        e.load_weights(w)
+        step = lambda: e.run_device(B, *(d[k].data_ptr() for k in keys), act.data_ptr(), pred.data_ptr())
+        for _ in range(6):
+            step()
+        e.sync()
+        rates = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                step()
+            e.sync()
+            rates.append(steps * B / (time.perf_counter() - t0))
+        rates.sort()
+        r = {"value": round(rates[1], 1), "unit": "sites/s", "ms_per_step": round(1e3 * B / rates[1], 4),
+             "min": round(rates[0], 1), "max": round(rates[2], 1)}
+        if prec == "bf16_all":
+            e.set_profiling(3)                      # every launch on one stream: stand-alone kernel durations (HIP events)
+            e.reset_stage_times()
+            for _ in range(6):
+                step()
+            e.sync()
+            ks = {k["name"]: k for k in e.kernel_stats() if k["launches"]}
+            e.set_profiling(0)
+            r["kernels_us_per_step_alone"] = {n: round(1e3 * k["total_ms"] / 6, 1) for n, k in ks.items()}
+            conv = [k for n, k in ks.items() if n.startswith("inception_fused_bf16_kernel")]
+            if conv:
+                c_ms = sum(k["total_ms"] for k in conv) / 6
+                c_bytes = 992 * 564 * B
+                out["conv_path_hbm"] = {
+                    "kernel": "inception_fused_bf16_kernel (3 launches: the modules of a width class chained per tile)",
+                    "us_per_step": round(c_ms * 1e3, 1), "algorithmic_bytes": c_bytes, "achieved": round(c_bytes / (c_ms * 1e-3) / 1e9, 1),
+                    "unit": "GB/s", "peak": 8000.0, "frac": round(c_bytes / (c_ms * 1e-3) / 8e12, 4),
+                    "how": "992 B per module row (512 in + 480 out, bf16) x 564 module rows per site x 4096 sites / HIP-event duration, "
+                           "every launch on one stream; HBM-side bytes by PMC: profiles/r03_bf16_all_4096_pmc_traffic.json"}
+        assert bool(torch.isfinite(act).all())
+        out[prec] = r
+        e.close()
+    return out
+
+
 def np_tile(a, n, off):
     """n rows of `a` starting at row `off`, wrapping around (contiguous copy)."""
     import numpy as np
@@ -311,6 +368,7 @@ def main():
     ap.add_argument("--no-host-path", action="store_true", help="skip the pcie_inclusive and e2e_tsv legs")
     ap.add_argument("--no-fast-mode", "--no-three-step", dest="no_fast_mode", action="store_true",
                     help="skip the fast_mode_folded leg (the default engine with the folded joint model)")
+    ap.add_argument("--no-configs2", action="store_true", help="skip the BASELINE configs[2] leg (bf16 modes at batch 4096)")
     ap.add_argument("--lstm-tiling", default="auto", help="diagnostic: force a BiLSTM cell-kernel variant (Engine(lstm_tiling=...))")
     ap.add_argument("--slots", type=int, default=0, help="diagnostic: forwards in flight (0 = engine default, 8)")
     ap.add_argument("--dry-run", action="store_true",
@@ -562,6 +620,8 @@ def main():
         result["fast_mode_folded"] = fm
         engf.close()
     eng.close()
+    if solo and not args.no_configs2:
+        result["configs2_bf16_batch4096"] = configs2_leg(Engine, w, torch, dev, local_rank)
     if solo and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(w)
     if dist is not None:

@@ -8,10 +8,10 @@ OUT=gpurun_out/prof_$R
 mkdir -p $OUT
 export TMPDIR=/tmp
 python3 bench.py > $OUT/bench.json 2> $OUT/bench.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --no-cpu-baseline --no-host-path --no-fast-mode --no-standalone-pass > $OUT/bench_under_rocprof.json 2> $OUT/trace.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --no-cpu-baseline --no-host-path --no-fast-mode --no-configs2 --no-standalone-pass > $OUT/bench_under_rocprof.json 2> $OUT/trace.err
 cp $(ls $OUT/trace/*/*kernel_stats.csv | head -1) $OUT/kernel_stats.csv 2>/dev/null
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 bench.py --steps 4 --warmup 1 --windows 1 --no-cpu-baseline --no-host-path --no-fast-mode --no-profile-pass > /dev/null 2> $OUT/fetch.err
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 bench.py --steps 4 --warmup 1 --windows 1 --no-cpu-baseline --no-host-path --no-fast-mode --no-profile-pass > /dev/null 2> $OUT/write.err
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 bench.py --steps 4 --warmup 1 --windows 1 --no-cpu-baseline --no-host-path --no-fast-mode --no-configs2 --no-profile-pass > /dev/null 2> $OUT/fetch.err
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 bench.py --steps 4 --warmup 1 --windows 1 --no-cpu-baseline --no-host-path --no-fast-mode --no-configs2 --no-profile-pass > /dev/null 2> $OUT/write.err
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/mfma -- python3 tools/probe_engine.py fp32 512 threestep > /dev/null 2> $OUT/mfma.err
 python3 tools/pmc_traffic.py $OUT/fetch $OUT/write $OUT/pmc_traffic.json > $OUT/pmc_traffic.txt 2>&1
 python3 tools/pmc_mfma_util.py $OUT/mfma $OUT/pmc_mfma_util.json > $OUT/pmc_mfma_util.txt 2>&1
