@@ -172,6 +172,20 @@ def test_call_mods_sharded_route_over_rccl_equals_the_plain_file(rccl, engine512
     assert a.count(b"\n") == n and a == b
 
 
+def test_config4_shard_with_the_gather_on_rccl(rccl, small_weights):
+    """BASELINE configs[3]'s own path (tools/config4.py::run_shard: per-read shard through ds_forward_device, then ONE gather
+    of f32[n,2] + i32[n]) with the gather on RCCL: 204,800 sites, same bits as the run without a process group."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import config4
+    sites = 204_800
+    rec0, a0, p0, _ = config4.run_shard(sites, batch=512, weights=small_weights, pool_sites=4096)
+    rec1, a1, p1, _ = config4.run_shard(sites, batch=512, weights=small_weights, pool_sites=4096, dist=rccl, rank=0, local=0, world=1)
+    to_np = lambda x: x.cpu().numpy() if hasattr(x, "cpu") else np.asarray(x)
+    assert rec1["sites"] == rec0["sites"] == sites and rec1["gather_bytes"] == sites * 12
+    assert hasattr(a1, "is_cuda") and a1.is_cuda                      # the collective path keeps the gathered results on the device
+    assert np.array_equal(to_np(a0), to_np(a1)) and np.array_equal(to_np(p0), to_np(p1))
+
+
 def test_bench_under_the_launcher_with_one_rank(tmp_path):
     """(d) the driver's N > 1 command line with N = 1: process group on RCCL, result gather inside every timed window,
     ONE JSON line with the contract keys."""

@@ -64,7 +64,7 @@ def run_shard(sites, batch=512, precision="fp32", weights=None, pool_sites=4096,
         reads = torch.arange(r, r + world * (cnt // SITES_PER_READ), world, dtype=torch.int64, device=dev)
         return (reads.repeat_interleave(SITES_PER_READ) * SITES_PER_READ + torch.arange(SITES_PER_READ, device=dev).repeat(reads.numel()))
     g_act, g_pred = sharding.gather_results(out_act[:n_mine], out_pred[:n_mine], None, dist, dst=0, device=dev, as_numpy=False,
-                                            index_of_rank=index_of_rank)
+                                            index_of_rank=index_of_rank, force_collective=dist is not None)      # one rank under the launcher: same RCCL calls
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()

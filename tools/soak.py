@@ -2,7 +2,7 @@
 every result compared bit for bit with a reference pass over the same sites. Exercises the slot rotation, the bounded
 plan cache (hundreds of distinct sizes), graph capture for recurring sizes and the ragged-tail kernels.
 
-usage: python tools/soak.py [seconds] [precision]"""
+usage: python tools/soak.py [seconds] [precision] [max_batch]"""
 import os, sys, time
 sys.path.insert(0, os.getcwd())
 import numpy as np, torch
@@ -11,7 +11,8 @@ from deepsignal_amd.engine import Engine
 
 secs = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 prec = sys.argv[2] if len(sys.argv) > 2 else "fp32"
-POOL, B = 8192, 512
+POOL = 8192
+B = int(sys.argv[3]) if len(sys.argv) > 3 else 512          # max_batch of the engine under test
 keys = ("kmer", "means", "stds", "sanums", "signals")
 feats = synth.synthetic_features(POOL, seed=77)
 eng = Engine(max_batch=B, precision=prec)
