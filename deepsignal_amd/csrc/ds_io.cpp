@@ -132,6 +132,46 @@ bool parse_list(const char* p, const char* e, int count, Out* out, bool as_int)
         } else {
             double v = 0;
             if (*p == '+') { ++p; if (p >= e || *p == '-' || *p == '+') return false; }   // float("+-5") raises in Python
+            {
+                // Fast path for what feature files hold ("%.6f" text, extract_features.py:289-303): [-]digits[.digits] with at
+                // most 15 significant digits and no exponent. The digits form an integer m < 2^53 and the value is m / 10^k
+                // with 10^k exact in double (k <= 22), so ONE IEEE division gives the correctly rounded double -- the number
+                // float() / strtod return (Clinger's fast path). Everything else (exponents, inf / nan, long mantissas) takes
+                // the general parser below. libstdc++ 11's from_chars<double> goes through strtod and a locale switch:
+                // ~10x the cost of this loop, and ~400 numbers per row make it the reader's whole budget.
+                static const double kPow10[23] = {1e0, 1e1, 1e2, 1e3, 1e4, 1e5, 1e6, 1e7, 1e8, 1e9, 1e10, 1e11, 1e12, 1e13, 1e14, 1e15,
+                                                  1e16, 1e17, 1e18, 1e19, 1e20, 1e21, 1e22};
+                const char* q = p;
+                const bool neg = q < e && *q == '-';
+                if (neg) ++q;
+                uint64_t m = 0;
+                int nd = 0, frac = 0;
+                bool any = false, dot = false, ok = true;
+                for (; q < e; ++q) {
+                    const unsigned c = (unsigned char)*q;
+                    if (c - '0' <= 9u) {
+                        any = true;
+                        if (nd == 0 && c == '0') { if (dot) ++frac; continue; }     // leading zeros carry no significance
+                        if (++nd > 15) { ok = false; break; }
+                        m = m * 10 + (c - '0');
+                        if (dot) ++frac;
+                    } else if (c == '.' && !dot) {
+                        dot = true;
+                    } else {
+                        break;
+                    }
+                }
+                if (ok && any && frac <= 22 && (q == e || *q == ',')) {
+                    v = (double)m / kPow10[frac];
+                    out[i] = (Out)(float)(neg ? -v : v);
+                    p = q;
+                    if (i + 1 < count) {
+                        if (p >= e || *p != ',') return false;
+                        ++p;
+                    }
+                    continue;
+                }
+            }
             auto r = std::from_chars(p, e, v);
             if (r.ec == std::errc::result_out_of_range) {
                 // Python's float() (the reference reader, call_modifications.py:78-85) gives +-inf for 1e400 and

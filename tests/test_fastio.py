@@ -109,6 +109,37 @@ def test_signs_follow_pythons_int_and_float(tmp_path):
             (int if col == 9 else float)(tok)
 
 
+def test_decimal_fast_path_is_pythons_float(tmp_path):
+    """The reader parses "[-]digits[.digits]" with <= 15 significant digits by one exact integer / power-of-ten division
+    (correctly rounded, as strtod) and everything else by the general parser: every token below must come out as
+    np.float32(float(token)) -- bit for bit, signed zeros included."""
+    rng = np.random.default_rng(9)
+    toks = ["0", "-0", "-0.000000", "0.000000", ".5", "-.5", "5.", "000123.4500", "123456789012345", "1234567890123456",
+            "0.000000000000000000001", "0.0000000000000000000001", "0.00000000000000000000001", "99999999.99999999",
+            "0.1", "0.2", "0.3", "16777217", "16777216.5", "0.333333", "1e-3", "-2.5E+2", "3.4028235e38", "1e39", "1e-50",
+            "0.3000000000000000444", "8.5", "-1.100000", "4.999999", "2.500001"]
+    for _ in range(400):
+        k = int(rng.integers(0, 6))
+        x = float(rng.normal(0, 10.0 ** int(rng.integers(-4, 6))))
+        toks.append(["%.6f" % x, "%.3f" % x, "%.15g" % x, "%.12f" % x, "%d" % int(x), repr(x)][k])
+    toks = [t for t in toks if "n" not in t.lower()]            # (inf / nan spellings are covered by the malformed corpus)
+    base = _synthetic_rows(1, 1, seed=4)[0].split("\t")
+    rows, want = [], []
+    for i in range(0, len(toks) - 16, 17):
+        c = list(base)
+        c[4] = "r%d" % i
+        c[7] = ",".join(toks[i:i + 17])
+        rows.append("\t".join(c))
+        with np.errstate(over="ignore"):                         # "1e39" -> inf in float32, as the TF feed gives
+            want.append([np.float32(float(t)) for t in toks[i:i + 17]])
+    p = str(tmp_path / "d.tsv")
+    _write(p, rows)
+    got = np.concatenate([it.means for it in fastio.FeatureReader(p).items(1000)])
+    want = np.asarray(want, np.float32)
+    assert got.shape == want.shape
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), [(t, g, w) for t, g, w in zip(sum((r.split("\t")[7].split(",") for r in rows), []), got.ravel(), want.ravel()) if np.float32(g).view(np.uint32) != np.float32(w).view(np.uint32)][:5]
+
+
 def test_error_names_the_byte_range_and_the_lines_offset(tmp_path):
     """Sharded call_mods restricts a rank's reader to byte ranges: a malformed row must be findable in the FILE (absolute
     byte offset of the line), not only counted relative to the range."""
