@@ -158,7 +158,7 @@ struct ds_handle {
     bool no_fused = false;    // DS_TUNE_NO_FUSED: layer-granular inception modules instead of the fused kernel
     bool fold_fc = false;     // joint model folded into one J x class_num matrix (fp32, not DS_TUNE_NO_FOLD_FC, not debug)
     bool serial = false;      // DS_TUNE_SERIAL: every launch of a forward on ONE stream (stand-alone kernel times)
-    bool serial_modules = false;   // DS_TUNE_NO_CHAIN: bf16 modes, one launch per inception module instead of one per width class
+    bool serial_modules = false;   // DS_TUNE_NO_CHAIN: one launch per inception module instead of one per width class
     int fuse_max_spt = 8;     // sites per fused-module tile, upper bound
     int fuse_min_tiles = 128; // fused-module grids keep at least this many workgroups when the batch allows it
     bool lstm_bf16 = false;   // DS_PRECISION_BF16_ALL: additionally bf16 h / weight operands in the LSTM matmuls (fp32 accumulate,
@@ -533,14 +533,14 @@ int alloc_workspace(ds_handle* h)
     if (!rc) h->cur->pred = reinterpret_cast<int*>(h->cur->act + B * h->C);
     if (h->bf16) A(&h->cur->joint, B * (size_t)h->JP / 2);
     // module outputs: ping-pong pair normally; one buffer per module in debug mode (for taps)
-    // bf16 modes chain the modules of a width class inside one launch (ds_internal.h FusedChain): a workgroup that is already
+    // the modules of a width class run as a chain inside one launch (ds_internal.h FusedChain): a workgroup that is already
     // in module 5 must not write into the buffer a slower workgroup still reads module 4's (stride-2 pooled, differently
     // tiled) input from, so a chain alternates between the two buffers that do NOT hold its first module's input: three buffers
-    const int nbuf = h->debug ? NMOD : (h->bf16 ? 3 : 2);
+    const int nbuf = h->debug ? NMOD : 3;
     static const int kChainBuf[NMOD] = {0, 1, 0, /* reads 0 */ 1, 2, 1, 2, 1, /* reads 1 */ 0, 2, 0};
     float* bufs[NMOD] = {nullptr};
     for (int i = 0; i < nbuf; ++i) A(&bufs[i], B * h->wa * INC_OUT);
-    for (int m = 0; m < NMOD; ++m) h->cur->modout[m] = bufs[h->debug ? m : (h->bf16 ? kChainBuf[m] : (m & 1))];
+    for (int m = 0; m < NMOD; ++m) h->cur->modout[m] = bufs[h->debug ? m : kChainBuf[m]];
     if (!rc && h->bf16) {
         // bf16 rows are [.., 256] with channels 240..255 (and the joint's tail) never written: they must read as zero
         hipError_t e = hipSuccess;
@@ -718,10 +718,10 @@ int build_plan(ds_handle* h, int n, Plan* plan)
             op.fa.dbg = h->dbg_stamps ? h->dbg_stamps + (size_t)m * 1024 * 16 : nullptr;
             op.flops = 2.0 * M * ((double)cin * 240 + 96 * 48 + 160 * 48 + 96 * 64 + 64 * 48);
             if (first_plan) h->stages[st].flops_per_site += op.flops / n;
-            // bf16 modes: a module joins the launch of the module before it when both tile the batch alike and it reads that
+            // a module joins the launch of the module before it when both tile the batch alike and it reads that
             // module's rows as they are (no stride-2 pool in between): every workgroup then takes its sites through the whole
             // chain (ds_internal.h FusedChain). Stage times of a chain are booked on its first module.
-            Op* prev = (bf && !cnn.empty() && cnn.back().kind == OP_FUSED) ? &cnn.back() : nullptr;
+            Op* prev = (!cnn.empty() && cnn.back().kind == OP_FUSED) ? &cnn.back() : nullptr;
             if (prev && prev->fc.nmod < FUSED_CHAIN_MAX && op.fa.pool_win == 0 && prev->fa.W == W && prev->fa.spt == best_spt &&
                 prev->tm == op.tm && prev->fc.m[prev->fc.nmod - 1].Y == op.fa.X && op.fa.Y != prev->fc.m[0].X && !h->serial_modules) {
                 prev->fc.m[prev->fc.nmod++] = op.fa;
@@ -982,7 +982,7 @@ int issue_op(ds_handle* h, Plan& plan, const Op& op, hipStream_t s)
         break;
     case OP_FUSED:
         if (h->bf16) HIPCHK(h, launch_inception_fused_bf16(op.tm, op.fc, s));
-        else HIPCHK(h, launch_inception_fused(op.tm, op.fa, s));
+        else HIPCHK(h, launch_inception_fused(op.tm, op.fc, s));
         break;
     case OP_HEAD:
         HIPCHK(h, launch_head(h->cur->fc1o, h->fc2, h->cur->logits, h->cur->act, h->cur->pred, n, h->J, h->C, s));

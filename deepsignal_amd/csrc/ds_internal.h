@@ -117,13 +117,12 @@ struct FusedArgs {
     const float *Bp3b, *bias3b, *Bp4b, *bias4b, *Bp5b, *bias5b, *Bp5c, *bias5c;
     unsigned long long* dbg;   // diagnostic: per-workgroup phase time stamps (null in normal runs)
 };
-// tm = 32-row m-tiles per workgroup (1..3), spt*W <= 32*tm
-hipError_t launch_inception_fused(int tm, const FusedArgs& a, hipStream_t s);
+
 size_t inception_fused_lds_bytes(int tm, int W, int spt);
 // once per device, before the first fused launch (raises the kernels' dynamic LDS limit to 160 KB)
 hipError_t configure_fused_kernels();
 // bf16-operand variant: X / Y are bf16 rows of 256-channel pitch, a.cin is the row pitch in 4-byte units (128).
-// A launch carries a CHAIN of consecutive modules of one width class (same W, spt, n_sites; m[k + 1].X == m[k].Y; only m[0]
+// A launch (either precision) carries a CHAIN of consecutive modules of one width class (same W, spt, n_sites; m[k + 1].X == m[k].Y; only m[0]
 // may pool its input): every workgroup takes its tile of whole sites through all of them, so the rows a module reads are
 // the rows the same workgroup wrote a moment ago (XCD-local L2 hits) and no launch boundary separates the modules.
 constexpr int FUSED_CHAIN_MAX = 5;
@@ -132,6 +131,8 @@ struct FusedChain {
     int nmod;
 };
 hipError_t launch_inception_fused_bf16(int tm, const FusedChain& c, hipStream_t s);
+// fp32 form of the same chain; tm = 32-row m-tiles per workgroup (1..3), spt*W <= 32*tm
+hipError_t launch_inception_fused(int tm, const FusedChain& c, hipStream_t s);
 size_t inception_fused_bf16_lds_bytes(int tm, int W, int spt);
 
 // conv_layer2 (1x1, 64 -> 128) + conv_layer3 (1x3, 128 -> 256), both with folded BN + ReLU        layers.py:192-203

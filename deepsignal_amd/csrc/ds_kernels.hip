@@ -1216,33 +1216,46 @@ struct FusedTagT { static constexpr bool value = true; };
 struct FusedTagF { static constexpr bool value = false; };
 
 template <int TM>
-__global__ __launch_bounds__(512, DS_FUSED_WPS) void inception_fused_kernel(const FusedArgs a)
+__device__ __forceinline__ void inception_fused_body(const FusedChain& c)
 {
     constexpr int TR32 = TM * 32;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Ad = smem;                         // [2][TR32*F_LDA] staged input rows
     float* Ys = smem;                         // [TR32][F_LD1] b1|b2 output tile, aliases Ad once P1 is done
     float* T1 = smem + TR32 * F_LD1;          // [spt*(W+4)][F_LD1]   (TR32*F_LD1 >= 4*TR32*F_LDA)
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int W = a.W, spt = a.spt, cin = a.cin;
+    const int W = c.m[0].W, spt = c.m[0].spt;          // the same for every module of a chain (ds_internal.h FusedChain)
     float* T2 = T1 + (spt * (W + 4) + 5) * F_LD1;   // [TR32*F_LD2]  (T1 has 5 spare rows: a dump row for padding rows + its halo)
     int* rowmap = reinterpret_cast<int*>(T2 + TR32 * F_LD2);   // [TR32] tile row -> T1 row
     float* const Bs = reinterpret_cast<float*>(rowmap + TR32); // [3][64] biases of b5b | b3b | b4b
     const int site0 = blockIdx.x * spt;
-    const int nhere = min(spt, a.n_sites - site0);
+    const int nhere = min(spt, c.m[0].n_sites - site0);
     const int TRv = nhere * W;                // valid rows of this tile
     const size_t grow0 = (size_t)site0 * W;
+    // once per workgroup: zero halo rows of T1 (every module rewrites the interior rows completely and never touches the
+    // halos) and the tile's row map
+    for (int i = threadIdx.x; i < (spt * (W + 4) + 5) * (F_LD1 / 4); i += 512)
+        reinterpret_cast<float4*>(T1)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (threadIdx.x < TR32)   // rows past the tile's last site map to the dump row, so LDS writes need no predicate
+        rowmap[threadIdx.x] = (int)threadIdx.x < TRv ? ((int)threadIdx.x / W) * (W + 4) + 2 + (int)threadIdx.x % W : spt * (W + 4) + 2;
+
+    // ---- the modules of the chain, one after the other on THIS tile (one module per launch in the diagnostic modes): module
+    // k + 1 reads the rows module k has just written -- same workgroup, so they come back from this XCD's L2 and no launch
+    // boundary (with its drain and its cold start) sits between the modules
+    for (int mi = 0; mi < c.nmod; ++mi) {
+    const FusedArgs& a = c.m[mi];
+    // every per-lane quantity derives from this opaque copy of the thread index: hipcc otherwise hoists loop-invariant
+    // per-lane addresses out of the module loop, and the kernel must stay within 184 VGPRs (co-tenancy)
+    int tid_opaque = threadIdx.x, wave_opaque = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    asm volatile("" : "+v"(tid_opaque), "+s"(wave_opaque));
+    const int tid = tid_opaque, lane = tid & 63, wave = wave_opaque;
+    const int cin = a.cin;
     const gptr1w Yg = (gptr1w)(a.Y + grow0 * 240);     // wave-uniform base; per-lane offsets stay 32-bit
 
     // diagnostic phase stamps (wave 0 and wave 7, lane 0): only when a debug buffer is attached
     const bool stamp = a.dbg != nullptr && lane == 0 && (wave == 0 || wave == 7) && blockIdx.x < DBG_MAX_WGS;
-    unsigned long long* sdst = a.dbg + ((size_t)blockIdx.x * 2 + (wave == 7)) * 8;
-#define DS_STAMP(i) do { if (stamp) sdst[i] = __builtin_amdgcn_s_memtime(); } while (0)
+    // (the destination is recomputed at every stamp: a pointer held in VGPRs for the whole kernel costs two registers)
+#define DS_STAMP(i) do { if (stamp) (a.dbg + ((size_t)blockIdx.x * 2 + (wave == 7)) * 8)[i] = __builtin_amdgcn_s_memtime(); } while (0)
     DS_STAMP(0);
-    for (int i = tid; i < (spt * (W + 4) + 5) * (F_LD1 / 4); i += 512)          // halos (and everything else) = 0
-        reinterpret_cast<float4*>(T1)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (tid < TR32)   // rows past the tile's last site map to the dump row, so LDS writes need no predicate
-        rowmap[tid] = tid < TRv ? (tid / W) * (W + 4) + 2 + tid % W : spt * (W + 4) + 2;
     if (tid >= 256 && tid < 448) {
         const int q = tid - 256;
         Bs[q] = gload((q < 64 ? a.bias5b : q < 128 ? a.bias3b : a.bias4b) + (q & 63));
@@ -1322,8 +1335,10 @@ __global__ __launch_bounds__(512, DS_FUSED_WPS) void inception_fused_kernel(cons
         constexpr int BD = DS_FUSED_BD;                  // register stages of the weight fragments (chunk c's are requested BD - 1 steps ahead)
         float4 bq[BD][2];
         float4 af[2][2][TM];
+        // (the pooling waves 6, 7 hold threads 384 .. 511 and a tile has at most 96 x 4 = 384 staging slots: they never stage,
+        // and their variant carries neither the staging registers nor the row pointers)
         auto load_a = [&](int V) __attribute__((always_inline)) {
-            if (stager) {
+            if (!POOL && stager) {
                 vc[V] = gload4(pc); pc += KC;
                 if (pooled_in) {       // wave-uniform per launch
                     vc[V] = f4max(f4max(vc[V], gload4(pq)), gload4(pr));
@@ -1332,7 +1347,7 @@ __global__ __launch_bounds__(512, DS_FUSED_WPS) void inception_fused_kernel(cons
             }
         };
         auto store_a = [&](int X, int V) __attribute__((always_inline)) {
-            if (stager) *reinterpret_cast<float4*>(Ad + X * TR32 * F_LDA + sr * F_LDA + sq * 4) = vc[V];
+            if (!POOL && stager) *reinterpret_cast<float4*>(Ad + X * TR32 * F_LDA + sr * F_LDA + sq * 4) = vc[V];
         };
         auto load_b = [&](int Bi) __attribute__((always_inline)) {
             bq[Bi][0] = gload4(bp);
@@ -1415,6 +1430,10 @@ __global__ __launch_bounds__(512, DS_FUSED_WPS) void inception_fused_kernel(cons
     auto unit_Bp = [&](int k) { return k == 1 ? a.Bp5b : k == 2 ? a.Bp3b : a.Bp4b; };
     auto unit_taps = [&](int k) { return k == 3 ? 5 : 3; };
     float4 pf[20];                                   // prefetched weights of the next unit
+    // (defined on every path: a register array that is only loaded under a wave-uniform condition is "undefined on some
+    // paths", and hipcc keeps such a value live around the whole module loop -- 80 + 32 VGPRs of phantom live range here)
+#pragma unroll
+    for (int g = 0; g < 20; ++g) pf[g] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (a1k) fused_unit_prefetch(unit_Bp(a1k), unit_taps(a1k), a1n, lane, pf);
 
     // ---- P1 epilogue (bias already inside acc): route the 256 columns. b1|b2 go through an LDS tile and leave as
@@ -1496,6 +1515,8 @@ __global__ __launch_bounds__(512, DS_FUSED_WPS) void inception_fused_kernel(cons
     }
     // weights of the first P2b job are requested before the barrier
     float4 b5c[8];
+#pragma unroll
+    for (int g = 0; g < 8; ++g) b5c[g] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (wave < 2) {
 #pragma unroll
         for (int g = 0; g < 8; ++g) b5c[g] = gload4(a.Bp5c + ((size_t)(wave * 8 + g) * 64 + lane) * 4);
@@ -1544,18 +1565,36 @@ __global__ __launch_bounds__(512, DS_FUSED_WPS) void inception_fused_kernel(cons
     }
     DS_STAMP(7);
 #undef DS_STAMP
+    // the next module reads the rows this one has stored (other waves' stores included) and re-uses every LDS region
+    if (mi + 1 < c.nmod) __syncthreads();
+    }   // modules of the chain
 }
 
-hipError_t launch_inception_fused(int tm, const FusedArgs& a, hipStream_t s)
+template <int TM>
+__global__ __launch_bounds__(512, DS_FUSED_WPS) void inception_fused_kernel(const FusedChain c) { inception_fused_body<TM>(c); }
+// one tiling for the whole chain; only its first module may pool its input (ds_internal.h FusedChain)
+static bool fused_chain_ok(const FusedChain& c)
 {
+    if (c.nmod <= 0 || c.nmod > FUSED_CHAIN_MAX) return false;
+    for (int i = 1; i < c.nmod; ++i)
+        if (c.m[i].W != c.m[0].W || c.m[i].spt != c.m[0].spt || c.m[i].n_sites != c.m[0].n_sites || c.m[i].pool_win != 0 ||
+            c.m[i].X != c.m[i - 1].Y) return false;
+    return true;
+}
+
+hipError_t launch_inception_fused(int tm, const FusedChain& c, hipStream_t s)
+{
+    if (!fused_chain_ok(c)) return hipErrorInvalidValue;
+    const FusedArgs& a = c.m[0];
     if (a.n_sites <= 0) return hipSuccess;
-    if (a.cin != 240 && a.cin != 256) return hipErrorInvalidValue;      // P1 is unrolled over 15 or 16 chunks (every module of the model)
+    for (int i = 0; i < c.nmod; ++i)
+        if (c.m[i].cin != 240 && c.m[i].cin != 256) return hipErrorInvalidValue;      // P1 is unrolled over 15 or 16 chunks (every module of the model)
     const size_t lds = inception_fused_lds_bytes(tm, a.W, a.spt);
     const int grid = (a.n_sites + a.spt - 1) / a.spt;
     switch (tm) {
-    case 1: hipLaunchKernelGGL(inception_fused_kernel<1>, dim3(grid), dim3(512), lds, s, a); break;
-    case 2: hipLaunchKernelGGL(inception_fused_kernel<2>, dim3(grid), dim3(512), lds, s, a); break;
-    case 3: hipLaunchKernelGGL(inception_fused_kernel<3>, dim3(grid), dim3(512), lds, s, a); break;
+    case 1: hipLaunchKernelGGL(inception_fused_kernel<1>, dim3(grid), dim3(512), lds, s, c); break;
+    case 2: hipLaunchKernelGGL(inception_fused_kernel<2>, dim3(grid), dim3(512), lds, s, c); break;
+    case 3: hipLaunchKernelGGL(inception_fused_kernel<3>, dim3(grid), dim3(512), lds, s, c); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
@@ -2331,11 +2370,11 @@ hipError_t configure_fused_kernels()
 
 hipError_t launch_inception_fused_bf16(int tm, const FusedChain& c, hipStream_t s)
 {
-    if (c.nmod <= 0 || c.nmod > FUSED_CHAIN_MAX || c.m[0].n_sites <= 0) return c.nmod > 0 && c.nmod <= FUSED_CHAIN_MAX ? hipSuccess : hipErrorInvalidValue;
+    if (!fused_chain_ok(c)) return hipErrorInvalidValue;
     const FusedArgs& a = c.m[0];
-    for (int i = 1; i < c.nmod; ++i)      // one tiling for the whole chain; only its first module may pool its input
-        if (c.m[i].W != a.W || c.m[i].spt != a.spt || c.m[i].n_sites != a.n_sites || c.m[i].cin != a.cin || c.m[i].pool_win != 0 ||
-            c.m[i].X != c.m[i - 1].Y) return hipErrorInvalidValue;
+    if (a.n_sites <= 0) return hipSuccess;
+    for (int i = 1; i < c.nmod; ++i)
+        if (c.m[i].cin != a.cin) return hipErrorInvalidValue;
     const size_t lds = inception_fused_bf16_lds_bytes(tm, a.W, a.spt);
     const int grid = (a.n_sites + a.spt - 1) / a.spt;
     switch (tm) {

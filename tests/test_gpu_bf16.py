@@ -113,9 +113,9 @@ def test_bf16_against_oracle_small(small_weights):
     eng.close()
 
 
-@pytest.mark.parametrize("precision", ["bf16", "bf16_all"])
+@pytest.mark.parametrize("precision", ["fp32", "bf16", "bf16_all"])
 def test_module_chain_gives_the_bits_of_one_launch_per_module(small_weights, precision):
-    """The bf16 modes take a tile of whole sites through all modules of a width class inside ONE launch (modules 1-3,
+    """Every precision takes a tile of whole sites through all modules of a width class inside ONE launch (modules 1-3,
     4-8, 9-11); DS_TUNE_NO_CHAIN launches every module on its own. Same arithmetic, same bits -- also on a ragged batch
     whose last tile is partial, and with the per-module tap buffers of debug mode."""
     feats = synth.synthetic_features(1333, seed=812)
