@@ -716,6 +716,7 @@ int build_plan(ds_handle* h, int n, Plan* plan)
             op.fa.Bp5b = h->m_b5b[m].Bp; op.fa.bias5b = h->m_b5b[m].bias;
             op.fa.Bp5c = h->m_b5c[m].Bp; op.fa.bias5c = h->m_b5c[m].bias;
             op.fa.dbg = h->dbg_stamps ? h->dbg_stamps + (size_t)m * 1024 * 16 : nullptr;
+            op.fa.write_rows = 1;
             op.flops = 2.0 * M * ((double)cin * 240 + 96 * 48 + 160 * 48 + 96 * 64 + 64 * 48);
             if (first_plan) h->stages[st].flops_per_site += op.flops / n;
             // a module joins the launch of the module before it when both tile the batch alike and it reads that
@@ -724,6 +725,8 @@ int build_plan(ds_handle* h, int n, Plan* plan)
             Op* prev = (!cnn.empty() && cnn.back().kind == OP_FUSED) ? &cnn.back() : nullptr;
             if (prev && prev->fc.nmod < FUSED_CHAIN_MAX && op.fa.pool_win == 0 && prev->fa.W == W && prev->fa.spt == best_spt &&
                 prev->tm == op.tm && prev->fc.m[prev->fc.nmod - 1].Y == op.fa.X && op.fa.Y != prev->fc.m[0].X && !h->serial_modules) {
+                // bf16: rows of a chain's inner modules never leave the CU (unless the taps of debug mode want them)
+                if (bf && !h->debug) prev->fc.m[prev->fc.nmod - 1].write_rows = 0;
                 prev->fc.m[prev->fc.nmod++] = op.fa;
                 prev->flops += op.flops;
             } else {

@@ -116,6 +116,8 @@ struct FusedArgs {
     const float* bias1;  // [256]
     const float *Bp3b, *bias3b, *Bp4b, *bias4b, *Bp5b, *bias5b, *Bp5c, *bias5c;
     unsigned long long* dbg;   // diagnostic: per-workgroup phase time stamps (null in normal runs)
+    int write_rows;      // bf16 chain: 1 = this module's rows go to Y (the chain's last module; every module when taps are on), 0 = they
+                         // stay in LDS as the next module's input. The fp32 kernel writes every module's rows.
 };
 
 size_t inception_fused_lds_bytes(int tm, int W, int spt);
@@ -123,8 +125,9 @@ size_t inception_fused_lds_bytes(int tm, int W, int spt);
 hipError_t configure_fused_kernels();
 // bf16-operand variant: X / Y are bf16 rows of 256-channel pitch, a.cin is the row pitch in 4-byte units (128).
 // A launch (either precision) carries a CHAIN of consecutive modules of one width class (same W, spt, n_sites; m[k + 1].X == m[k].Y; only m[0]
-// may pool its input): every workgroup takes its tile of whole sites through all of them, so the rows a module reads are
-// the rows the same workgroup wrote a moment ago (XCD-local L2 hits) and no launch boundary separates the modules.
+// may pool its input): every workgroup takes its tile of whole sites through all of them and no launch boundary separates the
+// modules. fp32: the rows a module reads are the rows the same workgroup wrote a moment ago (XCD-local L2 hits). bf16: the rows
+// stay in LDS from module to module; only m[0] reads X and only modules with write_rows store Y.
 constexpr int FUSED_CHAIN_MAX = 5;
 struct FusedChain {
     FusedArgs m[FUSED_CHAIN_MAX];

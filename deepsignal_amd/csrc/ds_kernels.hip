@@ -1601,21 +1601,24 @@ hipError_t launch_inception_fused(int tm, const FusedChain& c, hipStream_t s)
 }
 
 // ---------------------------------------------------------------------------------------------
-// Fused inception module, bf16 operands (DS_PRECISION_BF16*). Same phases and wave roles as
+// Fused inception modules, bf16 operands (DS_PRECISION_BF16*). Same phases and wave roles as
 // inception_fused_kernel; what changes is the data: activations are bf16 rows of 256-channel pitch (channels
-// 240..255 are zero), a K chunk is 16 four-byte units = 32 channels = two v_mfma_f32_32x32x16_bf16 steps, the
-// 32/64-channel intermediates live in LDS as bf16 (T1 row = 104, T2 row = 72 elements: odd numbers of 16-B
-// slots, conflict-free ds_read_b128), accumulation / bias / ReLU / residual are fp32 and every value is rounded
-// to bf16 (nearest even) exactly once, when it is stored. HBM traffic per module row: 512 B in, 480 B out.
+// 240..255 are zero in global memory), a K chunk is 16 four-byte units = 32 channels = two v_mfma_f32_32x32x16_bf16 steps,
+// the 32-channel intermediates live in LDS as bf16 (T1 row = 104 elements: an odd number of 16-B slots, conflict-free
+// ds_read_b128), accumulation / bias / ReLU / residual are fp32 and every value is rounded to bf16 (nearest even) exactly
+// once, when it is stored.
 //
-// Roofline: HBM. A 96-row tile moves 93 KB for ~2 us of matrix-pipe time, so what matters is how many bytes a CU keeps
-// in flight, not its MFMA schedule. Round 3 form: TWO workgroups per CU (<= 128 VGPRs, <= 76 KB of LDS each), so one
-// tile's load / store phases run under the other's MFMAs:
+// Roofline: HBM (module-granular bytes: 512 B in + 480 B out per module row). A 96-row tile is ~2 us of matrix-pipe time, so
+// what matters is the memory traffic and how much of it a CU keeps in flight. Round 3 form:
+//   * TWO workgroups per CU (<= 128 VGPRs, <= 76 KB of LDS each): one tile's load / store phases run under the other's MFMAs;
 //   * the 3-tap max-pooled copy of the input tile (branch 1's operand, 50 KB) is gone: waves 6, 7 pool their fragments
 //     on the fly (three ds_read_b128 + v_pk_max_i16 per fragment), as the fp32 kernel does;
-//   * the P1 weights stream through a ring of four fragments per wave instead of sixteen resident ones;
-//   * EVERY output leaves through an LDS tile as whole 16-byte pieces of contiguous row segments (b1|b2: 192 B, then
-//     b3|b4|b5: 288 B) -- the direct form stored 8 bytes per lane into 32 different rows per instruction.
+//   * the P1 weights stream through a ring of two fragments per wave instead of sixteen resident ones;
+//   * a launch carries the modules of one width class and the tile's rows STAY IN LDS from module to module: every result is
+//     written in place over the (dead) input rows in the layout the next module's P1 reads. Only the chain's first module
+//     loads rows and only its last one stores them (whole 480-byte rows): eight of the eleven module outputs never reach
+//     HBM. Bisect builds had priced the parts of the 755 us the global-memory chain took at 4096 sites: re-loading the rows
+//     55 us, issuing their stores 30 us, the write traffic itself 65 us; this form takes 620 us.
 #ifndef DS_FUSEDB_WPS
 #define DS_FUSEDB_WPS 4
 #endif
@@ -1636,15 +1639,12 @@ hipError_t launch_inception_fused(int tm, const FusedChain& c, hipStream_t s)
 #define DS_FUSEDB_RING 2      // register stages of a wave's P1 weight fragments (2, 3: same time on MI355X; 3 and 4 spill at 128 VGPRs)
 #endif
 constexpr int B_LDA = 132;      // staged input row stride in units (256 channels + 8 pad: 33 x 16 B, odd)
-constexpr int B_LD1 = 52;       // T1 / b1|b2 output-tile row stride in units (96 channels + 8 pad)
-constexpr int B_LD2 = 36;       // T2 row stride in units (64 channels + 8 pad)
-constexpr int B_LDY = 76;       // b3|b4|b5 output-tile row stride in units (144 channels + 8 pad: 19 x 16 B, odd)
-constexpr int B_T2OFF = 96;     // T2 block starts B_T2OFF units per tile row into the (dead) input tile: B_LDY <= 96, 96 + B_LD2 <= B_LDA
+constexpr int B_LD1 = 52;       // T1 row stride in units (96 channels + 8 pad)
 
 size_t inception_fused_bf16_lds_bytes(int tm, int W, int spt)
 {
     const int tr32 = tm * 32;
-    return (size_t)(tr32 * B_LDA + (spt * (W + 4) + 5) * B_LD1 + tr32 + 192) * sizeof(float);    // input tile (output tiles and T2 alias it) | T1 | rowmap | 3x64 biases
+    return (size_t)(tr32 * B_LDA + (spt * (W + 4) + 5) * B_LD1 + tr32 + 192) * sizeof(float);    // the tile's rows (input, then output in place; T2 in their last 64 channels) | T1 | rowmap | 3x64 biases
 }
 
 __device__ __forceinline__ floatx16 mfma_bf(float4 a, float4 b, floatx16 c)
@@ -1680,21 +1680,20 @@ __global__ __launch_bounds__(512, TM >= 2 ? DS_FUSEDB_WPS : 2) void inception_fu
 {
     constexpr int TR32 = TM * 32;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* const As = smem;                         // [TR32][B_LDA] the WHOLE input tile (256 channels per row); dead after P1, then:
-    float* const Ys = smem;                         //   [TR32][B_LD1] b1|b2 output tile (flushed before P2)
-    float* const Y2 = smem;                         //   [TR32][B_LDY] b3|b4|b5 output tile (over the flushed b1|b2 tile)
-    float* const T2 = smem + TR32 * B_T2OFF;        //   [TR32][B_LD2] branch 5's 64-channel intermediate
-    float* const T1 = smem + TR32 * B_LDA;          // [spt*(W+4)+5][B_LD1]
+    // [TR32][B_LDA] the tile's rows, 256 channels each. A module's INPUT during its P1; behind P1 the same rows receive the
+    // module's OUTPUT in place (b1 | b2 | b3 | b4 | b5 = channels [0, 240)), which is the next module's input: inside a chain
+    // the rows never leave the CU. Channels [192, 256) of a row hold branch 5's 64-channel intermediate (T2) between P2a and
+    // the tail; what T2 leaves in the pad channels [240, 256) is finite and meets zero weight rows in the next module's P1.
+    float* const As = smem;
+    float* const T1 = smem + TR32 * B_LDA;          // [spt*(W+4)+5][B_LD1] b3a | b4a | b5a with zero halo rows
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int W = c.m[0].W, spt = c.m[0].spt, cinu = c.m[0].cin;          // cin in units (128); the same for every module of a chain
     int* const rowmap = reinterpret_cast<int*>(T1 + (spt * (W + 4) + 5) * B_LD1);
     float* const Bs = reinterpret_cast<float*>(rowmap + TR32);                    // [3][64] biases of b5b | b3b | b4b
     unsigned short* const T1h = reinterpret_cast<unsigned short*>(T1);
-    unsigned short* const T2h = reinterpret_cast<unsigned short*>(T2);
-    unsigned short* const Ysh = reinterpret_cast<unsigned short*>(Ys);
-    unsigned short* const Y2h = reinterpret_cast<unsigned short*>(Y2);
-    // workgroup barrier for LDS traffic only: __syncthreads() also drains vmcnt, i.e. waits for the row stores that are meant
-    // to leave in the background (only the barrier at the end of a module needs them complete: the next module reads them)
+    unsigned short* const Ash = reinterpret_cast<unsigned short*>(As);
+    // workgroup barrier for LDS traffic only: __syncthreads() also drains vmcnt, i.e. waits for prefetched weights and for the
+    // row stores that are meant to leave in the background
     auto lds_barrier = []() __attribute__((always_inline)) { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
     constexpr int NSLOT = TR32 * 32 / 512;    // 16-B slots of the input tile per thread: 2 * TM
 
@@ -1708,21 +1707,22 @@ __global__ __launch_bounds__(512, TM >= 2 ? DS_FUSEDB_WPS : 2) void inception_fu
                           (unsigned)f2bf(fmaxf(x2, 0.0f)) | ((unsigned)f2bf(fmaxf(x3, 0.0f)) << 16));
     };
 
-    // static wave -> unit assignment of P2 (wave-uniform). kind: 0 none, 1 b5b, 2 b3b, 3 b4b
-    int a1k = 0, a1m = 0, a1n = 0, a2k = 0, a2m = 0, a2n = 0, a3m = -1;
-    int b1k = 0, b1m = 0, b1n = 0;
+    // static wave -> unit assignment of P2 (wave-uniform). kind: 0 none, 1 b5b, 2 b3b, 3 b4b; phase a runs `anm` m-tiles
+    // (am, am + 1, ...) on one set of weights
+    int ak = 0, am = 0, an = 0, anm = 1;
+    int bk = 0, bm = 0, bn = 0;
     if (TM == 3) {
-        if (wave < 6) { a1k = 1; a1m = wave % 3; a1n = wave / 3; }
-        else { a1k = 2; a1m = 0; a1n = wave - 6; a2k = 2; a2m = 1; a2n = wave - 6; a3m = 2; }    // three m-tiles on one set of weights
-        if (wave >= 2) { b1k = 3; b1m = (wave - 2) % 3; b1n = (wave - 2) / 3; }
+        if (wave < 6) { ak = 1; am = wave % 3; an = wave / 3; }
+        else { ak = 2; am = 0; an = wave - 6; anm = 3; }
+        if (wave >= 2) { bk = 3; bm = (wave - 2) % 3; bn = (wave - 2) / 3; }
     } else if (TM == 2) {
-        if (wave < 4) { a1k = 1; a1m = wave & 1; a1n = wave >> 1; }
-        else { a1k = 2; a1m = wave & 1; a1n = (wave - 4) >> 1; }
-        if (wave >= 2 && wave < 6) { b1k = 3; b1m = (wave - 2) & 1; b1n = (wave - 2) >> 1; }
+        if (wave < 4) { ak = 1; am = wave & 1; an = wave >> 1; }
+        else { ak = 2; am = wave & 1; an = (wave - 4) >> 1; }
+        if (wave >= 2 && wave < 6) { bk = 3; bm = (wave - 2) & 1; bn = (wave - 2) >> 1; }
     } else {
-        if (wave < 2) { a1k = 1; a1n = wave; }
-        else if (wave < 4) { a1k = 2; a1n = wave - 2; }
-        else if (wave < 6) { a1k = 3; a1n = wave - 4; }
+        if (wave < 2) { ak = 1; an = wave; }
+        else if (wave < 4) { ak = 2; an = wave - 2; }
+        else if (wave < 6) { ak = 3; an = wave - 4; }
     }
 
     // once per workgroup: the tile's row map and the zero halo rows of T1 (every module of the chain rewrites T1's interior
@@ -1732,8 +1732,8 @@ __global__ __launch_bounds__(512, TM >= 2 ? DS_FUSEDB_WPS : 2) void inception_fu
     if (tid < TR32)
         rowmap[tid] = tid < TRv ? (tid / W) * (W + 4) + 2 + tid % W : spt * (W + 4) + 2;
 
-    // ---- the modules of the chain, one after the other on THIS tile: module k + 1 reads the rows module k has just written
-    // (same workgroup, so the rows come back from this XCD's L2 instead of HBM and no launch boundary sits between them)
+    // ---- the modules of the chain, one after the other on THIS tile. Only the first module reads rows from global memory
+    // and only the last one writes rows back: in between a module's output rows are the next module's input, in LDS.
     for (int mi = 0; mi < c.nmod; ++mi) {
     const FusedArgs& a = c.m[mi];
     // Every per-lane quantity of the body derives from this opaque copy of the thread index: hipcc otherwise hoists ~100
@@ -1741,22 +1741,30 @@ __global__ __launch_bounds__(512, TM >= 2 ? DS_FUSEDB_WPS : 2) void inception_fu
     int tid_opaque = threadIdx.x, wave_opaque = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     asm volatile("" : "+v"(tid_opaque), "+s"(wave_opaque));
     const int tid = tid_opaque, lane = tid & 63, h4 = 4 * (lane >> 5), rlane = lane & 31, wave = wave_opaque;
-    const bool pooled_in = a.pool_win > 0;
     const bool stamp = a.dbg != nullptr && lane == 0 && (wave == 0 || wave == 7) && blockIdx.x < DBG_MAX_WGS;
     // (the destination is recomputed at every stamp: a pointer held in VGPRs for the whole kernel costs two of the 128)
 #define DS_STAMP(i) do { if (stamp) (a.dbg + ((size_t)blockIdx.x * 2 + (wave == 7)) * 8)[i] = __builtin_amdgcn_s_memtime(); } while (0)
     DS_STAMP(0);
-    // first output row of the tile; formed where it is used (a 64-bit value carried across P1 is a spill at 128 VGPRs)
-    auto out_rows = [&]() -> gbf16w {
-        return (gbf16w)(reinterpret_cast<unsigned short*>(a.Y) + (size_t)__builtin_amdgcn_readfirstlane(site0) * W * 256);
-    };
     auto unit_Bp = [&](int k) { return k == 1 ? a.Bp5b : k == 2 ? a.Bp3b : a.Bp4b; };
     auto unit_taps = [&](int k) { return k == 3 ? 5 : 3; };
 
-    // ---- the WHOLE input tile is requested at once (a bf16 K chunk is ~200 matrix-pipe cycles: nothing hides behind it;
-    // the other workgroup of the CU computes meanwhile)
-    float4 st[NSLOT];
-    {
+    // the small global requests of a module's prologue, all issued before anything waits: the unit biases, this wave's P1 bias
+    // (+ the tail's BN shift on the b5 stem columns)
+    float bsv;
+    float4 bv[4], tv[4];
+    auto request_biases = [&]() __attribute__((always_inline)) {
+        bsv = tid < 192 ? gload((tid < 64 ? a.bias5b : tid < 128 ? a.bias3b : a.bias4b) + (tid & 63)) : 0.0f;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            bv[g] = gload4(a.bias1 + wave * 32 + 8 * g + h4);                               // bias1 is zero-padded to 256
+            tv[g] = gload4(a.bias5c + (wave < 2 ? wave : 0) * 32 + 8 * g + h4);             // zero-padded to 64; used by waves 0, 1 only
+        }
+    };
+    if (mi == 0) {
+        // ---- chain head: the WHOLE input tile is requested at once (a bf16 K chunk is ~200 matrix-pipe cycles: nothing
+        // hides behind it; the other workgroup of the CU computes meanwhile)
+        const bool pooled_in = a.pool_win > 0;
+        float4 st[NSLOT];
         const size_t grow0 = (size_t)site0 * W;
         if (!pooled_in) {
 #pragma unroll
@@ -1780,25 +1788,17 @@ __global__ __launch_bounds__(512, TM >= 2 ? DS_FUSEDB_WPS : 2) void inception_fu
                 st[i] = bf8max_nn(bf8max_nn(gload4(sb + (size_t)ia * cinu), gload4(sb + (size_t)ib * cinu)), gload4(sb + (size_t)ic * cinu));
             }
         }
-    }
-    // every other global request of the prologue goes out behind the tile's, before anything waits: the unit biases, this
-    // wave's P1 bias (+ the tail's BN shift on the b5 stem columns) -- written with per-g branches these were four serialized
-    // L2 round trips in front of every tile
-    const float bsv = tid < 192 ? gload((tid < 64 ? a.bias5b : tid < 128 ? a.bias3b : a.bias4b) + (tid & 63)) : 0.0f;
-    float4 bv[4], tv[4];
+        request_biases();
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        bv[g] = gload4(a.bias1 + wave * 32 + 8 * g + h4);                               // bias1 is zero-padded to 256
-        tv[g] = gload4(a.bias5c + (wave < 2 ? wave : 0) * 32 + 8 * g + h4);             // zero-padded to 64; used by waves 0, 1 only
+        for (int i = 0; i < NSLOT; ++i) {
+            const int id = tid + i * 512, row = id >> 5, q = id & 31;
+            *reinterpret_cast<float4*>(As + row * B_LDA + q * 4) = st[i];
+        }
+    } else {
+        request_biases();
     }
-    if (tid < 192) Bs[tid] = bsv;
-#pragma unroll
-    for (int i = 0; i < NSLOT; ++i) {
-        const int id = tid + i * 512, row = id >> 5, q = id & 31;
-        *reinterpret_cast<float4*>(As + row * B_LDA + q * 4) = st[i];
-    }
-    // P1 weights of this wave's n-tile (16 fragments, L2-resident) through a ring of DS_FUSEDB_RING; requested once the tile's
-    // staging registers are free (the kernel lives on <= 128 VGPRs)
+    if (tid < 192) Bs[tid] = bsv;        // read behind the barriers of P1; the previous module's last use is behind its barriers
+    // P1 weights of this wave's n-tile (16 fragments, L2-resident) through a ring of DS_FUSEDB_RING
     // (wave-uniform base + one 32-bit lane offset: scalar address arithmetic, no 64-bit per-lane pointers in the loop)
     const char* const bp_base = reinterpret_cast<const char*>(a.Bp1) + (size_t)wave * ((cinu + 31) / 32 * 4) * 1024;
     const unsigned lane16 = (unsigned)lane * 16;
@@ -1824,7 +1824,7 @@ __global__ __launch_bounds__(512, TM >= 2 ? DS_FUSEDB_WPS : 2) void inception_fu
             }
         }
     }
-    __syncthreads();   // input tile, zeroed T1, rowmap, biases are in place
+    if (mi == 0) lds_barrier();   // input tile, zeroed T1, rowmap in place (later modules: behind the previous module's last barrier)
     DS_STAMP(1);
 
     // ---- P1: [rows x 256] x [256 x 256], 16 k-steps back to back out of LDS. Waves 6, 7
@@ -1892,13 +1892,13 @@ __global__ __launch_bounds__(512, TM >= 2 ? DS_FUSEDB_WPS : 2) void inception_fu
     if (wave >= 6) { __builtin_amdgcn_s_setprio(DS_FUSEDB_POOLPRIO); run_p1(FusedTagT{}); __builtin_amdgcn_s_setprio(0); }
     else run_p1(FusedTagF{});     // wave-uniform
     DS_STAMP(2);
-    __syncthreads();   // all fragment reads of the input tile are done before the output tile aliases it
+    lds_barrier();   // all fragment reads of the input rows are done: the output may overwrite them
     float4 pf[10];
     // (fragments 6..9 are only loaded for the five-tap unit; defined here so that their live range starts here and not, as an
     // "undefined on some paths" value, in front of the module loop -- sixteen registers held across P1 otherwise)
 #pragma unroll
     for (int g = 6; g < 10; ++g) pf[g] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (a1k) fusedb_unit_prefetch(unit_Bp(a1k), unit_taps(a1k), a1n, lane, pf);
+    if (ak) fusedb_unit_prefetch(unit_Bp(ak), unit_taps(ak), an, lane, pf);
 
     // ---- P1 epilogue (bias already inside acc)
     if (wave >= 3 && wave <= 5) {            // b3a | b4a | b5a -> T1 (bf16), through the row map (SAME-padding halos)
@@ -1910,7 +1910,7 @@ __global__ __launch_bounds__(512, TM >= 2 ? DS_FUSEDB_WPS : 2) void inception_fu
                 *reinterpret_cast<uint2*>(T1h + rm * (2 * B_LD1) + (wave * 32 - 96) + 8 * g + h4) =
                     pack4(acc[mt][4 * g], acc[mt][4 * g + 1], acc[mt][4 * g + 2], acc[mt][4 * g + 3]);
         }
-    } else if (wave != 0) {                  // b5s tail | b2 and b1 | padding -> output tile
+    } else if (wave != 0) {                  // b2 -> channels [48, 96), b1 -> channels [0, 48) of the tile's rows (b5 stem | padding stay behind)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int col = wave * 32 + 8 * g + h4;          // groups of 4 never straddle 48 / 240
@@ -1918,125 +1918,91 @@ __global__ __launch_bounds__(512, TM >= 2 ? DS_FUSEDB_WPS : 2) void inception_fu
                 const int ycol = col < 96 ? col : col - 192;
 #pragma unroll
                 for (int mt = 0; mt < TM; ++mt)
-                    *reinterpret_cast<uint2*>(Ysh + (mt * 32 + rlane) * (2 * B_LD1) + ycol) =
+                    *reinterpret_cast<uint2*>(Ash + (mt * 32 + rlane) * (2 * B_LDA) + ycol) =
                         pack4(acc[mt][4 * g], acc[mt][4 * g + 1], acc[mt][4 * g + 2], acc[mt][4 * g + 3]);
             }
         }
     }
-    __syncthreads();   // T1 and the b1|b2 tile complete
+    lds_barrier();   // T1 complete
     DS_STAMP(3);
-    // b1|b2 rows out (whole 192-byte row segments). No barrier behind this flush: nothing writes into the tile before the
-    // barrier at the end of P2a -- the second-stage units that run in P2a keep their results in registers until then
-    gbf16w Yg = out_rows();
-    for (int idx = tid; idx < TR32 * 12; idx += 512) {      // 96 channels = 12 x 16 B per row
-        const int row = idx / 12, q = idx - row * 12;
-        if (row < TRv) {
-            const float4 v = *reinterpret_cast<const float4*>(Ys + row * B_LD1 + q * 4);
-            v4f o = {v.x, v.y, v.z, v.w};
-            *(__attribute__((address_space(1))) v4f*)(Yg + (unsigned)(row * 256 + q * 8)) = o;
-        }
-    }
-    DS_STAMP(4);
 
-    // unit (kind, m-tile, n-tile) of the second-stage convs: 1 = 1x3 32 -> 64 of branch 5 (to T2, layers.py:127-131),
-    // 2 = 1x3 32 -> 48 of branch 3 (Y[96,144), layers.py:106-110), 3 = 1x5 32 -> 48 of branch 4 (Y[144,192), layers.py:115-119)
-    auto unit_compute = [&](int kind, int mt, int nt, floatx16& u) __attribute__((always_inline)) {
+    // unit (kind, m-tile, n-tile) of the second-stage convs: 1 = 1x3 32 -> 64 of branch 5 (-> T2 = channels [192, 256) of the
+    // rows, layers.py:127-131), 2 = 1x3 32 -> 48 of branch 3 (channels [96, 144), layers.py:106-110), 3 = 1x5 32 -> 48 of
+    // branch 4 (channels [144, 192), layers.py:115-119)
+    auto run_unit = [&](int kind, int mt, int nt) __attribute__((always_inline)) {
+        floatx16 u;
         const float* bsrc = Bs + (kind == 1 ? 0 : kind == 2 ? 64 : 128) + nt * 32 + h4;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const float4 t = *reinterpret_cast<const float4*>(bsrc + 8 * g);
             u[4 * g] = t.x; u[4 * g + 1] = t.y; u[4 * g + 2] = t.z; u[4 * g + 3] = t.w;
         }
-        const int rm = rowmap[mt * 32 + rlane];
+        const int row = mt * 32 + rlane;
+        const int rm = rowmap[row];
         if (kind == 1) fusedb_conv_unit<3>(T1, rm, 32, lane, pf, u);          // b5a = channels 64..95 = units 32..47
         else if (kind == 2) fusedb_conv_unit<3>(T1, rm, 0, lane, pf, u);      // b3a = channels 0..31
         else fusedb_conv_unit<5>(T1, rm, 16, lane, pf, u);                    // b4a = channels 32..63
-    };
-    auto unit_store = [&](int kind, int mt, int nt, const floatx16& u) __attribute__((always_inline)) {
-        const int row = mt * 32 + rlane;
-        if (kind == 1) {
+        const int cbase = kind == 1 ? 192 : kind == 2 ? 96 : 144;
+        const int ncol = kind == 1 ? 64 : 48;                                 // wave-uniform: 48 output channels = n-tile 0 and half of n-tile 1
 #pragma unroll
-            for (int g = 0; g < 4; ++g)
-                *reinterpret_cast<uint2*>(T2h + row * (2 * B_LD2) + nt * 32 + 8 * g + h4) = pack4(u[4 * g], u[4 * g + 1], u[4 * g + 2], u[4 * g + 3]);
-        } else {
-            const int ybase = kind == 2 ? 0 : 48;                             // channel inside the b3|b4|b5 tile
-#pragma unroll
-            for (int g = 0; g < 4; ++g)
-                if (nt * 32 + 8 * g < 48)       // wave-uniform: 48 output channels = n-tile 0 and half of n-tile 1
-                    *reinterpret_cast<uint2*>(Y2h + row * (2 * B_LDY) + ybase + nt * 32 + 8 * g + h4) =
-                        pack4(u[4 * g], u[4 * g + 1], u[4 * g + 2], u[4 * g + 3]);
-        }
+        for (int g = 0; g < 4; ++g)
+            if (nt * 32 + 8 * g < ncol)
+                *reinterpret_cast<uint2*>(Ash + row * (2 * B_LDA) + cbase + nt * 32 + 8 * g + h4) = pack4(u[4 * g], u[4 * g + 1], u[4 * g + 2], u[4 * g + 3]);
     };
 
-    // ---- P2a: branch 5's 1x3 units go to T2 (disjoint from the b1|b2 tile still being read out); branch 3 / 4 units that run
-    // here park their results in the accumulator registers P1 has left free (waves 0, 1 -- the stem accumulators -- run
-    // branch-5 units only) and write them into the output tile in P2b
-    const bool parked = a1k >= 2;
-    if (a1k == 1) {
-        floatx16 u;
-        unit_compute(1, a1m, a1n, u);
-        unit_store(1, a1m, a1n, u);
-    } else if (parked) {
-        unit_compute(a1k, a1m, a1n, acc[0]);
-        if (a2k) {
-            if (a2k != a1k || a2n != a1n) fusedb_unit_prefetch(unit_Bp(a2k), unit_taps(a2k), a2n, lane, pf);     // same n-tile: same weights
-            unit_compute(a2k, a2m, a2n, acc[1 % TM]);
-            if (a3m >= 0) unit_compute(a2k, a3m, a2n, acc[2 % TM]);
-        }
+    // ---- P2a: branch 5's 1x3 units -> T2, branch 3 (/ 4) units -> their output channels
+    if (ak) {
+        run_unit(ak, am, an);
+        if (anm == 3) { run_unit(ak, am + 1, an); run_unit(ak, am + 2, an); }      // same n-tile: same weights
     }
     if (wave < 2) {       // the tail's four weight fragments travel in the (idle) unit-weight registers
 #pragma unroll
         for (int g = 0; g < 4; ++g) pf[g] = gload4(a.Bp5c + ((size_t)(wave * 4 + g) * 64 + lane) * 4);
-    } else if (b1k) {
-        fusedb_unit_prefetch(unit_Bp(b1k), unit_taps(b1k), b1n, lane, pf);
+    } else if (bk) {
+        fusedb_unit_prefetch(unit_Bp(bk), unit_taps(bk), bn, lane, pf);
     }
+    DS_STAMP(4);
+    lds_barrier();     // T2 complete
     DS_STAMP(5);
-    lds_barrier();     // T2 complete, b1|b2 tile read out: the b3|b4|b5 tile may overwrite it
-    DS_STAMP(6);
 
-    // ---- P2b
-    if (parked) {
-        unit_store(a1k, a1m, a1n, acc[0]);
-        if (a2k) {
-            unit_store(a2k, a2m, a2n, acc[1 % TM]);
-            if (a3m >= 0) unit_store(a2k, a3m, a2n, acc[2 % TM]);
-        }
-    }
+    // ---- P2b: branch 4's 1x5 units; waves 0, 1: branch 5's tail
     if (wave < 2) {
-        // branch 5 tail: 1x1 64 -> 48 (BN, no ReLU) accumulated on top of the stem conv held in acc, then relu(stem + tail)   layers.py:132-138
+        // 1x1 64 -> 48 (BN, no ReLU) accumulated on top of the stem conv held in acc, then relu(stem + tail)   layers.py:132-138
 #pragma unroll
         for (int mt = 0; mt < TM; ++mt) {
-            const float* base = T2 + (mt * 32 + rlane) * B_LD2 + h4;
+            const float* base = As + (mt * 32 + rlane) * B_LDA + 96 + h4;
 #pragma unroll
             for (int g = 0; g < 4; ++g) acc[mt] = mfma_bf(pf[g], *reinterpret_cast<const float4*>(base + g * 8), acc[mt]);
         }
+    } else if (bk) {
+        run_unit(bk, bm, bn);
+    }
+    DS_STAMP(6);
+    lds_barrier();     // every T2 fragment has been read: branch 5's output may take its place
+    if (wave < 2) {
 #pragma unroll
         for (int mt = 0; mt < TM; ++mt)
 #pragma unroll
             for (int g = 0; g < 4; ++g)
                 if (wave * 32 + 8 * g < 48)
-                    *reinterpret_cast<uint2*>(Y2h + (mt * 32 + rlane) * (2 * B_LDY) + 96 + wave * 32 + 8 * g + h4) =
+                    *reinterpret_cast<uint2*>(Ash + (mt * 32 + rlane) * (2 * B_LDA) + 192 + wave * 32 + 8 * g + h4) =
                         pack4(acc[mt][4 * g], acc[mt][4 * g + 1], acc[mt][4 * g + 2], acc[mt][4 * g + 3]);
-    } else if (b1k) {
-        floatx16 u;
-        unit_compute(b1k, b1m, b1n, u);
-        unit_store(b1k, b1m, b1n, u);
     }
-    lds_barrier();     // the b3|b4|b5 tile is complete
-    Yg = out_rows();
-    for (int idx = tid; idx < TR32 * 18; idx += 512) {      // 144 channels = 18 x 16 B per row, Y[96, 240)
-        const int row = idx / 18, q = idx - row * 18;
-        if (row < TRv) {
-            const float4 v = *reinterpret_cast<const float4*>(Y2 + row * B_LDY + q * 4);
-            v4f o = {v.x, v.y, v.z, v.w};
-            *(__attribute__((address_space(1))) v4f*)(Yg + (unsigned)(row * 256 + 96 + q * 8)) = o;
+    lds_barrier();     // the module's output rows are complete: the next module's input
+    if (a.write_rows) {
+        // ---- the chain's last module (every module when taps are on): rows out, 480 contiguous bytes each (30 x 16 B)
+        const gbf16w Yg = (gbf16w)(reinterpret_cast<unsigned short*>(a.Y) + (size_t)__builtin_amdgcn_readfirstlane(site0) * W * 256);
+        for (int idx = tid; idx < TR32 * 30; idx += 512) {
+            const int row = idx / 30, q = idx - row * 30;
+            if (row < TRv) {
+                const float4 v = *reinterpret_cast<const float4*>(As + row * B_LDA + q * 4);
+                v4f o = {v.x, v.y, v.z, v.w};
+                *(__attribute__((address_space(1))) v4f*)(Yg + (unsigned)(row * 256 + q * 8)) = o;
+            }
         }
     }
     DS_STAMP(7);
 #undef DS_STAMP
-    // the next module reads the rows this one has just stored (other waves' stores included) and overwrites the LDS tile the
-    // flush above is still reading: everybody's stores and LDS reads are complete behind this barrier
-    if (mi + 1 < c.nmod) __syncthreads();
     }   // modules of the chain
 }
 
