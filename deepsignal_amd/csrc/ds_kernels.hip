@@ -86,6 +86,21 @@ __device__ __forceinline__ unsigned short f2bf(float v)     // round to nearest 
     return __builtin_bit_cast(unsigned short, (__bf16)v);
 }
 __device__ __forceinline__ float bf2f(unsigned short b) { return __uint_as_float((unsigned)b << 16); }
+// relu on the bits: max(int(x), 0). One v_max_i32; relu_f(x) costs two instructions in IEEE mode (hipcc first quiets
+// a possible signalling NaN with v_max_f32 x, x). Same result for every non-NaN x (-0.0 -> +0.0 either way).
+__device__ __forceinline__ float relu_f(float x)
+{
+    const int b = __builtin_bit_cast(int, x);
+    return __builtin_bit_cast(float, b > 0 ? b : 0);
+}
+// two floats -> one dword of two bf16 (round to nearest even): ONE v_cvt_pk_bf16_f32, low half = a
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float float2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pack_bf2(float a, float b)
+{
+    const float2_t f = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f, bf16x2_t));
+}
 
 // BF = bf16 operands. The byte geometry is the same as fp32: a "unit" is 4 bytes (one float or two bf16), a
 // K chunk is 16 units = 64 B per row (16 floats / 32 bf16), one 16-B fragment per lane feeds four
@@ -498,7 +513,7 @@ __global__ __launch_bounds__(64 * WM * WN * KS, 1) void gemm_kernel(const GemmLa
                     if (row < M && r >= r_lo && r < r_hi) {
                         float v = acc[mt][nt][r] + bias;
                         if (os.add) v += gload(os.add + (size_t)row * os.add_ld + cc);
-                        if (os.relu) v = fmaxf(v, 0.0f);
+                        if (os.relu) v = relu_f(v);
                         if (BF && os.bf16)
                             *(__attribute__((address_space(1))) unsigned short*)((unsigned short*)os.base + (size_t)row * os.ld + cc) = f2bf(v);
                         else
@@ -1445,8 +1460,8 @@ __device__ __forceinline__ void inception_fused_body(const FusedChain& c)
 #pragma unroll
             for (int g = 0; g < 4; ++g)
                 *reinterpret_cast<float4*>(T1 + rm * F_LD1 + (wave * 32 - 96) + 8 * g + h4) =
-                    make_float4(fmaxf(acc[mt][4 * g], 0.0f), fmaxf(acc[mt][4 * g + 1], 0.0f), fmaxf(acc[mt][4 * g + 2], 0.0f),
-                                fmaxf(acc[mt][4 * g + 3], 0.0f));
+                    make_float4(relu_f(acc[mt][4 * g]), relu_f(acc[mt][4 * g + 1]), relu_f(acc[mt][4 * g + 2]),
+                                relu_f(acc[mt][4 * g + 3]));
         }
     } else if (wave != 0) {                  // n-tiles 1,2 (b5s tail | b2) and 6,7 (b1 | padding) -> output tile
 #pragma unroll
@@ -1457,8 +1472,8 @@ __device__ __forceinline__ void inception_fused_body(const FusedChain& c)
 #pragma unroll
                 for (int mt = 0; mt < TM; ++mt)
                     *reinterpret_cast<float4*>(Ys + (mt * 32 + rlane) * F_LD1 + ycol) =
-                        make_float4(fmaxf(acc[mt][4 * g], 0.0f), fmaxf(acc[mt][4 * g + 1], 0.0f), fmaxf(acc[mt][4 * g + 2], 0.0f),
-                                    fmaxf(acc[mt][4 * g + 3], 0.0f));
+                        make_float4(relu_f(acc[mt][4 * g]), relu_f(acc[mt][4 * g + 1]), relu_f(acc[mt][4 * g + 2]),
+                                    relu_f(acc[mt][4 * g + 3]));
             }
         }
     }
@@ -1489,7 +1504,7 @@ __device__ __forceinline__ void inception_fused_body(const FusedChain& c)
 #pragma unroll
             for (int g = 0; g < 4; ++g)
                 *reinterpret_cast<float4*>(T2 + row * F_LD2 + nt * 32 + 8 * g + h4) =
-                    make_float4(fmaxf(u[4 * g], 0.0f), fmaxf(u[4 * g + 1], 0.0f), fmaxf(u[4 * g + 2], 0.0f), fmaxf(u[4 * g + 3], 0.0f));
+                    make_float4(relu_f(u[4 * g]), relu_f(u[4 * g + 1]), relu_f(u[4 * g + 2]), relu_f(u[4 * g + 3]));
         } else {
             // kind 2: 1x3, 32 -> 48, ReLU, to Y[96,144)   layers.py:106-110
             // kind 3: 1x5, 32 -> 48, ReLU, to Y[144,192)  layers.py:115-119
@@ -1500,7 +1515,7 @@ __device__ __forceinline__ void inception_fused_body(const FusedChain& c)
 #pragma unroll
                 for (int g = 0; g < 4; ++g)
                     if (nt * 32 + 8 * g < 48) {      // wave-uniform: 48 output channels = n-tile 0 and half of n-tile 1
-                        v4f o = {fmaxf(u[4 * g], 0.0f), fmaxf(u[4 * g + 1], 0.0f), fmaxf(u[4 * g + 2], 0.0f), fmaxf(u[4 * g + 3], 0.0f)};
+                        v4f o = {relu_f(u[4 * g]), relu_f(u[4 * g + 1]), relu_f(u[4 * g + 2]), relu_f(u[4 * g + 3])};
                         *(__attribute__((address_space(1))) v4f*)(Yg + (unsigned)(row * 240 + ybase + nt * 32 + 8 * g + h4)) = o;
                     }
             }
@@ -1550,8 +1565,8 @@ __device__ __forceinline__ void inception_fused_body(const FusedChain& c)
 #pragma unroll
                 for (int g = 0; g < 4; ++g)
                     if (wave * 32 + 8 * g < 48) {
-                        v4f o = {fmaxf(acc[mt][4 * g], 0.0f), fmaxf(acc[mt][4 * g + 1], 0.0f), fmaxf(acc[mt][4 * g + 2], 0.0f),
-                                 fmaxf(acc[mt][4 * g + 3], 0.0f)};
+                        v4f o = {relu_f(acc[mt][4 * g]), relu_f(acc[mt][4 * g + 1]), relu_f(acc[mt][4 * g + 2]),
+                                 relu_f(acc[mt][4 * g + 3])};
                         *(__attribute__((address_space(1))) v4f*)(Yg + (unsigned)(row * 240 + 192 + wave * 32 + 8 * g + h4)) = o;
                     }
             }
@@ -1703,8 +1718,7 @@ __global__ __launch_bounds__(512, TM >= 2 ? DS_FUSEDB_WPS : 2) void inception_fu
 
     // relu + round four consecutive channels to bf16 -> one 8-byte group
     auto pack4 = [](float x0, float x1, float x2, float x3) -> uint2 {
-        return make_uint2((unsigned)f2bf(fmaxf(x0, 0.0f)) | ((unsigned)f2bf(fmaxf(x1, 0.0f)) << 16),
-                          (unsigned)f2bf(fmaxf(x2, 0.0f)) | ((unsigned)f2bf(fmaxf(x3, 0.0f)) << 16));
+        return make_uint2(pack_bf2(relu_f(x0), relu_f(x1)), pack_bf2(relu_f(x2), relu_f(x3)));
     };
 
     // static wave -> unit assignment of P2 (wave-uniform). kind: 0 none, 1 b5b, 2 b3b, 3 b4b; phase a runs `anm` m-tiles
@@ -2098,7 +2112,7 @@ __global__ __launch_bounds__(512, 2) void stem23_kernel(const Stem23Args a)
             float* const td = T + rowmap[row] * S23_LDT + n2 * 32 + h4;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const float4 o = make_float4(fmaxf(u[4 * g], 0.0f), fmaxf(u[4 * g + 1], 0.0f), fmaxf(u[4 * g + 2], 0.0f), fmaxf(u[4 * g + 3], 0.0f));
+                const float4 o = make_float4(relu_f(u[4 * g]), relu_f(u[4 * g + 1]), relu_f(u[4 * g + 2]), relu_f(u[4 * g + 3]));
                 *reinterpret_cast<float4*>(td + 8 * g) = o;
                 if (a.C2 && row < TRv) {                       // diagnostic tap (debug mode): conv_layer2's output rows
                     const v4f ov = {o.x, o.y, o.z, o.w};
@@ -2148,7 +2162,7 @@ __global__ __launch_bounds__(512, 2) void stem23_kernel(const Stem23Args a)
             float* const yd = a.Y + (grow0 + row) * 256 + wave * 32 + h4;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const v4f o = {fmaxf(acc[m][4 * g], 0.0f), fmaxf(acc[m][4 * g + 1], 0.0f), fmaxf(acc[m][4 * g + 2], 0.0f), fmaxf(acc[m][4 * g + 3], 0.0f)};
+                const v4f o = {relu_f(acc[m][4 * g]), relu_f(acc[m][4 * g + 1]), relu_f(acc[m][4 * g + 2]), relu_f(acc[m][4 * g + 3])};
                 *(__attribute__((address_space(1))) v4f*)(yd + 8 * g) = o;
             }
         }
@@ -2197,8 +2211,7 @@ __global__ __launch_bounds__(512, 4) void stem23_bf16_kernel(const Stem23Args a)
     unsigned short* const Th = reinterpret_cast<unsigned short*>(T);
     unsigned short* const Oh = reinterpret_cast<unsigned short*>(Ot);
     auto pack4 = [](float x0, float x1, float x2, float x3) -> uint2 {
-        return make_uint2((unsigned)f2bf(fmaxf(x0, 0.0f)) | ((unsigned)f2bf(fmaxf(x1, 0.0f)) << 16),
-                          (unsigned)f2bf(fmaxf(x2, 0.0f)) | ((unsigned)f2bf(fmaxf(x3, 0.0f)) << 16));
+        return make_uint2(pack_bf2(relu_f(x0), relu_f(x1)), pack_bf2(relu_f(x2), relu_f(x3)));
     };
 
     // ---- stage: zero T (halo rows), row map, input rows (96 rows x 8 slots of 16 B: 768 slots)
@@ -2391,7 +2404,7 @@ __global__ __launch_bounds__(256) void stem1_kernel(const float* __restrict__ si
             const int wc = wc0 + pt;
             best = (wc >= 0 && wc < w1) ? fmaxf(best, a) : best;     // padded pool taps are ignored
         }
-        const float y = fmaxf(best + b, 0.0f);
+        const float y = relu_f(best + b);
         if (OUT_BF) reinterpret_cast<unsigned short*>(out)[((size_t)site * wa + p) * 64 + c] = f2bf(y);
         else out[((size_t)site * wa + p) * 64 + c] = y;
     }

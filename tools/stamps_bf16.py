@@ -9,8 +9,8 @@ e = Engine(max_batch=B, precision="bf16_all", slots=1, serial=True, debug_stamps
 f = synth.synthetic_features(B, seed=2)
 args = [f[k] for k in ("kmer", "means", "stds", "sanums", "signals")]
 for _ in range(3): e.run(*args)
-names = ["(n)", "load+stage", "P1 mfma", "P1 epi+sync", "Ys store", "P2a", "sync", "P2b"]
-for m in (2, 5, 10):
+names = ["(n)", "prologue(+load)", "P1 mfma", "sync+epi+sync", "P2a", "sync", "P2b", "sync+tail st+sync(+rows out)"]
+for m in range(1, 12):
     st = e.intermediate("stamps%d" % m, (16,))
     print("module", m, "wgs", int(st[0]))
     for wv in range(2):
