@@ -1690,6 +1690,20 @@ __device__ __forceinline__ void fusedb_conv_unit(const float* T1, int rm, int co
     }
 }
 
+// the same unit on NM m-tiles at once (one set of weights, NM independent accumulator chains: a single unit is a chain of
+// dependent MFMAs behind dependent LDS reads, i.e. latency)
+template <int NTAPS, int NM>
+__device__ __forceinline__ void fusedb_conv_units(const float* T1, const int (&rm)[NM], int coloff_units, int lane, const float4 (&ub)[10], floatx16 (&acc)[NM])
+{
+#pragma unroll
+    for (int t = 0; t < NTAPS; ++t)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int m = 0; m < NM; ++m)
+                acc[m] = mfma_bf(ub[t * 2 + j], *reinterpret_cast<const float4*>(T1 + (rm[m] + t - NTAPS / 2) * B_LD1 + coloff_units + (lane >> 5) * 4 + j * 8), acc[m]);
+}
+
 template <int TM>
 __global__ __launch_bounds__(512, TM >= 2 ? DS_FUSEDB_WPS : 2) void inception_fused_bf16_kernel(const FusedChain c)
 {
@@ -1965,9 +1979,34 @@ __global__ __launch_bounds__(512, TM >= 2 ? DS_FUSEDB_WPS : 2) void inception_fu
     };
 
     // ---- P2a: branch 5's 1x3 units -> T2, branch 3 (/ 4) units -> their output channels
-    if (ak) {
+    if (TM == 3 && wave >= 6) {
+        // branch 3's n-tile on all three m-tiles (same weights): m-tiles 0, 1 interleaved, then m-tile 2 (one after the other
+        // the three units took 4.4 k cycles against 2.4 k for the single unit of the other waves: a unit is a chain of
+        // dependent LDS reads and MFMAs; three accumulators at once do not fit the 128 registers next to the stem's)
+        {
+            floatx16 u2[2];
+            const float* bsrc = Bs + 64 + an * 32 + h4;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 t = *reinterpret_cast<const float4*>(bsrc + 8 * g);
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) { u2[mt][4 * g] = t.x; u2[mt][4 * g + 1] = t.y; u2[mt][4 * g + 2] = t.z; u2[mt][4 * g + 3] = t.w; }
+            }
+            int rm[2];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) rm[mt] = rowmap[mt * 32 + rlane];
+            fusedb_conv_units<3, 2>(T1, rm, 0, lane, pf, u2);
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    if (an * 32 + 8 * g < 48)
+                        *reinterpret_cast<uint2*>(Ash + (mt * 32 + rlane) * (2 * B_LDA) + 96 + an * 32 + 8 * g + h4) =
+                            pack4(u2[mt][4 * g], u2[mt][4 * g + 1], u2[mt][4 * g + 2], u2[mt][4 * g + 3]);
+        }
+        run_unit(2, 2, an);
+    } else if (ak) {
         run_unit(ak, am, an);
-        if (anm == 3) { run_unit(ak, am + 1, an); run_unit(ak, am + 2, an); }      // same n-tile: same weights
     }
     if (wave < 2) {       // the tail's four weight fragments travel in the (idle) unit-weight registers
 #pragma unroll
