@@ -472,13 +472,13 @@ int finalize_weights(ds_handle* h)
                 for (int c = 0; c < C; ++c) o[c] += v * (double)a2[(size_t)m * C + c];
             }
         }
-        std::vector<float> wf((size_t)J * C);
+        // row pitch of module 11's rows as the head reads them: 240 channels (fp32) or the bf16 rows' 256 (pad channels: zero rows)
+        const int rp = h->bf16 ? 256 : INC_OUT;
         const int ev = h->is_rnn ? 2 * HID : 0;
+        std::vector<float> wf(((size_t)ev + (h->is_cnn ? (size_t)h->wc * rp : 0)) * C, 0.0f);
         for (int k = 0; k < ev; ++k)
             for (int c = 0; c < C; ++c) wf[(size_t)k * C + c] = (float)w12[(size_t)k * C + c];
-        if (h->is_cnn && h->bf16) {      // bf16 modes keep the pooling kernel (it writes the bf16 joint row the head reads)
-            for (size_t i = (size_t)ev * C; i < wf.size(); ++i) wf[i] = (float)w12[i];
-        } else if (h->is_cnn) {
+        if (h->is_cnn) {
             const int wc = h->wc;
             for (int w = 0; w < wc; ++w)
                 for (int ch = 0; ch < INC_OUT; ++ch)
@@ -488,7 +488,7 @@ int finalize_weights(ds_handle* h)
                             const int cnt = std::min(wc - 1, wp + 3) - std::max(0, wp - 3) + 1;
                             sacc += w12[(size_t)(ev + wp * INC_OUT + ch) * C + c] / cnt;
                         }
-                        wf[(size_t)(ev + w * INC_OUT + ch) * C + c] = (float)sacc;
+                        wf[(size_t)(ev + w * rp + ch) * C + c] = (float)sacc;
                     }
         }
         if ((rc = upload(h, &h->w12f, wf))) return rc;
@@ -798,7 +798,7 @@ int build_plan(ds_handle* h, int n, Plan* plan)
         }
     }
     sig_rows = x;
-    if (!h->fold_fc || bf) {   // avgpool_layer1 + flatten (folded into the head's matrix in fp32)            layers.py:233-238
+    if (!h->fold_fc) {   // avgpool_layer1 + flatten (the folded head's matrix carries the pool: it reads module 11's rows)   layers.py:233-238
         Op op{};
         op.kind = OP_AVGPOOL; op.stream = 0; op.stage = stage_id(h, "pools", 0);
         op.in = x; op.out = bf ? h->cur->joint : h->cur->sigfeat; op.a = h->wc; op.d = INC_OUT;
@@ -895,7 +895,9 @@ int build_plan(ds_handle* h, int n, Plan* plan)
         op.kind = OP_HEADF; op.stream = 0; op.stage = st;
         HeadFoldedArgs& a = op.ha;
         if (bf) {
-            a.seg[0] = h->cur->joint; a.len[0] = h->J; a.nseg = 1; a.bf16_pitch = h->JP;
+            a.bf16 = 1;
+            if (h->is_rnn) { a.seg[a.nseg] = h->cur->joint; a.len[a.nseg] = 2 * HID; a.pitch[a.nseg++] = h->JP; }     // [bf16 h_fw | h_bw] (pack_event_feat_bf16_kernel)
+            if (h->is_cnn) { a.seg[a.nseg] = sig_rows; a.len[a.nseg] = h->wc * 256; a.pitch[a.nseg++] = h->wc * 256; }
         } else {
         if (h->is_rnn) {
             a.seg[a.nseg] = h->cur->hlast[0]; a.len[a.nseg++] = HID;

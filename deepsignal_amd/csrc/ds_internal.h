@@ -176,7 +176,9 @@ struct HeadFoldedArgs {
     int len[3];           // floats per site in the segment (multiple of 4)
     int nseg;
     const float* w;       // [sum len][C]
-    int bf16_pitch;       // > 0: ONE segment of bf16 rows (seg[0], len[0] values per site, this many bf16 per row): the bf16 modes' joint buffer
+    int bf16;             // 1: the segments are bf16 rows, len[s] values of a site's pitch[s] (the bf16 modes: [bf16 h_fw | h_bw] and module 11's
+                          // rows of 256-channel pitch, whose pad channels meet zero weight rows)
+    int pitch[3];
     float *logits, *act;
     int* pred;
     int n, C;

@@ -2594,12 +2594,13 @@ __global__ __launch_bounds__(256) void head_folded_kernel(const HeadFoldedArgs a
 #pragma unroll
     for (int c = 0; c < 16; ++c) accv[c] = 0.0f;
     int koff = 0;
-    if (a.bf16_pitch > 0) {                               // bf16 modes: [event | signal features] bf16 row, 8 values per 16 bytes
-        const float4* x8 = reinterpret_cast<const float4*>(reinterpret_cast<const unsigned short*>(a.seg[0]) + (size_t)site * a.bf16_pitch);
-        for (int k8 = tid; k8 < (a.len[0] >> 3); k8 += 256) {
+    if (a.bf16) {                                         // bf16 modes: bf16 rows, 8 values per 16 bytes
+        for (int sg = 0; sg < a.nseg; ++sg) {             // uniform
+        const float4* x8 = reinterpret_cast<const float4*>(reinterpret_cast<const unsigned short*>(a.seg[sg]) + (size_t)site * a.pitch[sg]);
+        for (int k8 = tid; k8 < (a.len[sg] >> 3); k8 += 256) {
             const float4 raw = x8[k8];
             const unsigned u[4] = {__float_as_uint(raw.x), __float_as_uint(raw.y), __float_as_uint(raw.z), __float_as_uint(raw.w)};
-            const float* w = a.w + (size_t)k8 * 8 * C;
+            const float* w = a.w + (size_t)(koff + k8 * 8) * C;
             if (C == 2) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -2617,6 +2618,8 @@ __global__ __launch_bounds__(256) void head_folded_kernel(const HeadFoldedArgs a
                         if (c < C) accv[c] += x0 * w[(2 * e) * C + c] + x1 * w[(2 * e + 1) * C + c];
                 }
             }
+        }
+        koff += a.len[sg];
         }
     } else
     for (int sg = 0; sg < a.nseg; ++sg) {                 // uniform

@@ -154,3 +154,31 @@ def test_bf16_lstm_tile_shapes_give_the_same_bits(small_weights):
     assert np.array_equal(a_mid, a_big[:1000]) and np.array_equal(p_mid, p_big[:1000])
     assert np.array_equal(a_small, a_big[:700]) and np.array_equal(p_small, p_big[:700])
     assert np.array_equal(a_one, a_big[2099:2100]) and np.array_equal(p_one, p_big[2099:2100])
+
+
+@pytest.mark.parametrize("precision", ["bf16", "bf16_all"])
+@pytest.mark.parametrize("variant", [dict(), dict(is_cnn=False), dict(is_rnn=False), dict(class_num=3)])
+def test_bf16_folded_head_against_the_three_step_bf16_path(variant, precision):
+    """bf16 modes, default engine: the head multiplies [bf16 h_fw | bf16 h_bw | module 11's bf16 rows] with the fp32 matrix
+    (avgpool^T)(W1 W2) -- no pooling kernel, no rounding of the pooled features. The three-step form of the same precision
+    (DS_TUNE_NO_FOLD_FC: bf16 pooling kernel, bf16 dense(J, J) weights, fp32 dense(J, C)) is the same function up to those
+    bf16 roundings: logits within 2e-2 of their scale, sigmoids within 5e-3, equal labels wherever the margin exceeds 2e-2."""
+    from deepsignal_amd import weights as W
+    w = W.random_weights(seed=21, lstm_bias_std=0.1, **variant)
+    feats = synth.synthetic_features(200, seed=78)
+    keys = ("kmer", "means", "stds", "sanums", "signals")
+    folded = _engine(w, max_batch=256, precision=precision, **variant)
+    steps = _engine(w, max_batch=256, precision=precision, fold_fc=False, **variant)
+    act_f, pred_f = folded.run(*[feats[k] for k in keys])
+    act_s, pred_s = steps.run(*[feats[k] for k in keys])
+    C = variant.get("class_num", 2)
+    lf, ls = folded.intermediate("logits", (200, C)), steps.intermediate("logits", (200, C))
+    scale = max(1.0, float(np.abs(ls).max()))
+    print("bf16 folded vs three-step (%s, %s): max |d logit| %.3e (scale %.2f), max |d act| %.3e" %
+          (precision, variant, float(np.abs(lf - ls).max()), scale, float(np.abs(act_f - act_s).max())))
+    assert np.abs(lf - ls).max() <= 2e-2 * scale
+    assert np.abs(act_f - act_s).max() <= FP32_ACT_ATOL
+    srt = np.sort(act_s, axis=1)
+    decided = srt[:, -1] - srt[:, -2] > FP32_LABEL_MARGIN
+    assert (pred_f[decided] == pred_s[decided]).all()
+    folded.close(); steps.close()
