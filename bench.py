@@ -138,12 +138,12 @@ def _recorded_commit(path):
         return None
 
 
-def pmc_traffic(kernel_name):
+def pmc_traffic(kernel_name, pattern="r[0-9][0-9]_pmc_traffic.json"):
     """HBM bytes per launch of `kernel_name` from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE are
     collected in separate runs of this same command and corrected as MI355X_MICROARCH.md prescribes; see
     tools/pmc_traffic.py). Counters cannot be read from inside the process: this is a COMMITTED CONSTANT of an earlier
     run, not a measurement of this one, and `traffic_source` says so."""
-    path = _latest_profile("r[0-9][0-9]_pmc_traffic.json")
+    path = _latest_profile(pattern)
     try:
         rec = json.load(open(path))
         for name, v in rec["kernels"].items():
@@ -299,11 +299,17 @@ def configs2_leg(Engine, w, torch, dev, local_rank):
                 c_ms = sum(k["total_ms"] for k in conv) / 6
                 c_bytes = 992 * 564 * B
                 out["conv_path_hbm"] = {
-                    "kernel": "inception_fused_bf16_kernel (3 launches: the modules of a width class chained per tile)",
+                    "kernel": "inception_fused_bf16_kernel (3 launches: the modules of a width class chained per tile, the tile's rows "
+                              "kept in LDS from module to module)",
                     "us_per_step": round(c_ms * 1e3, 1), "algorithmic_bytes": c_bytes, "achieved": round(c_bytes / (c_ms * 1e-3) / 1e9, 1),
                     "unit": "GB/s", "peak": 8000.0, "frac": round(c_bytes / (c_ms * 1e-3) / 8e12, 4),
-                    "how": "992 B per module row (512 in + 480 out, bf16) x 564 module rows per site x 4096 sites / HIP-event duration, "
-                           "every launch on one stream; HBM-side bytes by PMC: profiles/r03_bf16_all_4096_pmc_traffic.json"}
+                    "how": "module-granular bytes (SURVEY.md 8d): 992 B per module row (512 in + 480 out, bf16) x 564 module rows per "
+                           "site x 4096 sites / HIP-event duration, every launch on one stream. The kernel moves fewer bytes than that: "
+                           "only a chain's first module reads rows from HBM and only its last one writes them (traffic_per_step)"}
+                t = pmc_traffic("inception_fused_bf16_kernel<3>", "r[0-9][0-9]_bf16_all_4096_pmc_traffic.json")
+                if t.get("traffic"):
+                    out["conv_path_hbm"].update({"traffic_per_step": 3 * t["traffic"], "traffic_source": t["traffic_source"],
+                                                 "hbm_side_frac": round(3 * t["traffic"] / (c_ms * 1e-3) / 8e12, 4)})
         assert bool(torch.isfinite(act).all())
         out[prec] = r
         e.close()
