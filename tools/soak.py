@@ -11,8 +11,8 @@ from deepsignal_amd.engine import Engine
 
 secs = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 prec = sys.argv[2] if len(sys.argv) > 2 else "fp32"
-POOL = 8192
 B = int(sys.argv[3]) if len(sys.argv) > 3 else 512          # max_batch of the engine under test
+POOL = max(8192, 4 * B)
 keys = ("kmer", "means", "stds", "sanums", "signals")
 feats = synth.synthetic_features(POOL, seed=77)
 eng = Engine(max_batch=B, precision=prec)
