@@ -253,6 +253,24 @@ def test_short_signals_at_big_batches(geom, batch):
     eng.close()
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16", "bf16_all"])
+def test_a_batch_of_8192_gives_the_bits_of_batches_of_512(small_weights, precision):
+    """Every tiling decision the planner takes from the batch size (sites per fused-module tile, BiLSTM tile shapes, the
+    bf16 module chain that keeps its rows in LDS, grids of > 65,535 workgroups) must leave a site's bits alone: one forward
+    of 8,192 sites (and a ragged one of 8,155) against the same sites in passes of 512."""
+    feats = synth.synthetic_features(8192, seed=91)
+    keys = ("kmer", "means", "stds", "sanums", "signals")
+    ref = _engine(small_weights, max_batch=512, precision=precision)
+    r_act, r_pred = ref.run(*(feats[k] for k in keys))
+    ref.close()
+    big = _engine(small_weights, max_batch=8192, precision=precision)
+    act, pred = big.run(*(feats[k] for k in keys))
+    assert np.array_equal(act, r_act) and np.array_equal(pred, r_pred)
+    act, pred = big.run(*(feats[k][37:] for k in keys))
+    assert np.array_equal(act, r_act[37:]) and np.array_equal(pred, r_pred[37:])
+    big.close()
+
+
 def test_submit_wait_matches_run(small_weights):
     """Asynchronous host boundary (ds_submit / ds_wait): tickets waited in order give the bits of the blocking run();
     over-subscription and stale tickets are refused."""
