@@ -182,3 +182,31 @@ def test_bf16_folded_head_against_the_three_step_bf16_path(variant, precision):
     decided = srt[:, -1] - srt[:, -2] > FP32_LABEL_MARGIN
     assert (pred_f[decided] == pred_s[decided]).all()
     folded.close(); steps.close()
+
+
+@pytest.mark.parametrize("geom,batch", [(dict(kmer_len=17, signal_len=128), 1024), (dict(kmer_len=9, signal_len=62), 1536),
+                                        (dict(kmer_len=17, signal_len=360), 700)])
+def test_bf16_all_other_geometries_and_ragged_batches(geom, batch):
+    """--cent_signals_len / --kmer_len other than the defaults change every tile shape of the bf16 kernels (module widths
+    32 / 16 / 8 and 16 / 8 / 4 instead of 90 / 45 / 23: up to twelve sites per 96-row tile, chains of the same lengths) and
+    the BiLSTM's step count; 700 sites leave ragged last tiles everywhere. Outputs within the bf16 tolerance of the fp32
+    engine, and a site's bits must not depend on the batch it travels in."""
+    from deepsignal_amd import weights as W
+    w = W.random_weights(seed=36, lstm_bias_std=0.1, **geom)
+    feats = synth.synthetic_features(batch, seed=10, **geom)
+    keys = ("kmer", "means", "stds", "sanums", "signals")
+    f32 = _engine(w, max_batch=batch, **geom)
+    r_act, r_pred = f32.run(*(feats[k] for k in keys))
+    f32.close()
+    eng = _engine(w, max_batch=batch, precision="bf16_all", **geom)
+    act, pred = eng.run(*(feats[k] for k in keys))
+    assert np.isfinite(act).all()
+    print("bf16_all %s batch %d: max |d act| vs fp32 %.3e" % (geom, batch, float(np.abs(act - r_act).max())))
+    assert np.abs(act - r_act).max() <= FP32_ACT_ATOL
+    srt = np.sort(r_act, axis=1)
+    decided = srt[:, -1] - srt[:, -2] > FP32_LABEL_MARGIN
+    assert (pred[decided] == r_pred[decided]).all()
+    sel = np.random.default_rng(2).choice(batch, 83, replace=False)
+    a2, p2 = eng.run(*(feats[k][sel] for k in keys))
+    assert np.array_equal(a2, act[sel]) and np.array_equal(p2, pred[sel])
+    eng.close()
