@@ -1737,13 +1737,13 @@ __global__ __launch_bounds__(512, TM >= 2 ? DS_FUSEDB_WPS : 2) void inception_fu
         return make_uint2(pack_bf2(relu_f(x0), relu_f(x1)), pack_bf2(relu_f(x2), relu_f(x3)));
     };
 
-    // static wave -> unit assignment of P2 (wave-uniform). kind: 0 none, 1 b5b, 2 b3b, 3 b4b; phase a runs `anm` m-tiles
-    // (am, am + 1, ...) on one set of weights
-    int ak = 0, am = 0, an = 0, anm = 1;
+    // static wave -> unit assignment of P2 (wave-uniform). kind: 0 none, 1 b5b, 2 b3b, 3 b4b; with three m-tiles waves 6, 7 run
+    // branch 3's n-tile on all of them in phase a (one set of weights)
+    int ak = 0, am = 0, an = 0;
     int bk = 0, bm = 0, bn = 0;
     if (TM == 3) {
         if (wave < 6) { ak = 1; am = wave % 3; an = wave / 3; }
-        else { ak = 2; am = 0; an = wave - 6; anm = 3; }
+        else { ak = 2; am = 0; an = wave - 6; }
         if (wave >= 2) { bk = 3; bm = (wave - 2) % 3; bn = (wave - 2) / 3; }
     } else if (TM == 2) {
         if (wave < 4) { ak = 1; am = wave & 1; an = wave >> 1; }
