@@ -1591,6 +1591,10 @@ int64_t ds_get_intermediate(ds_handle* h, const char* name, float* out, int64_t 
             }
         return rows * ch;
     };
+    if (h->fold_fc && (s == "signal_feat" || s == "fc1" || s == "joint"))
+        return fail(h, DS_ERR_INVALID, "the folded joint model has no " + s + " tensor: use debug mode or DS_TUNE_NO_FOLD_FC");
+    if (s == "stem_conv2" && !h->debug && !h->no_fused)
+        return fail(h, DS_ERR_INVALID, "conv_layer2's rows stay in LDS (stem23 kernels): the stem_conv2 tap needs debug mode");
     if (h->bf16) {
         if (s == "stem_pool") return copy_bf(h->cur->stem_pool, (int64_t)n * h->wa, 64, 64);
         if (s == "stem_conv2") return copy_bf(h->cur->conv2o, (int64_t)n * h->wa, 128, 128);
@@ -1600,22 +1604,22 @@ int64_t ds_get_intermediate(ds_handle* h, const char* name, float* out, int64_t 
         if (s.rfind("module", 0) == 0) {
             const int m = atoi(s.c_str() + 6) - 1;
             if (m < 0 || m >= NMOD) return fail(h, DS_ERR_INVALID, "bad module index");
-            if (!h->debug && m < NMOD - 2) return fail(h, DS_ERR_INVALID, "module taps need debug mode (cfg.reserved[0]=1)");
+            // (outside debug mode the module buffers are shared and, in the bf16 modes, the rows of a chain's inner modules
+            // never leave the CU: only the last module's rows exist)
+            if (!h->debug && m < NMOD - 1) return fail(h, DS_ERR_INVALID, "module taps other than the last module need debug mode (cfg.reserved[0]=1)");
             return copy_bf(h->cur->modout[m], (int64_t)n * module_width(h, m), INC_OUT, 256);
         }
     }
     if (s == "stem_pool") return copy(h->cur->stem_pool, (int64_t)n * h->wa * 64);
     if (s == "stem_conv2") return copy(h->cur->conv2o, (int64_t)n * h->wa * 128);
     if (s == "stem_conv3") return copy(h->cur->conv3o, (int64_t)n * h->wa * 256);
-    if (h->fold_fc && (s == "signal_feat" || s == "fc1" || s == "joint"))
-        return fail(h, DS_ERR_INVALID, "the folded joint model has no " + s + " tensor: use debug mode or DS_TUNE_NO_FOLD_FC");
     if (s == "signal_feat") return copy(h->cur->sigfeat, (int64_t)n * h->SF);
     if (s == "fc1") return copy(h->cur->fc1o, (int64_t)n * h->J);
     if (s == "logits") return copy(h->cur->logits, (int64_t)n * h->C);
     if (s.rfind("module", 0) == 0) {
         const int m = atoi(s.c_str() + 6) - 1;
         if (m < 0 || m >= NMOD) return fail(h, DS_ERR_INVALID, "bad module index");
-        if (!h->debug && m < NMOD - 2) return fail(h, DS_ERR_INVALID, "module taps need debug mode (cfg.reserved[0]=1)");
+        if (!h->debug && m < NMOD - 1) return fail(h, DS_ERR_INVALID, "module taps other than the last module need debug mode (cfg.reserved[0]=1)");
         return copy(h->cur->modout[m], (int64_t)n * module_width(h, m) * INC_OUT);
     }
     if (s.rfind("lstm_", 0) == 0 && s.size() == 10) {   // lstm_fw_l0: device layout [T][B][256] -> [n][T][256]

@@ -407,3 +407,26 @@ def test_folded_joint_model_matches_the_three_step_path(variant):
 
 def steps_j(variant):
     return spec.net_dims(is_cnn=variant.get("is_cnn", True), is_rnn=variant.get("is_rnn", True)).joint
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16_all"])
+def test_taps_that_do_not_exist_are_refused(small_weights, precision):
+    """Outside debug mode conv_layer2's rows never leave LDS, the module buffers are shared (and in the bf16 modes a chain's
+    inner modules keep their rows in LDS), and the folded joint model has no pooled features / fc1: those taps must fail
+    loudly, not hand back whatever the buffer last held. The last module's rows and the logits always exist."""
+    feats = synth.synthetic_features(40, seed=5)
+    keys = ("kmer", "means", "stds", "sanums", "signals")
+    eng = _engine(small_weights, max_batch=64, precision=precision)
+    eng.run(*(feats[k] for k in keys))
+    for name, shape in (("stem_conv2", (40, 90, 128)), ("module5", (40, 45, 240)), ("module10", (40, 23, 240)),
+                        ("signal_feat", (40, 5520)), ("joint", (40, 6032)), ("fc1", (40, 6032))):
+        with pytest.raises(RuntimeError):
+            eng.intermediate(name, shape)
+    assert np.isfinite(eng.intermediate("module11", (40, 23, 240))).all()
+    assert np.isfinite(eng.intermediate("logits", (40, 2))).all()
+    eng.close()
+    dbg = _engine(small_weights, max_batch=64, precision=precision, debug=True)
+    dbg.run(*(feats[k] for k in keys))
+    for name, shape in (("stem_conv2", (40, 90, 128)), ("module5", (40, 45, 240)), ("module10", (40, 23, 240)), ("fc1", (40, 6032))):
+        assert np.isfinite(dbg.intermediate(name, shape)).all()
+    dbg.close()
