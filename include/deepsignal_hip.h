@@ -143,7 +143,9 @@ int ds_free_host(void *p);
 /* Test/diagnostic access to intermediate tensors of the LAST forward (float32, row-major, same
  * names/shapes as the oracle taps: stem_pool, stem_conv2, stem_conv3, module1..module11,
  * signal_feat, lstm_{fw,bw}_l{0,1,2}, joint, fc1, logits). Returns the number of floats written,
- * or a negative error. */
+ * or a negative error. A tensor the configured path does not materialise is an error, not stale data: outside debug
+ * mode (reserved[0]) that is stem_conv2 and module1..module10 (rows that stay in LDS / shared buffers), and with the
+ * folded joint model signal_feat, joint and fc1. */
 int64_t ds_get_intermediate(ds_handle *h, const char *name, float *out, int64_t capacity);
 
 /* Timing with HIP events on the engine's own streams (forwards run eagerly while it is on).
