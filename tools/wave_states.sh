@@ -1,7 +1,7 @@
 set -u
 export TMPDIR=/tmp
 O=gpurun_out/ws; mkdir -p $O
-rocprofv3 -L > $O/avail.txt 2>&1 || true
+
 for cfg in "bf16_all 4096" "fp32 512 threestep"; do
   tag=$(echo $cfg | tr ' ' '_')
   rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA --output-format csv -d $O/${tag}_p1 -- python3 tools/probe_engine.py $cfg > /dev/null 2> $O/${tag}_p1.err
@@ -12,4 +12,4 @@ for cfg in "bf16_all 4096" "fp32 512 threestep"; do
   tail -3 $O/${tag}_p2.err $O/${tag}_p3.err
   rm -rf $O/${tag}_p1 $O/${tag}_p2 $O/${tag}_p3
 done
-grep -c . $O/avail.txt
+
