@@ -203,3 +203,21 @@ def test_formatter_matches_reference_rows():
                 pred = np.argmax(act, axis=1).astype(np.int32)
                 got = fastio.format_rows(np.frombuffer(info, np.uint8), off[s:e + 1], act, pred, kmer[s:e]).decode().splitlines()
                 assert got == [next(rows_iter) for _ in range(e - s)]
+
+
+def test_decimal_token_parsers_give_strtods_bits_on_three_million_tokens(tmp_path):
+    """tools/parse_bench.cpp holds the reader's two fast paths for plain decimals (the byte loop and the one-load SSSE3 /
+    SSE4.1 form of csrc/ds_io.cpp) side by side and checks every token either accepts against strtod: 2 M "%.6f"-style
+    values as feature files hold them, 1 M random digit strings with a dot anywhere, and the edge forms (no digits, two
+    dots, exponents, 16 digits, a lone sign), which must be left to the general parser."""
+    import shutil
+    import subprocess
+    cxx = shutil.which("g++")
+    if cxx is None:
+        pytest.skip("no g++")
+    exe = os.path.join(str(tmp_path), "parse_bench")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.run([cxx, "-O2", "-std=c++17", os.path.join(root, "tools", "parse_bench.cpp"), "-o", exe], check=True, timeout=300)
+    out = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+    text = out.stdout.decode()
+    assert out.returncode == 0 and "mismatches 0" in text, text[-2000:]
