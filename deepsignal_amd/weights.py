@@ -80,6 +80,60 @@ def random_weights(seed: int = WEIGHT_SEED, kmer_len: int = 17, signal_len: int 
     return out
 
 
+STRESS_SEED = 20260417
+
+
+def stress_weights(seed: int = STRESS_SEED, lstm_scale: float = 3.5, lstm_bias_std: float = 0.6,
+                   gamma_hi: float = 3.0, hot_frac: float = 0.1, head: "np.ndarray | None" = None,
+                   **geometry) -> Dict[str, np.ndarray]:
+    """Random weights at the scale a TRAINED model has, for parity tests outside the linear regime of `random_weights`
+    (whose glorot-uniform LSTM kernels keep every gate pre-activation near 0 and every logit within +-0.7):
+
+      * LSTM kernels x `lstm_scale`, LSTM bias ~ N(0, `lstm_bias_std`): gate pre-activations of std ~1.5, |h| up to 0.99
+        (`layers.py:45-72`: the sigmoid / tanh of the cells leave their linear part);
+      * BN gamma: a `hot_frac` share of the channels of every layer drawn from U(1.5, `gamma_hi`), the rest as
+        `random_weights` (all channels at 3 would grow the eleven residual modules to 1e5, which no trained net does);
+      * `head`: a `dense_1/kernel` [J, 2] to install (see `centred_head`), else the glorot one stays.
+
+    Pure numpy, no forward pass: tests/golden/make_stress_golden.py computes the head once and commits it."""
+    w = random_weights(seed=seed, lstm_bias_std=lstm_bias_std, **geometry)
+    rng = np.random.default_rng(seed + 1)
+    for name in w:
+        leaf = name.rsplit("/", 1)[-1]
+        if name.endswith("lstm_cell/kernel"):
+            w[name] = (w[name] * np.float32(lstm_scale)).astype(np.float32)
+        elif leaf == "gamma":
+            g = w[name].copy()
+            hot = rng.random(g.shape) < hot_frac
+            g[hot] = rng.uniform(1.5, gamma_hi, size=int(hot.sum()))
+            w[name] = g.astype(np.float32)
+    if head is not None:
+        install_head(w, head)
+    return w
+
+
+def centred_head(fc1: np.ndarray, direction: np.ndarray, logit_std: float, seed: int) -> np.ndarray:
+    """A two-class `dense_1/kernel` whose labels are balanced on the batch that produced `fc1` [n, J] (the input of
+    `layers.py:261-263`'s second dense layer, from ANY forward implementation): `direction` [J] has its component along
+    the batch mean of fc1 removed (mean logit 0 -- the joint model has no bias to do that with), is scaled so that the
+    logits have standard deviation `logit_std` over the batch, and the second column is its negative plus 2 % noise
+    (anti-correlated columns: sigmoid outputs far apart, both labels present)."""
+    fc1 = np.asarray(fc1, np.float64)
+    col = np.asarray(direction, np.float64).copy()
+    m = fc1.mean(axis=0)
+    col -= m * (m @ col) / (m @ m)
+    col *= logit_std / (fc1 @ col).std()
+    noise = np.random.default_rng(seed).normal(0.0, 0.02 * np.abs(col).mean(), size=col.shape)
+    return np.stack([col, -col + noise], axis=1).astype(np.float32)
+
+
+def install_head(weights: Dict[str, np.ndarray], head: np.ndarray) -> None:
+    head = np.ascontiguousarray(head, dtype=np.float32)
+    if head.shape != weights["dense_1/kernel"].shape:
+        raise ValueError("head has shape %s, dense_1/kernel %s" % (head.shape, weights["dense_1/kernel"].shape))
+    weights["dense_1/kernel"] = head
+
+
 def check_weights(weights: Dict[str, np.ndarray], kmer_len: int = 17, signal_len: int = 360,
                   class_num: int = 2, **variant) -> None:
     for name, shape in spec.tensor_table(kmer_len, signal_len, class_num, **variant):

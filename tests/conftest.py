@@ -38,3 +38,29 @@ def small_weights():
     """Seeded random-init weights with non-zero LSTM bias and randomised BN (exercises every fold)."""
     from deepsignal_amd import weights
     return weights.random_weights(seed=7, lstm_bias_std=0.1)
+
+
+def _stress_golden():
+    import numpy as np
+    return np.load(os.path.join(ROOT, "tests", "golden", "stress_golden.npz"))
+
+
+@pytest.fixture(scope="session")
+def balanced_weights(small_weights):
+    """`small_weights` with the committed balanced head (tests/golden/make_stress_golden.py): same benign regime, but logits
+    of std 0.5 around 0 and anti-correlated columns, so a batch holds both labels and a label check asserts something."""
+    from deepsignal_amd import weights
+    g = _stress_golden()
+    assert int(g["small_seed"]) == 7 and float(g["small_lstm_bias_std"]) == 0.1
+    w = dict(small_weights)
+    weights.install_head(w, g["small_head"])
+    return w
+
+
+@pytest.fixture(scope="session")
+def stress_weights():
+    """Weights at a trained model's scale (saturating LSTM gates, hot BN channels, logits spanning +-10, both labels):
+    `weights.stress_weights` + the committed head."""
+    from deepsignal_amd import weights
+    g = _stress_golden()
+    return weights.stress_weights(int(g["stress_seed"]), head=g["stress_head"])

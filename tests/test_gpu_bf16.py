@@ -101,6 +101,66 @@ def test_bf16_config3_tolerance_vs_fp32(small_weights, precision):
     assert np.array_equal(a_small, a16[100:177]) and np.array_equal(p_small, p16[100:177])
 
 
+# bf16 distance to fp32 where the read-out is balanced (tests/golden/make_stress_golden.py): (mean |d act| gate, share of
+# label flips allowed, fp32 margin |p1 - p0| above which no label may flip). Measured values: DESIGN.md section 9.
+TRAINED_REGIME_GATES = {"balanced": (0.04, 0.10, 0.30), "stress": (0.06, 0.10, 0.60)}
+
+
+@pytest.mark.parametrize("precision", ["bf16", "bf16_all"])
+@pytest.mark.parametrize("which", ["balanced", "stress"])
+def test_bf16_config3_tolerance_vs_fp32_in_the_trained_regime(request, which, precision):
+    """configs[2]'s "tolerance vs fp32 reported", second column: on `small_weights` every logit is within +-0.7, every site
+    has the same label and '0 flips' says nothing. Here the head is centred (both labels, anti-correlated columns; `stress`
+    also saturates the LSTM and has hot BN channels): the read-out then amplifies the site-to-site variation of features
+    whose common mode is ~13x larger, and bf16 storage noise (2^-9 per stored activation, through 3 + 11 x 6 layers) shows.
+    The numbers are a property of bf16 storage, not of this implementation: the CPU emulation that rounds at the same points
+    (oracle/torch_statement.forward_bf16) is held to the same statistics on a 256-site subset."""
+    import json
+    import os
+    n = 4096
+    w = request.getfixturevalue(which + "_weights")
+    feats = synth.synthetic_features(n, seed=4096)
+    args = [feats[k] for k in ("kmer", "means", "stds", "sanums", "signals")]
+    e32 = _engine(w, max_batch=n, slots=1)
+    a32, p32 = e32.run(*args)
+    e32.close()
+    e16 = _engine(w, max_batch=n, slots=1, precision=precision)
+    a16, p16 = e16.run(*args)
+    e16.close()
+    assert np.isfinite(a16).all()
+    pn = lambda a: a / a.sum(axis=1, keepdims=True)
+    d = np.abs(a16 - a32).max(axis=1)
+    dpn = np.abs(pn(a16) - pn(a32)).max(axis=1)
+    margin = np.abs(a32[:, 1] - a32[:, 0])
+    flips = p16 != p32
+    sub = {k: v[:256] for k, v in feats.items()}
+    e_act, e_pred = torch_statement.forward_bf16(w, sub, lstm_bf16=precision == "bf16_all")[:2]
+    d_emu = np.abs(e_act - a32[:256]).max(axis=1)
+    rec = {"n": n, "max_abs_d_act": float(d.max()), "mean_abs_d_act": float(d.mean()), "p99_abs_d_act": float(np.quantile(d, 0.99)),
+           "max_abs_d_pnorm": float(dpn.max()), "mean_abs_d_pnorm": float(dpn.mean()),
+           "label_flip_rate": float(flips.mean()), "largest_fp32_margin_of_a_flipped_site": float(margin[flips].max()) if flips.any() else 0.0,
+           "label1_share_fp32": float(p32.mean()),
+           "cpu_emulation_256": {"max_abs_d_act": float(d_emu.max()), "mean_abs_d_act": float(d_emu.mean()),
+                                 "label_flip_rate": float((e_pred != p32[:256]).mean())},
+           "engine_vs_emulation_256_mean_abs": float(np.abs(a16[:256] - e_act).max(axis=1).mean())}
+    print("\n%s / %s vs fp32 at batch %d: %s" % (which, precision, n, json.dumps(rec)))
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "stress_bf16_tolerance.json")
+    try:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        old = json.load(open(path)) if os.path.exists(path) else {}
+        old["%s_%s" % (which, precision)] = rec
+        json.dump(old, open(path, "w"), indent=1, sort_keys=True)
+    except OSError:
+        pass
+    assert 0.2 <= float(p32.mean()) <= 0.8
+    mean_gate, flip_gate, margin_gate = TRAINED_REGIME_GATES[which]
+    assert rec["mean_abs_d_act"] <= mean_gate
+    assert rec["label_flip_rate"] <= flip_gate
+    assert rec["largest_fp32_margin_of_a_flipped_site"] <= margin_gate
+    # the engine is as far from fp32 as the emulation of its rounding points is -- not further
+    assert float(d[:256].mean()) <= 1.5 * float(d_emu.mean()) + 1e-3
+
+
 def test_bf16_against_oracle_small(small_weights):
     """Same gate as the north star states for the path (outputs within 1e-4 of the reference) does NOT hold for
     bf16 -- this test documents the actual distance to the fp32 CPU oracle on a small batch."""
