@@ -1,0 +1,125 @@
+"""GPU: everything about N > 1 that ONE GPU can prove (VERDICT r03 "next" #7). Two processes under the real launcher
+(`python -m torch.distributed.run --nproc-per-node 2`), each with its OWN Engine on GPU 0, collectives on gloo -- the
+process topology, the sharded call_mods route, bench.py's timed-window code with a barrier / gather across real ranks, and
+the failure paths (a rank that raises, a rank that dies) run here; an 8-GPU box then only adds RCCL-over-xGMI itself
+(which tests/test_gpu_rccl.py runs with one rank)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+import time
+
+import numpy as np
+import pytest
+
+from deepsignal_amd import synth, weights as W
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+WORKER = os.path.join(ROOT, "tests", "two_rank_worker.py")
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _launch(nproc, script_and_args, timeout, extra_env=None):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.update(extra_env or {})
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port())] + script_and_args
+    t0 = time.time()
+    out = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout)
+    return out, time.time() - t0
+
+
+def _write_feature_tsv(path, feats, reads):
+    bases = "ACGTN"
+    with open(path, "w") as f:
+        for i in range(len(reads)):
+            cols = ["chr1", str(100 + i), "+", str(i), reads[i], "t", "".join(bases[int(c)] for c in feats["kmer"][i]),
+                    ",".join("%.6f" % x for x in feats["means"][i]), ",".join("%.6f" % x for x in feats["stds"][i]),
+                    ",".join(str(int(x)) for x in feats["sanums"][i]), ",".join("%.6f" % x for x in feats["signals"][i]),
+                    str(int(feats["labels"][i]))]
+            f.write("\t".join(cols) + "\n")
+
+
+@pytest.fixture(scope="module")
+def job(tmp_path_factory, balanced_weights):
+    """6,000 sites in reads of 1 .. 29 sites, the balanced weight set (both labels in the file), and the plain
+    single-process result file as the reference."""
+    from deepsignal_amd import call_modifications as cm
+    from deepsignal_amd.engine import Engine
+    tmp = str(tmp_path_factory.mktemp("two_procs"))
+    rng = np.random.default_rng(13)
+    lens = []
+    while sum(lens) < 6000:
+        lens.append(int(rng.integers(1, 30)))
+    reads = ["read_%05d" % k for k, m in enumerate(lens) for _ in range(m)]
+    feats = synth.synthetic_features(len(reads), seed=43)
+    tsv, wfile, plain = os.path.join(tmp, "features.tsv"), os.path.join(tmp, "w.dsw"), os.path.join(tmp, "plain.tsv")
+    _write_feature_tsv(tsv, feats, reads)
+    W.save_weights(wfile, balanced_weights)
+    eng = Engine(device=0, max_batch=512)
+    eng.load_weights_file(wfile)
+    n = cm.call_mods(tsv, "unused", plain, 17, 360, 512, 0.001, 2, 1, True, True, True, True, None, engine=eng, f5_batch_num=20)
+    eng.close()
+    assert n == len(reads)
+    labels = np.array([int(l.split("\t")[-2]) for l in open(plain).read().splitlines()])
+    assert 0.2 < labels.mean() < 0.8, "the reference file holds one label only"
+    return {"tmp": tmp, "tsv": tsv, "wfile": wfile, "plain": plain, "n": n}
+
+
+@pytest.mark.parametrize("nproc", [2, 3])
+def test_sharded_call_mods_two_processes_on_one_gpu(job, nproc):
+    """Each rank parses its own byte ranges, runs them on its own engine (own HIP context, streams, weight replica) and
+    rank 0 writes the gathered rows: byte-identical to the single-process file, about 20 rounds of the row gather."""
+    out = os.path.join(job["tmp"], "sharded_%d.tsv" % nproc)
+    res, dt = _launch(nproc, [WORKER, "ok", job["tsv"], job["wfile"], out, str(1 << 19)], timeout=600)
+    assert res.returncode == 0, res.stderr.decode()[-3000:]
+    assert open(out, "rb").read() == open(job["plain"], "rb").read()
+    for r in range(nproc):
+        assert int(open(out + ".rank%d.count" % r).read()) == job["n"]           # every rank learns the job-wide count
+        assert r == 0 or not os.path.exists(out + ".rank%d" % r)
+
+
+@pytest.mark.parametrize("mode", ["raise", "die"])
+def test_a_failing_rank_ends_the_job_with_an_error_and_no_hang(job, mode):
+    """Rank 1's engine raises (or its process dies) on its third batch: no rank may hang in a collective -- the launcher
+    must come back non-zero well inside the process-group timeout budget, and no rank may report success."""
+    out = os.path.join(job["tmp"], "failing_%s.tsv" % mode)
+    res, dt = _launch(2, [WORKER, mode, job["tsv"], job["wfile"], out, str(1 << 17)], timeout=400,
+                      extra_env={"DS_TEST_PG_TIMEOUT": "45"})
+    assert res.returncode != 0
+    assert dt < 300, "the surviving rank sat in a collective for %.0f s" % dt
+    assert not os.path.exists(out + ".rank0.count") and not os.path.exists(out + ".rank1.count")
+    if mode == "raise":
+        assert b"injected engine failure" in res.stderr
+
+
+def test_bench_timed_windows_across_two_ranks_on_one_gpu(tmp_path):
+    """bench.py's N > 1 code path with two REAL ranks (barrier + synchronize fences, max over ranks, the result gather
+    inside every window), both engines on GPU 0, collectives on gloo (--backend gloo --share-gpu): one JSON line, both
+    ranks' window times in it, 2 x K x 512 sites gathered per window."""
+    res, dt = _launch(2, [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5", "--windows", "3",
+                          "--no-profile-pass", "--backend", "gloo", "--share-gpu", "--collective-timeout", "120"], timeout=900)
+    assert res.returncode == 0, res.stderr.decode()[-3000:]
+    lines = [l for l in res.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, res.stdout.decode()[-2000:]
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["steps"] == 20 and r["scaling"] == "weak"
+    assert r["gather"]["backend"] == "gloo" and r["gather"]["world"] == 2 and r["gather"]["bytes_per_window"] == 2 * 20 * 512 * 12
+    pr = r["windows"]["per_rank_ms_per_step"]
+    assert len(pr) == 3 and all(len(w_) == 2 and min(w_) > 0 for w_ in pr)
+    # value = all ranks' sites / the slowest rank's time
+    assert abs(r["ms_per_step"] - sorted(max(w_) for w_ in pr)[1]) < 1e-3
+    assert r["value"] > 1e5          # two engines sharing one GPU: about the one-GPU rate in total
+    with open(os.path.join(str(tmp_path), "bench_two_ranks_one_gpu.json"), "w") as f:
+        f.write(lines[0])

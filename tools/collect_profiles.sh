@@ -3,13 +3,16 @@
 #   tools/collect_profiles.sh r03      -> gpurun_out/prof_r03/{bench.json, kernel_stats.csv, fetch/, write/, mfma/}
 # Counter passes are separate runs with --pmc only (no trace domains), as the pool requires.
 set -u
-R=${1:-r03}
+R=${1:-r04}
 OUT=gpurun_out/prof_$R
 mkdir -p $OUT
 export TMPDIR=/tmp
 python3 bench.py > $OUT/bench.json 2> $OUT/bench.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --no-cpu-baseline --no-host-path --no-fast-mode --no-configs2 --no-standalone-pass > $OUT/bench_under_rocprof.json 2> $OUT/trace.err
 cp $(ls $OUT/trace/*/*kernel_stats.csv | head -1) $OUT/kernel_stats.csv 2>/dev/null
+# stand-alone kernel durations (every launch on one stream): the figures bench.py's roofline leads with must agree with this CSV
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/strace -- python3 tools/probe_engine.py fp32 512 threestep reps=40 > /dev/null 2> $OUT/strace.err
+cp $(ls $OUT/strace/*/*kernel_stats.csv | head -1) $OUT/serial_kernel_stats.csv 2>/dev/null
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 bench.py --steps 4 --warmup 1 --windows 1 --no-cpu-baseline --no-host-path --no-fast-mode --no-configs2 --no-profile-pass > /dev/null 2> $OUT/fetch.err
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 bench.py --steps 4 --warmup 1 --windows 1 --no-cpu-baseline --no-host-path --no-fast-mode --no-configs2 --no-profile-pass > /dev/null 2> $OUT/write.err
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/mfma -- python3 tools/probe_engine.py fp32 512 threestep > /dev/null 2> $OUT/mfma.err
@@ -29,7 +32,7 @@ rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/bwrite -- python3 tools/p
 python3 tools/pmc_traffic.py $OUT/bfetch $OUT/bwrite $OUT/bf16_all_4096_pmc_traffic.json > $OUT/bf16_all_4096_pmc_traffic.txt 2>&1
 cp $(ls $OUT/bfetch/*/*counter_collection.csv | head -1) $OUT/bf16_fetch_size_counter_collection.csv 2>/dev/null
 cp $(ls $OUT/bwrite/*/*counter_collection.csv | head -1) $OUT/bf16_write_size_counter_collection.csv 2>/dev/null
-rm -rf $OUT/trace $OUT/fetch $OUT/write $OUT/mfma $OUT/btrace $OUT/bfetch $OUT/bwrite
+rm -rf $OUT/strace $OUT/trace $OUT/fetch $OUT/write $OUT/mfma $OUT/btrace $OUT/bfetch $OUT/bwrite
 cat $OUT/bf16_all_4096_pmc_traffic.txt | head -12
 ls -la $OUT
 cat $OUT/pmc_mfma_util.txt
