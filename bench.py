@@ -473,6 +473,7 @@ def main():
         w = None
         eng = _DryRunEngine(torch)
     else:
+        from deepsignal_amd import engine as _engine_mod
         from deepsignal_amd.engine import Engine
         w = W.random_weights(seed=W.WEIGHT_SEED)          # TF-initializer style, randomised BN
         # the headline engine runs the REFERENCE GRAPH: joint model as avgpool + dense(6032, 6032) + dense(6032, 2)
@@ -563,6 +564,8 @@ def main():
                     "min": round(world * K * BATCH / max(windows), 1) if K else 0.0,
                     "max": round(world * K * BATCH / min(windows), 1) if K else 0.0},
     }
+    if not args.dry_run and _engine_mod.LIBRARY_OVERRIDE:
+        result["library_override"] = _engine_mod.LIBRARY_OVERRIDE       # DS_HIP_LIBRARY was set: NOT the in-tree product library
     if dist is not None:
         result["windows"]["per_rank_ms_per_step"] = [[round(1e3 * x / max(K, 1), 4) for x in w_] for w_ in per_rank[:len(windows)]]
         result["gather"] = {"backend": dist.get_backend(), "world": world, "bytes_per_window": gathered["bytes"],

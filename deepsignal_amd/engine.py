@@ -16,8 +16,12 @@ from typing import Dict, List, Optional, Tuple
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# DS_HIP_LIBRARY: developer override (kernel A/B builds under tools/); the product path is always the in-tree library
-LIB_PATH = os.environ.get("DS_HIP_LIBRARY") or os.path.join(_HERE, "libdeepsignal_hip.so")
+# DS_HIP_LIBRARY: developer override (kernel A/B builds under tools/). The product path is the in-tree library; an active
+# override is announced on stderr when the library is loaded and shows up in bench.py's JSON ("library_override"), so a
+# variable left over from an A/B session cannot silently change what a product run or a benchmark measures.
+DEFAULT_LIB_PATH = os.path.join(_HERE, "libdeepsignal_hip.so")
+LIB_PATH = os.environ.get("DS_HIP_LIBRARY") or DEFAULT_LIB_PATH
+LIBRARY_OVERRIDE = LIB_PATH if os.path.abspath(LIB_PATH) != os.path.abspath(DEFAULT_LIB_PATH) else None
 
 # every symbol include/deepsignal_hip.h declares
 EXPORTED_SYMBOLS = (
@@ -86,6 +90,9 @@ def load_library() -> ctypes.CDLL:
             "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(or `make -C deepsignal_amd/csrc`). There is no CPU fallback." % LIB_PATH)
     _share_hip_runtime_with_torch()
+    if LIBRARY_OVERRIDE:
+        import sys
+        print("deepsignal_amd: DS_HIP_LIBRARY is set -- loading %s instead of the in-tree library" % LIBRARY_OVERRIDE, file=sys.stderr)
     lib = ctypes.CDLL(LIB_PATH)
     vp, i32, i64 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64
     lib.ds_create.argtypes = [ctypes.POINTER(DsConfig), ctypes.POINTER(vp)]

@@ -13,6 +13,7 @@ tombo-resquiggled single-read fast5 files are opened with `h5py` where it exists
 from __future__ import annotations
 
 import os
+import sys
 import random
 from typing import Dict, Iterable, List, Optional, Sequence, Set, Tuple
 
@@ -27,6 +28,8 @@ iupac_alphabets = {"A": ["A"], "T": ["T"], "C": ["C"], "G": ["G"], "R": ["A", "G
 iupac_alphabets_rna = {k: [("U" if b == "T" else b) for b in v] for k, v in iupac_alphabets.items() if k != "T"}
 iupac_alphabets_rna["U"] = ["U"]
 
+
+_UNSUPPORTED_SEEN = set()      # minihdf5.Unsupported messages already reported (per process)
 
 def get_motif_seqs(motifs: str, is_dna: bool = True) -> List[str]:
     """'CG' / 'CHG,CHH' -> every concrete sequence of the IUPAC motifs (process_utils.py:113-143)."""
@@ -191,8 +194,17 @@ def _extract_features(fast5s, corrected_group, basecall_subgroup, normalize_meth
             features_list += extract_read_features(raw, starts, lengths, bases, scaling, offset, readname, strand,
                                                    alignstrand, chrom, chrom_start, chromlen, motif_seqs, methyloc,
                                                    kmer_len, raw_signals_len, methy_label, normalize_method, positions)
-        except Exception:
+        except Exception as exc:
+            # the reference counts and continues (extract_features.py:263-265). A file the built-in HDF5 reader cannot
+            # open for a NAMED reason (VBZ-compressed signal, dense groups ...) is also counted, but the reason is
+            # printed once per kind: a directory of such files would otherwise end as "N failed" and nothing else
             error += 1
+            if type(exc).__name__ == "Unsupported":
+                msg = str(exc)
+                if msg not in _UNSUPPORTED_SEEN:
+                    _UNSUPPORTED_SEEN.add(msg)
+                    print("warning - %s: fast5 feature not supported by the built-in HDF5 reader: %s (install h5py to read "
+                          "such files; further files failing for this reason are only counted)" % (fp, msg), file=sys.stderr)
     return features_list, error
 
 

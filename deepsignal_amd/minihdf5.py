@@ -158,6 +158,7 @@ class _Messages:
     def __init__(self, f: "File", addr: int):
         b = f._b
         self.items: List[Tuple[int, bytes]] = []
+        self.shared = set()       # message types whose body is a shared-message reference (header message flag bit 1)
         d = b.d
         if d[addr:addr + 4] == b"OHDR":
             self._v2(f, addr)
@@ -175,6 +176,8 @@ class _Messages:
                 body = d[p + 8:p + 8 + msize]
                 if mtype == 0x10:
                     blocks.append((b.off(p + 8), b.length(p + 8 + b.so)))
+                if d[p + 4] & 0x02:
+                    self.shared.add(mtype)                         # body = a reference to a shared / committed message
                 self.items.append((mtype, body))
                 p += 8 + msize
 
@@ -196,6 +199,8 @@ class _Messages:
             end = p + left
             while p + 4 <= end:
                 mtype, msize = d[p], b.u(p + 1, 2)
+                if d[p + 3] & 0x02:
+                    self.shared.add(mtype)
                 p += 4 + (2 if track else 0)
                 if p + msize > end:
                     break
@@ -208,13 +213,19 @@ class _Messages:
                 self.items.append((mtype, body))
                 p += msize
 
+    def _not_shared(self, mtype: int) -> None:
+        if mtype in self.shared:
+            raise Unsupported("shared header message (type 0x%02x: a committed datatype or a shared-message-table entry)" % mtype)
+
     def first(self, mtype: int) -> Optional[bytes]:
+        self._not_shared(mtype)
         for t, body in self.items:
             if t == mtype:
                 return body
         return None
 
     def all(self, mtype: int) -> Iterator[bytes]:
+        self._not_shared(mtype)
         return (body for t, body in self.items if t == mtype)
 
 
@@ -318,6 +329,35 @@ class Dataset(_Object):
                 raise Unsupported("dataset filter id %d" % fid)
         return chunk
 
+    def _filled(self) -> np.ndarray:
+        """An array of the dataset's shape holding its fill value: what HDF5 returns for storage that was never written
+        (an undefined data address, a chunk absent from the index). Fill value message 0x05, versions 1 - 3; the old fill
+        message 0x04 is raised as unsupported rather than guessed at."""
+        out = np.zeros(self.shape, self.dtype)
+        body = self._msgs.first(0x05)
+        if body is None:
+            if self._msgs.first(0x04) is not None:
+                raise Unsupported("old-style fill value message (0x04) on a dataset with unwritten storage")
+            return out
+        ver = body[0]
+        if ver in (1, 2):
+            defined = ver == 1 or body[3]
+            if not defined or len(body) < 8:
+                return out
+            size, p = int.from_bytes(body[4:8], "little"), 8
+        elif ver == 3:
+            if not body[1] & 0x20:
+                return out
+            size, p = int.from_bytes(body[2:6], "little"), 6
+        else:
+            raise Unsupported("fill value message version %d" % ver)
+        if size == 0:
+            return out
+        if size != self.dtype.itemsize:
+            raise Unsupported("fill value of %d bytes for a %d-byte element type" % (size, self.dtype.itemsize))
+        out[...] = np.frombuffer(body, dtype=self.dtype, count=1, offset=p)[0]
+        return out
+
     def _read_all(self) -> np.ndarray:
         f, b, d = self._f, self._f._b, self._f._b.d
         if self._type.vlen_str:
@@ -339,6 +379,8 @@ class Dataset(_Object):
                 size = int.from_bytes(body[p:p + 4], "little")
                 return np.frombuffer(body, dtype=self.dtype, count=n, offset=p + 4).reshape(self.shape).copy()
             if cls == 1:
+                if b.undefined(addr):
+                    return self._filled()                      # never written
                 return np.frombuffer(d, dtype=self.dtype, count=n, offset=addr).reshape(self.shape).copy()
             chunk_dims, btree = dims, addr                     # rank counts the element-size dimension, dims hold the chunk shape
             p_es = p
@@ -352,7 +394,7 @@ class Dataset(_Object):
             if cls == 1:
                 addr = int.from_bytes(body[2:2 + b.so], "little")
                 if b.undefined(addr):
-                    return np.zeros(self.shape, self.dtype)    # never written: fill value
+                    return self._filled()                      # never written
                 return np.frombuffer(d, dtype=self.dtype, count=n, offset=addr).reshape(self.shape).copy()
             if cls != 2:
                 raise Unsupported("data layout class %d" % cls)
@@ -366,7 +408,7 @@ class Dataset(_Object):
             raise Unsupported("data layout message version %d" % ver)
         # ---- chunked: walk the version-1 B-tree of chunks
         cshape = tuple(chunk_dims[:-1])
-        out = np.zeros(self.shape, self.dtype)
+        out = self._filled()                           # chunks absent from the index keep the fill value
         if b.undefined(btree):
             return out
         filters = self._filters()

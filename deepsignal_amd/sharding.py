@@ -141,7 +141,6 @@ class OrderedRowGather:
         return self.total_sites, self.total_errors
 
     def _run(self):
-        import warnings
         import torch
         try:
             dist, world, rank = self.dist, self.world, self.rank
@@ -152,7 +151,7 @@ class OrderedRowGather:
             # staging reused across rounds (grown when a round is bigger): on a GPU the rows go host -> PINNED buffer ->
             # device buffer -> RCCL, and on rank 0 back through one pinned buffer; one host sync per round for the lengths
             cap = 0
-            pin = dbuf = gbuf = pin_out = None
+            pin = pin_np = dbuf = gbuf = pin_out = None
             lens_dev = torch.zeros(world, dtype=torch.int64, device=dev)
             for _ in range(self.nrounds):
                 data = self._q.get()
@@ -165,14 +164,16 @@ class OrderedRowGather:
                 if nmax > cap:
                     cap = max(nmax, 2 * cap, 1 << 20)
                     pin = torch.empty(cap, dtype=torch.uint8, pin_memory=on_gpu)
+                    pin_np = pin.numpy()
                     dbuf = torch.empty(cap, dtype=torch.uint8, device=dev) if on_gpu else pin
                     if rank == 0:
                         gbuf = torch.empty(world * cap, dtype=torch.uint8, device=dev)
                         pin_out = torch.empty(world * cap, dtype=torch.uint8, pin_memory=on_gpu)
                 if data:
-                    with warnings.catch_warnings():       # bytes are immutable: a read-only view is all that is needed (one copy)
-                        warnings.simplefilter("ignore")
-                        pin[:len(data)] = torch.frombuffer(data, dtype=torch.uint8)
+                    # one copy, bytes -> pinned buffer, through numpy views (torch.frombuffer on immutable bytes warns, and
+                    # silencing it with warnings.catch_warnings() in this thread would swap the process-global filter list
+                    # under the main thread's feet)
+                    pin_np[:len(data)] = np.frombuffer(data, dtype=np.uint8)
                 if on_gpu:
                     dbuf[:nmax].copy_(pin[:nmax], non_blocking=True)
                 gl = [gbuf[r * nmax:(r + 1) * nmax] for r in range(world)] if rank == 0 else None

@@ -1,3 +1,4 @@
+#!/bin/bash
 for r in 1 2; do
 for n in base new; do
   if [ $n = base ]; then export DS_HIP_LIBRARY=$PWD/build/variants/lib_base.so; else unset DS_HIP_LIBRARY; fi
