@@ -2,7 +2,8 @@
 """Generate the TensorFlow-tied pin of the forward arithmetic ("parity unpinned").
 
 CANNOT RUN IN THE BUILD CONTAINER OR ON THE GPU BOX: it needs TensorFlow 1.8 - 1.13 (README.md:28 of the reference; needs
-`tf.contrib`) and the reference checkout. Anyone who has such an environment runs it ONCE:
+`tf.contrib`) and the reference checkout. Anyone who has such an environment runs it ONCE (tests/golden/README.md has the
+Docker one-liner and the expected output):
 
     python tests/golden/make_tf_golden.py --reference /path/to/deepsignal [--out tests/golden/tf]
 
@@ -18,7 +19,9 @@ What it does (the reference's own code path, nothing of this repository's arithm
   4. RESTORES it into a fresh session (call_modifications.py:208-212) and runs
      sess.run([model.activation_logits, model.prediction], feed_dict) with the feed of call_modifications.py:168-178
      (training False, keep_prob 1.0) on the inputs of tests/golden/forward_golden.npz, in one batch and in batches of 5;
-  5. writes <out>/tf_golden.npz: inputs, TensorFlow's activation_logits / prediction, the weight seed and a CRC-32 of
+  5. runs the same graph on the trained-regime STRESS set (weights.stress_weights + the committed head and inputs of
+     tests/golden/stress_golden.npz) and records TensorFlow's outputs there too;
+  6. writes <out>/tf_golden.npz: inputs, TensorFlow's activation_logits / prediction, the weight seed and a CRC-32 of
      every weight tensor as assigned (so a consumer regenerating the weights from the seed can tell whether it got the
      same numbers), TensorFlow's version string.
 
@@ -101,7 +104,30 @@ def main():
     pred5 = np.concatenate([p[1] for p in parts])
     assert np.array_equal(act, act_direct) and np.array_equal(pred, pred_direct), "restore changed the outputs"
 
+    # ---- the trained-regime stress set (tests/golden/stress_golden.npz: saturating LSTM gates, hot BN channels, logits spanning
+    # +-10, both labels): same graph, weights assigned in place, no checkpoint -- so the TensorFlow pin covers the regime the
+    # benign random-init weights never visit
+    sg = np.load(os.path.join(HERE, "stress_golden.npz"))
+    ws = W.stress_weights(int(sg["stress_seed"]), head=sg["stress_head"])
+    W.check_weights(ws)
+    sfeats = {k: sg["in_" + k] for k in ("kmer", "means", "stds", "sanums", "signals", "labels")}
+    tf.reset_default_graph()
+    model = Model(base_num=17, signal_num=360, class_num=2)
+    gvars = {v.op.name: v for v in tf.global_variables()}
+    with tf.Session() as sess:
+        sess.run(tf.global_variables_initializer())
+        for name, _ in spec.tensor_table():
+            gvars[name].load(ws[name], sess)
+        ns = sfeats["kmer"].shape[0]
+        s_act, s_pred = sess.run([model.activation_logits, model.prediction], feed_dict={
+            model.base_int: sfeats["kmer"], model.means: sfeats["means"], model.stds: sfeats["stds"], model.sanums: sfeats["sanums"],
+            model.signals: sfeats["signals"], model.labels: sfeats["labels"], model.lr: 0.001, model.training: False,
+            model.keep_prob: 1.0})
+    print("stress set: %d sites, label-1 share %.2f, max |act - float64 oracle (committed)| = %.3g"
+          % (ns, float(np.mean(s_pred)), float(np.abs(s_act - sg["act"]).max())))
+
     out = {"tf_version": tf.__version__, "weight_seed": seed, "lstm_bias_std": bias_std,
+           "stress_act": s_act.astype(np.float32), "stress_pred": s_pred.astype(np.int64), "stress_seed": int(sg["stress_seed"]),
            "act": act.astype(np.float32), "pred": pred.astype(np.int64), "act_batches_of_5": act5.astype(np.float32),
            "pred_batches_of_5": pred5.astype(np.int64),
            "weight_names": np.array([name for name, _ in spec.tensor_table()]),

@@ -52,3 +52,26 @@ def test_checkpoint_importer_reads_the_file_tensorflow_wrote():
         assert got[name].shape == w[name].shape and np.array_equal(got[name], w[name]), name
     _, entries = tf_checkpoint.read_index(prefix)
     assert set(str(v) for v in g["checkpoint_variables"]) <= set(entries), "variables TensorFlow saved that the index reader did not list"
+
+
+def test_oracle_matches_tensorflow_on_the_stress_set():
+    """Row 8c in the regime a trained model lives in (saturating LSTM gates, logits spanning +-10, both labels): TensorFlow's
+    fp32 outputs within 1e-4 of the float64 oracle (fp32 evaluations of this set differ from float64 by 3 - 5e-5 whatever
+    the summation order: tests/test_gpu_stress.py), labels equal wherever the margin exceeds 1e-3, both labels present."""
+    import os
+    from oracle import oracle
+    from deepsignal_amd import weights as W
+    g = fx.golden()
+    if "stress_act" not in g.files:
+        import pytest
+        pytest.skip("tf_golden.npz predates the stress set: re-run tests/golden/make_tf_golden.py")
+    sg = np.load(os.path.join(fx.ROOT, "tests", "golden", "stress_golden.npz"))
+    assert int(g["stress_seed"]) == int(sg["stress_seed"])
+    w = W.stress_weights(int(sg["stress_seed"]), head=sg["stress_head"])
+    feats = {k: sg["in_" + k] for k in ("kmer", "means", "stds", "sanums", "signals")}
+    a64, p64 = oracle.forward(w, feats, "f64")
+    tf_act, tf_pred = g["stress_act"], g["stress_pred"]
+    assert np.abs(a64 - tf_act).max() <= 1e-4
+    decided = np.abs(a64[:, 1] - a64[:, 0]) > 1e-3
+    assert (p64[decided] == tf_pred[decided]).all()
+    assert 0.2 < float(np.mean(tf_pred)) < 0.8
