@@ -254,7 +254,7 @@ def forward_blocking(eng, feats, batch):
     return out
 
 
-def configs2_leg(Engine, w, torch, dev, local_rank):
+def configs2_leg(Engine, w, torch, dev, local_rank, host_path=True):
     """BASELINE configs[2] inside the driver-run line: bf16 conv + FC with fp32 BiLSTM accumulate, batch 4096 (`bf16_all`: bf16
     operands everywhere, fp32 accumulate / gates / cell state; `bf16`: fp32 BiLSTM operands as well), resident inputs, 3
     windows of 30 steps, plus the stand-alone time of the fused inception kernel -> the conv path against the HBM roofline
@@ -311,6 +311,9 @@ def configs2_leg(Engine, w, torch, dev, local_rank):
                     out["conv_path_hbm"].update({"traffic_per_step": 3 * t["traffic"], "traffic_source": t["traffic_source"],
                                                  "hbm_side_frac": round(3 * t["traffic"] / (c_ms * 1e-3) / 8e12, 4)})
         assert bool(torch.isfinite(act).all())
+        if prec == "bf16_all" and host_path:
+            # feature TSV -> result TSV through call_mods with this engine: the row pipeline fills the engine's 4096-site batches
+            r["e2e_tsv"] = e2e_tsv(e, feats, 327680, B)
         out[prec] = r
         e.close()
     out["tolerance_vs_fp32"] = configs2_tolerance(Engine, w, local_rank, feats, keys)
@@ -394,8 +397,9 @@ def e2e_tsv(eng, feats, rows, batch):
         shutil.rmtree(tmpdir, ignore_errors=True)
     return {"value": round(rows / dt, 1), "unit": "sites/s", "rows": rows, "input_MB": round(size / 1e6, 1),
             "host_cores": effective_cores(),
-            "path": "call_mods(feature TSV -> result TSV): native reader + ds_submit / ds_wait + native formatter, "
-                    "20 sites per read, f5_batch_num 50"}
+            "engine_batch": int(getattr(eng, "max_batch", batch)),
+            "path": "call_mods(feature TSV -> result TSV): native reader + ds_submit / ds_wait (whole engine batches filled across "
+                    "queue items) + native formatter, 20 sites per read, f5_batch_num 50"}
 
 
 def main():
@@ -703,7 +707,9 @@ def main():
         engf.close()
     eng.close()
     if solo and not args.no_configs2:
-        result["configs2_bf16_batch4096"] = configs2_leg(Engine, w, torch, dev, local_rank)
+        result["configs2_bf16_batch4096"] = configs2_leg(Engine, w, torch, dev, local_rank, host_path=not args.no_host_path)
+        if "e2e_tsv" in result["configs2_bf16_batch4096"].get("bf16_all", {}):
+            result["e2e_tsv_bf16_all"] = dict(result["configs2_bf16_batch4096"]["bf16_all"]["e2e_tsv"], engine="bf16_all, max_batch 4096 (`deepsignal call_mods --precision bf16_all`)")
     if solo and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(w)
     if dist is not None:

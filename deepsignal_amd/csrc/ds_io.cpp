@@ -107,6 +107,10 @@ struct ds_tsv {
     std::vector<char> info;
     std::vector<int64_t> info_off;
     std::vector<std::pair<const char*, const char*>> lines;
+    // lines located ahead of the consumer by the parallel newline scan (non-blank, '\r'-trimmed, file order): [pend_head, size)
+    // are not handed out yet; `scanned` = first byte behind the last located line (always a line start, or `limit`)
+    std::vector<std::pair<const char*, const char*>> pend;
+    size_t pend_head = 0, scanned = 0, scan_bytes = 2u << 20;
     ds_team* team = nullptr;   // nthreads - 1 helpers, started with the first item that needs them
 };
 
@@ -198,8 +202,10 @@ int base_code(char c)
     }
 }
 
-// one row -> slot i of the batch arrays; returns false on a malformed row
-bool parse_row(ds_tsv* t, size_t i, const char* b, const char* e, int64_t* info_len)
+struct RowDest { int32_t* kmer; float* means; float* stds; float* lens; float* signals; int32_t* labels; };
+
+// one row -> slot i of the destination arrays; returns false on a malformed row
+bool parse_row(const ds_tsv* t, const RowDest& d, size_t i, const char* b, const char* e, int64_t* info_len)
 {
     // col[c] = start of column c; col[12] = one past the tab (or line end) that closes column 11. Columns beyond the
     // 12th are ignored, as the reference reader ignores words[12:] (call_modifications.py:47-57).
@@ -221,19 +227,19 @@ bool parse_row(ds_tsv* t, size_t i, const char* b, const char* e, int64_t* info_
     for (int k = 0; k < K; ++k) {
         const int code = base_code(cb(6)[k]);
         if (code < 0) return false;
-        t->kmer[i * K + k] = code;
+        d.kmer[i * K + k] = code;
     }
     const char* const safe = t->size >= 17 ? t->data + t->size - 17 : nullptr;      // a token may be looked at 17 bytes at a time up to here
-    if (!parse_list(cb(7), ce(7), K, &t->means[i * K], false, safe)) return false;
-    if (!parse_list(cb(8), ce(8), K, &t->stds[i * K], false, safe)) return false;
-    if (!parse_list(cb(9), ce(9), K, &t->lens[i * K], true)) return false;
-    if (!parse_list(cb(10), ce(10), S, &t->signals[i * S], false, safe)) return false;
+    if (!parse_list(cb(7), ce(7), K, &d.means[i * K], false, safe)) return false;
+    if (!parse_list(cb(8), ce(8), K, &d.stds[i * K], false, safe)) return false;
+    if (!parse_list(cb(9), ce(9), K, &d.lens[i * K], true)) return false;
+    if (!parse_list(cb(10), ce(10), S, &d.signals[i * S], false, safe)) return false;
     const char* le = ce(11);
     while (le > cb(11) && (le[-1] == '\r' || le[-1] == ' ')) --le;
     int lab = 0;
     auto r = std::from_chars(cb(11), le, lab);
     if (r.ec != std::errc() || r.ptr != le) return false;
-    t->labels[i] = lab;
+    d.labels[i] = lab;
     *info_len = ce(5) - b;       // columns 0..5 joined by tabs, verbatim
     return true;
 }
@@ -317,6 +323,78 @@ std::string row_where(const ds_tsv* t, int64_t index0, const char* line)
 }
 }  // namespace
 
+namespace {
+// [begin, end) of column 5 (the read id) of the line starting at p; false when the line has fewer than 5 columns
+bool line_read_id(const char* p, const char* le, const char** ib, const char** ie)
+{
+    const char* c = p;
+    int tabs = 0;
+    while (tabs < 4 && c < le) { c = find_tab(c, le); if (c < le) { ++c; ++tabs; } }
+    if (tabs < 4) return false;
+    *ib = c; *ie = find_tab(c, le);
+    return true;
+}
+
+// Locate the lines of the next window of the file ON THE WHOLE TEAM and append them to t->pend. A row is ~3.8 KB of text
+// and the calling thread used to walk all of it (memchr for the newline, and -- first touch of a freshly mapped file --
+// one page fault per row): 0.6 us per row that no number of parser threads could shrink, against 4 us / nthreads for the
+// parsing itself (tools/e2e_profile.py: 1.18 M rows/s on 16 threads). Now the window is cut into one chunk per thread, every
+// thread finds the newlines of its chunk (and takes its faults), and the caller only strings the offsets together.
+void scan_lines(ds_tsv* t)
+{
+    if (t->pend_head) {                         // drop what has been handed out
+        t->pend.erase(t->pend.begin(), t->pend.begin() + (ptrdiff_t)t->pend_head);
+        t->pend_head = 0;
+    }
+    const char* data = t->data;
+    size_t target = t->scan_bytes;
+    for (;;) {
+        const size_t a = t->scanned, e0 = std::min(t->limit, a + target);
+        const int nt = (int)std::max<size_t>(1, std::min<size_t>((size_t)t->nthreads, (e0 - a) >> 18));      // >= 256 KB per thread
+        std::vector<std::vector<size_t>> found((size_t)nt);
+        std::atomic<int> next(0);
+        auto work = [&]() {
+            for (;;) {
+                const int c = next.fetch_add(1);
+                if (c >= nt) break;
+                const size_t b0 = a + (e0 - a) * (size_t)c / (size_t)nt, b1 = a + (e0 - a) * (size_t)(c + 1) / (size_t)nt;
+                std::vector<size_t>& v = found[(size_t)c];
+                v.reserve((b1 - b0) / 2048 + 16);
+                const char* p = data + b0;
+                const char* const e = data + b1;
+                while (p < e) {
+                    const char* nl = (const char*)memchr(p, '\n', (size_t)(e - p));
+                    if (!nl) break;
+                    v.push_back((size_t)(nl - data));
+                    p = nl + 1;
+                }
+            }
+        };
+        if (nt <= 1) work();
+        else {
+            if (!t->team) t->team = new ds_team(t->nthreads - 1);
+            const std::function<void()> f = work;
+            t->team->run(nt - 1, f);
+        }
+        size_t prev = a;
+        auto add = [&](size_t b, size_t e) {
+            while (e > b && data[e - 1] == '\r') --e;
+            if (e > b) t->pend.emplace_back(data + b, data + e);        // blank lines are skipped
+        };
+        bool any = false;
+        for (const auto& v : found)
+            for (size_t nl : v) { add(prev, nl); prev = nl + 1; any = true; }
+        if (e0 == t->limit) {                   // the last line may lack its newline
+            if (prev < e0) add(prev, e0);
+            t->scanned = t->limit;
+            return;
+        }
+        if (any) { t->scanned = prev; return; }
+        target *= 2;                            // one line longer than the window: look further
+    }
+}
+}  // namespace
+
 extern "C" {
 
 int ds_tsv_open(const char* path, int32_t kmer_len, int32_t signal_len, int32_t nthreads, ds_tsv** out)
@@ -353,46 +431,58 @@ void ds_tsv_close(ds_tsv* t)
 
 const char* ds_tsv_error(const ds_tsv* t) { return t ? t->err.c_str() : "null reader"; }
 
-// Next queue item: all rows of the next `max_reads` reads (a read = maximal run of consecutive rows with the
-// same column 5). Returns the number of sites, 0 at end of file, negative on a malformed row.
-int64_t ds_tsv_next(ds_tsv* t, int32_t max_reads)
+// Locate (not parse) the rows of the next queue item: all rows of the next `max_reads` reads (a read = maximal run of
+// consecutive rows with the same column 5). Returns their number (0 at end of file, negative on a row with fewer than five
+// columns); ds_tsv_parse_into() parses them.
+int64_t ds_tsv_locate(ds_tsv* t, int32_t max_reads)
 {
     if (!t || max_reads < 1) return DS_ERR_INVALID;
     t->lines.clear();
-    const char* end = t->data + t->limit;
-    const char* p = t->data + std::min(t->pos, t->limit);
+    if (t->scanned < t->pos || t->pend_head > t->pend.size()) { t->scanned = t->pos; t->pend.clear(); t->pend_head = 0; }
     const char* prev_id = nullptr;
     size_t prev_len = 0;
     int reads = 0;
-    while (p && p < end) {
-        const char* nl = (const char*)memchr(p, '\n', (size_t)(end - p));
-        const char* le = nl ? nl : end;
-        const char* ltrim = le;
-        while (ltrim > p && (ltrim[-1] == '\r')) --ltrim;
-        if (ltrim == p) { p = nl ? nl + 1 : end; continue; }       // blank line
-        // read id = column 5 (0-based 4)
-        const char* c = p;
-        int tabs = 0;
-        while (tabs < 4 && c < ltrim) { c = find_tab(c, ltrim); if (c < ltrim) { ++c; ++tabs; } }
-        if (tabs < 4) { t->err = row_where(t, t->line_no + (int64_t)t->lines.size(), p) + ": fewer than 5 columns"; return DS_ERR_IO; }
-        const char* ide = find_tab(c, ltrim);
-        const size_t idl = (size_t)(ide - c);
-        if (!prev_id || idl != prev_len || memcmp(c, prev_id, idl) != 0) {
-            if (prev_id) {
-                ++reads;
-                if (reads % max_reads == 0) break;                // this row starts the next item
+    bool full = false;
+    const size_t item_begin = t->pend_head < t->pend.size() ? (size_t)(t->pend[t->pend_head].first - t->data) : t->scanned;
+    for (;;) {
+        // group the located lines into reads (a few bytes per row: the newline search itself ran on the whole team)
+        while (t->pend_head < t->pend.size()) {
+            const char* p = t->pend[t->pend_head].first;
+            const char* ltrim = t->pend[t->pend_head].second;
+            const char *c, *ide;
+            if (!line_read_id(p, ltrim, &c, &ide)) {
+                t->err = row_where(t, t->line_no + (int64_t)t->lines.size(), p) + ": fewer than 5 columns";
+                return DS_ERR_IO;
             }
-            prev_id = c; prev_len = idl;
+            const size_t idl = (size_t)(ide - c);
+            if (!prev_id || idl != prev_len || memcmp(c, prev_id, idl) != 0) {
+                if (prev_id) {
+                    ++reads;
+                    if (reads % max_reads == 0) { full = true; break; }     // this row starts the next item
+                }
+                prev_id = c; prev_len = idl;
+            }
+            t->lines.emplace_back(p, ltrim);
+            ++t->pend_head;
         }
-        t->lines.emplace_back(p, ltrim);
-        p = nl ? nl + 1 : end;
+        if (full || t->scanned >= t->limit) break;
+        scan_lines(t);
     }
-    t->pos = p ? (size_t)(p - t->data) : 0;
+    t->pos = t->pend_head < t->pend.size() ? (size_t)(t->pend[t->pend_head].first - t->data) : t->scanned;
+    if (t->pos > item_begin) t->scan_bytes = std::max<size_t>(1u << 20, (t->pos - item_begin) + (t->pos - item_begin) / 4);
+    return (int64_t)t->lines.size();
+}
+
+// Parse the rows ds_tsv_locate() found into the CALLER's arrays (kmer int32[n,kmer_len], means / stds / lens
+// float[n,kmer_len], signals float[n,signal_len], labels int32[n]) on the team; the six sampleinfo columns go to the
+// reader's own buffer (ds_tsv_info / ds_tsv_info_offsets). Returns n, or a negative code on a malformed row.
+int64_t ds_tsv_parse_into(ds_tsv* t, int32_t* kmer, float* means, float* stds, float* lens, float* signals, int32_t* labels)
+{
+    if (!t) return DS_ERR_INVALID;
     const size_t n = t->lines.size();
     if (n == 0) return 0;
-    const int K = t->kmer_len, S = t->signal_len;
-    t->kmer.resize(n * K); t->means.resize(n * K); t->stds.resize(n * K); t->lens.resize(n * K);
-    t->signals.resize(n * S); t->labels.resize(n);
+    if (!kmer || !means || !stds || !lens || !signals || !labels) return DS_ERR_INVALID;
+    const RowDest dest{kmer, means, stds, lens, signals, labels};
     std::vector<int64_t> ilen(n);
     std::atomic<size_t> next(0);
     std::atomic<int64_t> bad(-1);
@@ -402,7 +492,7 @@ int64_t ds_tsv_next(ds_tsv* t, int32_t max_reads)
             if (i0 >= n) break;
             const size_t i1 = std::min(n, i0 + 64);
             for (size_t i = i0; i < i1; ++i)
-                if (!parse_row(t, i, t->lines[i].first, t->lines[i].second, &ilen[i])) {
+                if (!parse_row(t, dest, i, t->lines[i].first, t->lines[i].second, &ilen[i])) {
                     int64_t exp = -1;
                     bad.compare_exchange_strong(exp, (int64_t)i);
                 }
@@ -426,23 +516,24 @@ int64_t ds_tsv_next(ds_tsv* t, int32_t max_reads)
     t->info.resize((size_t)tot);
     for (size_t i = 0; i < n; ++i) memcpy(t->info.data() + t->info_off[i], t->lines[i].first, (size_t)ilen[i]);
     t->line_no += (int64_t)n;
+    t->lines.clear();
     return (int64_t)n;
 }
 
-int64_t ds_tsv_size(const ds_tsv* t) { return t ? (int64_t)t->size : DS_ERR_INVALID; }
-
-namespace {
-// [begin, end) of column 5 (the read id) of the line starting at p; false when the line has fewer than 5 columns
-bool line_read_id(const char* p, const char* le, const char** ib, const char** ie)
+// Next queue item: all rows of the next `max_reads` reads (a read = maximal run of consecutive rows with the
+// same column 5), parsed into the reader's own arrays (the ds_tsv_kmer ... accessors). Returns the number of sites, 0 at
+// end of file, negative on a malformed row.
+int64_t ds_tsv_next(ds_tsv* t, int32_t max_reads)
 {
-    const char* c = p;
-    int tabs = 0;
-    while (tabs < 4 && c < le) { c = find_tab(c, le); if (c < le) { ++c; ++tabs; } }
-    if (tabs < 4) return false;
-    *ib = c; *ie = find_tab(c, le);
-    return true;
+    const int64_t n = ds_tsv_locate(t, max_reads);
+    if (n <= 0) return n;
+    const size_t K = (size_t)t->kmer_len, S = (size_t)t->signal_len, m = (size_t)n;
+    t->kmer.resize(m * K); t->means.resize(m * K); t->stds.resize(m * K); t->lens.resize(m * K);
+    t->signals.resize(m * S); t->labels.resize(m);
+    return ds_tsv_parse_into(t, t->kmer.data(), t->means.data(), t->stds.data(), t->lens.data(), t->signals.data(), t->labels.data());
 }
-}  // namespace
+
+int64_t ds_tsv_size(const ds_tsv* t) { return t ? (int64_t)t->size : DS_ERR_INVALID; }
 
 // First read boundary at or after byte `pos`: the start of the first line that begins at or after `pos` and whose
 // read id (column 5) differs from the line before it -- so [align(a), align(b)) always holds whole reads, and the
@@ -490,6 +581,7 @@ int ds_tsv_set_range(ds_tsv* t, int64_t begin, int64_t end)
     if (!t || begin < 0 || end < begin || (size_t)end > t->size) return DS_ERR_INVALID;
     t->pos = (size_t)begin;
     t->limit = (size_t)end;
+    t->scanned = t->pos; t->pend.clear(); t->pend_head = 0;
     t->range_begin = (size_t)begin;
     t->line_no = 0;
     t->err.clear();

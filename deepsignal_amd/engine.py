@@ -32,7 +32,7 @@ EXPORTED_SYMBOLS = (
     # scope row f1 (host I/O)
     "ds_tsv_open", "ds_tsv_close", "ds_tsv_error", "ds_tsv_next", "ds_tsv_kmer", "ds_tsv_means", "ds_tsv_stds",
     "ds_tsv_lens", "ds_tsv_signals", "ds_tsv_labels", "ds_tsv_info", "ds_tsv_info_offsets", "ds_format_rows",
-    "ds_tsv_size", "ds_tsv_align", "ds_tsv_set_range",
+    "ds_tsv_size", "ds_tsv_align", "ds_tsv_set_range", "ds_tsv_locate", "ds_tsv_parse_into",
     # scope row f3 (TF checkpoint import)
     "ds_crc32c",
 )

@@ -65,6 +65,10 @@ def _bind():
     lib.ds_tsv_error.restype = ctypes.c_char_p
     lib.ds_tsv_next.argtypes = [vp, i32]
     lib.ds_tsv_next.restype = i64
+    lib.ds_tsv_locate.argtypes = [vp, i32]
+    lib.ds_tsv_locate.restype = i64
+    lib.ds_tsv_parse_into.argtypes = [vp, vp, vp, vp, vp, vp, vp]
+    lib.ds_tsv_parse_into.restype = i64
     for name in ("kmer", "means", "stds", "lens", "signals", "labels", "info", "info_offsets"):
         f = getattr(lib, "ds_tsv_" + name)
         f.argtypes = [vp]
@@ -135,17 +139,21 @@ class FeatureReader:
     def items(self, f5_batch_num: int = 50) -> Iterator[FeatureItem]:
         lib, h, K, S = self._lib, self._h, self.kmer_len, self.signal_len
         while True:
-            n = lib.ds_tsv_next(h, f5_batch_num)
+            # locate the item's rows, then parse them straight into arrays this item owns (no copy out of the reader)
+            n = lib.ds_tsv_locate(h, f5_batch_num)
             if n < 0:
                 raise ValueError("feature file: %s" % lib.ds_tsv_error(h).decode())
             if n == 0:
                 return
+            kmer, labels = np.empty((n, K), np.int32), np.empty((n,), np.int32)
+            means, stds, lens = (np.empty((n, K), np.float32) for _ in range(3))
+            signals = np.empty((n, S), np.float32)
+            got = lib.ds_tsv_parse_into(h, kmer.ctypes.data, means.ctypes.data, stds.ctypes.data, lens.ctypes.data,
+                                        signals.ctypes.data, labels.ctypes.data)
+            if got != n:
+                raise ValueError("feature file: %s" % lib.ds_tsv_error(h).decode())
             off = _view(lib.ds_tsv_info_offsets(h), np.int64, (n + 1,))
-            yield FeatureItem(
-                _view(lib.ds_tsv_info(h), np.uint8, (int(off[-1]),)), off,
-                _view(lib.ds_tsv_kmer(h), np.int32, (n, K)), _view(lib.ds_tsv_means(h), np.float32, (n, K)),
-                _view(lib.ds_tsv_stds(h), np.float32, (n, K)), _view(lib.ds_tsv_lens(h), np.float32, (n, K)),
-                _view(lib.ds_tsv_signals(h), np.float32, (n, S)), _view(lib.ds_tsv_labels(h), np.int32, (n,)))
+            yield FeatureItem(_view(lib.ds_tsv_info(h), np.uint8, (int(off[-1]),)), off, kmer, means, stds, lens, signals, labels)
 
 
 def format_rows(item_info: np.ndarray, info_off: np.ndarray, act: np.ndarray, pred: np.ndarray,

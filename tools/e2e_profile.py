@@ -15,7 +15,7 @@ tails = ["\t".join(["".join(code2base_dna[int(c)] for c in feats["kmer"][i]), ",
 with open(path, "w") as f:
     for i in range(rows):
         f.write("chr1\t%d\t+\t%d\tread_%06d\tt\t%s\n" % (1000 + i, i, i // 20, tails[i % 4096]))
-eng = Engine(max_batch=512, slots=int(os.environ.get("E2E_SLOTS", "0")), precision=os.environ.get("E2E_PRECISION", "fp32")); eng.load_weights(W.random_weights(seed=1))
+eng = Engine(max_batch=int(os.environ.get("E2E_BATCH", "512")), slots=int(os.environ.get("E2E_SLOTS", "0")), precision=os.environ.get("E2E_PRECISION", "fp32")); eng.load_weights(W.random_weights(seed=1))
 args = (path, "x", os.path.join(tmp, "out.tsv"), 17, 360, 512, 0.001, 2, 1, True, True, True, True, None)
 cm.call_mods(*args, engine=eng)
 t0 = time.perf_counter(); cm.call_mods(*args, engine=eng); dt = time.perf_counter() - t0
