@@ -1167,8 +1167,20 @@ __global__ __launch_bounds__(256, MTW * NTW >= 4 ? 2 : 3) void lstm_cell_bf16_ke
 //     56 co-resident workgroups (the grid is min(strands, 3 per CU)) and AT MOST ONE such launch in flight per GPU: the
 //     engine issues them on one stream shared by all its slots. Every wait is bounded (timeout -> abort flag -> every
 //     workgroup leaves, the host reports the error).
-// Same arithmetic, same K order per element as lstm_cell_bf16_kernel: the bits of the diagonal form.
+// Same arithmetic, same K order per element as lstm_cell_bf16_kernel: the bits of the diagonal form (tests/test_gpu_bf16.py).
 // Roofline: operand delivery (L2 -> LDS, 64 B/clk per CU) ~ MFMA at three workgroups per CU; algorithmic FLOPs as the cells.
+//
+// MEASURED (round 4, MI355X, 4096 sites per forward, stand-alone): 899 us per forward against 688 us for the 19 diagonal
+// launches -- NOT the default (DS_LSTM_TILING_PERSISTENT selects it). Two design iterations, VERDICT r03's kill criterion:
+//   1. this form (sc1 hand-off, every request waited for): 899 us, 2.69 M sites/s against 3.24 M;
+//   2. plain h loads with counted waits, as the diagonal kernel pipelines them: 831 us -- and WRONG (a few stale m-tiles per
+//      forward: a plain load of another CU's freshly written line is stale without an agent-scope acquire, exactly as
+//      MI355X_MICROARCH.md warns), so its time is an upper bound on what an acquire-fence form could reach.
+// Why it loses: a strand's steps are a dependency CHAIN -- poll, accumulator init, first operands (which the sc1 stores have
+// just pushed out of every L2), loop, gates, drain, counter -- ~16 us of latency per step for ~7 us of loop, and at 198 VGPRs
+// only two workgroups share a CU to hide it, where the diagonal form runs three INDEPENDENT tiles per CU. 1536 strands / 512
+// resident x 17 steps x 16 us = 830 us. What would change the picture is a loader-wave / compute-wave split (exact
+// vmcnt(0) per loader wave gives back the two-stage prefetch) at three workgroups per CU: a third design, not attempted.
 __device__ __forceinline__ void glds16s_sc1(const void* gbase, unsigned lane_off, unsigned lds_dst)
 {
     unsigned keep;
@@ -1321,8 +1333,11 @@ __global__ __launch_bounds__(256, 2) void lstm_persistent_bf16_kernel(const Lstm
             const float* const fb0 = ring + (FRA + nj * NTW) * 256 + lane4;
             auto stage = [&](int st, auto slot_c) __attribute__((always_inline)) {
                 constexpr int SLOT = decltype(slot_c)::value;
-                if (st + 1 < nstages) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                // EVERY request is waited for, not "all but the next stage's": sc1 LDS-DMA requests do not retire in issue order
+                // -- neither with respect to plain ones nor among themselves -- so a counted vmcnt let a stage through before
+                // its h fragment had landed (whole m-tiles wrong from some step on, a few per forward; measured). The price is
+                // a prefetch distance of one stage instead of two.
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
                 if (st + 2 < nstages) request(st + 2, (SLOT + 2) % 3);
 #pragma unroll
