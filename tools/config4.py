@@ -23,7 +23,25 @@ def pool_features(pool_sites, rank=0):
     return synth.synthetic_features(pool_sites, seed=synth.FEATURE_SEED + rank)
 
 
-def run_shard(sites, batch=512, precision="fp32", weights=None, pool_sites=4096, dist=None, rank=0, local=0, world=1):
+def gpu_telemetry():
+    """Clocks / temperature / power of GPU 0 as rocm-smi reports them (an ordinary user may read them): sampled before, in the
+    middle of and after the sustained run, so that a reader can tell a throttled run from a quiet one."""
+    import subprocess
+    try:
+        out = subprocess.run(["rocm-smi", "-d", "0", "--showclocks", "--showtemp", "--showpower", "--json"], capture_output=True,
+                             text=True, timeout=20).stdout
+        card = next(iter(json.loads(out).values()))
+        keep = {}
+        for k, v in card.items():
+            kl = k.lower()
+            if any(w in kl for w in ("sclk", "mclk", "fclk", "temperature", "power")):
+                keep[k] = v
+        return keep
+    except Exception as exc:       # rocm-smi absent or unreadable: the run itself does not depend on it
+        return {"unavailable": str(exc)[:80]}
+
+
+def run_shard(sites, batch=512, precision="fp32", weights=None, pool_sites=4096, dist=None, rank=0, local=0, world=1, telemetry=False):
     """This rank's reads of a `sites`-site job through the resident-input boundary, then the one result gather.
     Returns (record, gathered act, gathered pred, my_reads); the gathered tensors are on rank 0's device (None elsewhere)."""
     import torch
@@ -54,11 +72,17 @@ def run_shard(sites, batch=512, precision="fp32", weights=None, pool_sites=4096,
     eng.sync(); torch.cuda.synchronize()
     if dist is not None:
         dist.barrier(); torch.cuda.synchronize()
+    tele = [gpu_telemetry()] if telemetry else None
     t0 = time.perf_counter()
     for i in range(nsteps):
         step(i)
+        if telemetry and i == nsteps // 2:
+            # (a ~10 ms host call in the middle of thousands of steps: the slots keep the GPU busy meanwhile)
+            tele.append(gpu_telemetry())
     eng.sync()
     t_compute = time.perf_counter() - t0
+    if telemetry:
+        tele.append(gpu_telemetry())
     # global site index of my j-th site: read my_reads[j // 20], position j % 20
     def index_of_rank(r, cnt):       # the sharding rule: rank r owns reads r, r + world, ...; 20 sites per read
         reads = torch.arange(r, r + world * (cnt // SITES_PER_READ), world, dtype=torch.int64, device=dev)
@@ -78,6 +102,8 @@ def run_shard(sites, batch=512, precision="fp32", weights=None, pool_sites=4096,
     rec = {"config": "configs[3]: per-read shard of %d synthetic sites, %d GPU(s), batch %d, %s" % (total, world, B, precision),
            "n_gpus": world, "sites": total, "seconds": round(elapsed, 3), "seconds_compute_max_rank": round(t_compute, 3),
            "sites_per_s": round(total / elapsed, 1), "gather_bytes": total * 12, "pool_sites": NPOOL * B}
+    if telemetry:
+        rec["gpu_telemetry_before_mid_after"] = tele
     return rec, g_act, g_pred, my_reads
 
 
@@ -87,6 +113,7 @@ def main():
     ap.add_argument("--sites", type=int, default=10_000_000)
     ap.add_argument("--batch", type=int, default=512)
     ap.add_argument("--precision", default="fp32")
+    ap.add_argument("--telemetry", action="store_true", help="record rocm-smi clocks / temperature / power before, during and after")
     args = ap.parse_args()
     rank, local, world = int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
     dist = None
@@ -94,7 +121,8 @@ def main():
         import torch.distributed as dist
         torch.cuda.set_device(local)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-    rec, g_act, g_pred, _ = run_shard(args.sites, args.batch, args.precision, dist=dist, rank=rank, local=local, world=world)
+    rec, g_act, g_pred, _ = run_shard(args.sites, args.batch, args.precision, dist=dist, rank=rank, local=local, world=world,
+                                       telemetry=args.telemetry and rank == 0)
     if rank == 0:
         if world > 1:
             assert g_act.shape[0] == rec["sites"] and bool(torch.isfinite(g_act).all())
