@@ -623,7 +623,7 @@ __device__ __forceinline__ void lstm_gates(const floatx16& acc, const float4& cp
 // CU. The host sorts the cells by descending K and passes the tile counts c0, c1 of the two heaviest classes; logical
 // tiles are cell-major (heaviest first), inside a cell n-group-major with the m-blocks of one weight panel adjacent.
 // The map uses the dispatch pattern observed on MI355X -- workgroup b runs on XCD b % 8, CU slot (b >> 3) % 32 of that
-// XCD, so blocks b, b + 256, b + 512 share a CU (tools/lstm_rawstamps.py):
+// XCD, so blocks b, b + 256, b + 512 share a CU (tools/attic/lstm_rawstamps.py):
 //   * every XCD takes a CONTIGUOUS eighth of each class (half a K = 512 cell and a quarter of a K = 256 cell on a full
 //     diagonal), so a cell's activation rows are fetched by two L2s, not by four, and a weight panel by one;
 //   * inside the XCD the heavier classes come first in dispatch order, so CU slot s gets the XCD's tiles s, s + 32,
@@ -853,7 +853,7 @@ __global__ __launch_bounds__(256, NT == 1 ? 5 : 2) void lstm_cell_lds_kernel(con
     // request j of this wave: linear fragment index q = wave + 4 j of the stage -> (k-group kgi, fragment f). The
     // source of a request is WAVE-UNIFORM up to the lane's 16 bytes, so it is kept as a scalar base (advanced with
     // scalar adds) plus one loop-invariant VGPR offset: on gfx950 a VALU instruction does not run in the shadow of an
-    // fp32 MFMA (tools/mfma_valu.hip) -- per-lane 64-bit pointer arithmetic in the K loop is matrix-pipe time lost.
+    // fp32 MFMA (tools/attic/mfma_valu.hip) -- per-lane 64-bit pointer arithmetic in the K loop is matrix-pipe time lost.
     const char* src[LPS];
     int kgi_[LPS];
     bool is_a[LPS];
@@ -2330,7 +2330,7 @@ __global__ __launch_bounds__(512, TM >= 2 ? DS_FUSEDB_WPS : 2) void inception_fu
 //   conv3  wave w = output channels [32 w, 32 w + 32) of all three m-tiles. The WHOLE activation tile is in LDS, so the
 //          48 k-groups (3 taps x 16) run without a barrier: weights global -> VGPR through a ring of four register
 //          stages, activation fragments from T one k-group ahead. Every LDS / global offset is an immediate on a
-//          loop-invariant base (fully unrolled): no vector ALU work between the MFMAs (tools/mfma_valu.hip).
+//          loop-invariant base (fully unrolled): no vector ALU work between the MFMAs (tools/attic/mfma_valu.hip).
 // MFMAs are issued transposed (weights, activations) as in the fused module: a lane holds 4 x 4 consecutive channels of
 // one row, bias = accumulator init, float4 stores.
 // Roofline: MFMA. Algorithmic FLOPs per site = 2 * W * (64 * 128 + 3 * 128 * 256); HBM bytes per row 256 in, 1024 out.
