@@ -1178,7 +1178,9 @@ __global__ __launch_bounds__(256, MTW * NTW >= 4 ? 2 : 3) void lstm_cell_bf16_ke
 //      MI355X_MICROARCH.md warns), so its time is an upper bound on what an acquire-fence form could reach.
 // Why it loses: a strand's steps are a dependency CHAIN -- poll, accumulator init, first operands (which the sc1 stores have
 // just pushed out of every L2), loop, gates, drain, counter -- ~16 us of latency per step for ~7 us of loop, and at 198 VGPRs
-// only two workgroups share a CU to hide it, where the diagonal form runs three INDEPENDENT tiles per CU. 1536 strands / 512
+// only two workgroups share a CU to hide it, where the diagonal form runs three INDEPENDENT tiles per CU (squeezed to 168
+// VGPRs -- three per CU, 64 B of spills outside the loop -- it took 1033 us: more chains in flight contend for the same L2
+// and LDS-DMA queues, they do not hide each other's latency). 1536 strands / 512
 // resident x 17 steps x 16 us = 830 us. What would change the picture is a loader-wave / compute-wave split (exact
 // vmcnt(0) per loader wave gives back the two-stage prefetch) at three workgroups per CU: a third design, not attempted.
 __device__ __forceinline__ void glds16s_sc1(const void* gbase, unsigned lane_off, unsigned lds_dst)
