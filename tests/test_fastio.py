@@ -221,3 +221,49 @@ def test_decimal_token_parsers_give_strtods_bits_on_three_million_tokens(tmp_pat
     out = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
     text = out.stdout.decode()
     assert out.returncode == 0 and "mismatches 0" in text, text[-2000:]
+
+
+def test_locate_then_parse_into_equals_next(tmp_path):
+    """The two-step form (ds_tsv_locate + ds_tsv_parse_into: rows parsed straight into the caller's arrays) gives the bits of
+    ds_tsv_next on the reader's own arrays, item by item, including across set_range() rewinds; parse_into without located
+    rows returns 0 and null destinations are refused."""
+    import ctypes
+    from deepsignal_amd import fastio, synth
+    lens = [3, 1, 8, 2, 2, 11, 1, 4, 6, 5]
+    reads = [("q%d" % k) for k, m in enumerate(lens) for _ in range(m)]
+    feats = synth.synthetic_features(len(reads), seed=21)
+    path = os.path.join(str(tmp_path), "f.tsv")
+    bases = "ACGTN"
+    with open(path, "w") as f:
+        for i in range(len(reads)):
+            f.write("\t".join(["chr1", str(100 + i), "+", str(i), reads[i], "t", "".join(bases[int(c)] for c in feats["kmer"][i]),
+                               ",".join("%.6f" % x for x in feats["means"][i]), ",".join("%.6f" % x for x in feats["stds"][i]),
+                               ",".join(str(int(x)) for x in feats["sanums"][i]), ",".join("%.6f" % x for x in feats["signals"][i]),
+                               str(int(feats["labels"][i]))]) + "\n")
+    lib = fastio._bind()
+    rd = fastio.FeatureReader(path, nthreads=3)
+    two_step = list(rd.items(2))                       # items() uses locate + parse_into
+    # the composed call, read through the accessors
+    rd.set_range(0, rd.size)
+    K, S = 17, 360
+    i = 0
+    while True:
+        n = lib.ds_tsv_next(rd._h, 2)
+        assert n >= 0
+        if n == 0:
+            break
+        it = two_step[i]
+        assert n == len(it.labels)
+        for name, arr, shape, dt in (("kmer", it.kmer, (n, K), np.int32), ("means", it.means, (n, K), np.float32),
+                                     ("stds", it.stds, (n, K), np.float32), ("lens", it.lens, (n, K), np.float32),
+                                     ("signals", it.signals, (n, S), np.float32), ("labels", it.labels, (n,), np.int32)):
+            got = fastio._view(getattr(lib, "ds_tsv_" + name)(rd._h), dt, shape)
+            assert np.array_equal(got, arr), name
+        i += 1
+    assert i == len(two_step) and sum(len(it.labels) for it in two_step) == len(reads)
+    # nothing located: parse_into has nothing to do; null destination after a locate: refused
+    assert lib.ds_tsv_parse_into(rd._h, None, None, None, None, None, None) == 0
+    rd.set_range(0, rd.size)
+    assert lib.ds_tsv_locate(rd._h, 1) == lens[0]
+    assert lib.ds_tsv_parse_into(rd._h, None, None, None, None, None, None) < 0
+    rd.close()
