@@ -43,7 +43,7 @@ struct PackedGemm {      // device-resident packed weights of one GEMM
     int K = 0, N = 0;
 };
 
-enum OpKind { OP_GEMM, OP_STEM1, OP_MAXPOOL, OP_AVGPOOL, OP_HEAD, OP_FUSED, OP_PACKEV, OP_LSTM, OP_STEM23, OP_HEADF, OP_LSTMP };
+enum OpKind { OP_GEMM, OP_STEM1, OP_MAXPOOL, OP_AVGPOOL, OP_HEAD, OP_FUSED, OP_PACKEV, OP_LSTM, OP_STEM23, OP_HEADF };
 
 struct Op {
     OpKind kind;
@@ -70,7 +70,7 @@ struct Op {
 
 // per-kernel accumulators (one entry per __global__ function / template instantiation)
 enum KernelClass { K_GEMM_CONV = 0, K_GEMM_FC, K_GEMM_LSTM, K_GEMM_CONV_WIDE, K_GEMM_CONV_POOL, K_GEMM_FC_DENSE, K_GEMM_LSTM_DENSE, K_FUSED1, K_FUSED2, K_FUSED3, K_STEM1, K_MAXPOOL, K_AVGPOOL, K_HEAD,
-                   K_GEMM_BCONV, K_GEMM_BCONV_POOL, K_GEMM_BFC, K_GEMM_BFC_DENSE, K_PACKEV, K_GEMM_BLSTM, K_GEMM_BLSTM_DENSE, K_FUSEDB1, K_FUSEDB2, K_FUSEDB3, K_GEMM_LSTM_T, K_GEMM_LSTM_T_DENSE, K_GEMM_BLSTM_T, K_GEMM_BLSTM_T_DENSE, K_LSTM_CELL1, K_LSTM_CELL2, K_LSTM_CELL4, K_LSTM_LDS1, K_LSTM_LDS2, K_STEM23, K_HEADF, K_LSTM_B11, K_LSTM_B12, K_LSTM_B22, K_STEM23B, K_LSTM_PERSIST, K_COUNT };
+                   K_GEMM_BCONV, K_GEMM_BCONV_POOL, K_GEMM_BFC, K_GEMM_BFC_DENSE, K_PACKEV, K_GEMM_BLSTM, K_GEMM_BLSTM_DENSE, K_FUSEDB1, K_FUSEDB2, K_FUSEDB3, K_GEMM_LSTM_T, K_GEMM_LSTM_T_DENSE, K_GEMM_BLSTM_T, K_GEMM_BLSTM_T_DENSE, K_LSTM_CELL1, K_LSTM_CELL2, K_LSTM_CELL4, K_LSTM_LDS1, K_LSTM_LDS2, K_STEM23, K_HEADF, K_LSTM_B11, K_LSTM_B12, K_LSTM_B22, K_STEM23B, K_COUNT };
 const char* const kKernelNames[K_COUNT] = {"gemm_kernel<1,2,4,1,0,0,1,1>", "gemm_kernel<1,3,4,1,0,0,2,1>", "gemm_kernel<1,4,4,1,1,0,1,1>",
                                            "gemm_kernel<2,2,2,2,0,0,1,1>", "gemm_kernel<1,2,4,1,0,1,1,1>", "gemm_kernel<1,3,4,1,0,2,2,1>",
                                            "gemm_kernel<1,4,4,1,1,2,1,1>", "inception_fused_kernel<1>",
@@ -85,8 +85,7 @@ const char* const kKernelNames[K_COUNT] = {"gemm_kernel<1,2,4,1,0,0,1,1>", "gemm
                                            "gemm_kernel<1,1,4,1,2,0,3,1,bf16>", "gemm_kernel<1,1,4,1,2,2,3,1,bf16>",
                                            "lstm_cell_kernel<1>", "lstm_cell_kernel<2>", "lstm_cell_kernel<4>",
                                            "lstm_cell_lds_kernel<1>", "lstm_cell_lds_kernel<2>", "stem23_kernel", "head_folded_kernel",
-                                           "lstm_cell_bf16_kernel<1,1>", "lstm_cell_bf16_kernel<1,2>", "lstm_cell_bf16_kernel<2,2>", "stem23_bf16_kernel",
-                                           "lstm_persistent_bf16_kernel"};
+                                           "lstm_cell_bf16_kernel<1,1>", "lstm_cell_bf16_kernel<1,2>", "lstm_cell_bf16_kernel<2,2>", "stem23_bf16_kernel"};
 struct KernelStat {
     int64_t launches = 0;
     double total_ms = 0;
@@ -107,7 +106,6 @@ struct Plan {
     std::vector<GemmLaunch> launches;     // host copy
     GemmLaunch* d_launches = nullptr;
     std::vector<LstmLaunch> lstm_launches;   // fp32 BiLSTM diagonals (lstm_cell_*kernel): passed by value at launch
-    std::vector<LstmPersist> lstm_persist;   // DS_LSTM_TILING_PERSISTENT: the one launch of the whole BiLSTM
     std::vector<Op> ops;                  // merged issue order
     hipGraphExec_t graph = nullptr;
     int64_t uses = 0, last_use = 0;       // ragged tails produce many one-off sizes: graphs are captured for sizes that
@@ -135,9 +133,6 @@ struct Slot {
     float *fc1o = nullptr, *logits = nullptr, *act = nullptr;
     int* pred = nullptr;
     float* joint = nullptr;              // bf16 mode: [B][JP] bf16 FC operand (event features | signal features | zero pad)
-    unsigned* lp_abort_host = nullptr;   // ... pinned copy of the launch's abort word (copied behind every launch, read after the sync)
-    unsigned* lp_sync = nullptr;         // DS_LSTM_TILING_PERSISTENT: tickets / abort flag / per-(direction, layer, m-block) step counters
-    bool owns_s1 = true;                 // ... every slot shares slot 0's event-model stream (one persistent launch at a time)
 
     // ds_submit / ds_wait: pinned host staging of one batch (inputs in, 12 B/site out), allocated on first use
     char* pin_in = nullptr;
@@ -168,8 +163,6 @@ struct ds_handle {
     int fuse_min_tiles = 128; // fused-module grids keep at least this many workgroups when the batch allows it
     bool lstm_bf16 = false;   // DS_PRECISION_BF16_ALL: additionally bf16 h / weight operands in the LSTM matmuls (fp32 accumulate,
                               // gates and cell state; the layer-0 input projection stays an fp32 table lookup)
-    bool lstm_persist = false;   // DS_LSTM_TILING_PERSISTENT on a DS_PRECISION_BF16_ALL handle
-    int lp_grid = 0;             // workgroups of the persistent launch (co-resident by construction)
     bool lstm_frag = false;   // fp32 BiLSTM cells: lstm_cell_kernel on fragment-major h / c (every mode but DS_PRECISION_BF16_ALL)
     int Bp32 = 0;             // max_batch rounded up to whole 32-site m-tiles (rows of the fragment-major buffers)
     int JP = 0;           // J rounded up to a whole K chunk (32 bf16)
@@ -539,11 +532,6 @@ int alloc_workspace(ds_handle* h)
     A(&h->cur->act, B * h->C + B);            // [act | pred]: one block, one D2H copy
     if (!rc) h->cur->pred = reinterpret_cast<int*>(h->cur->act + B * h->C);
     if (h->bf16) A(&h->cur->joint, B * (size_t)h->JP / 2);
-    if (h->lstm_persist) {
-        A(&h->cur->lp_sync, lstm_persist_sync_words((int)(h->Bp32 / 128 + 1)));
-        if (!rc && hipHostMalloc(reinterpret_cast<void**>(&h->cur->lp_abort_host), 64) != hipSuccess) rc = fail(h, DS_ERR_NOMEM, "hipHostMalloc");
-        if (!rc) *h->cur->lp_abort_host = 0;
-    }
     // module outputs: ping-pong pair normally; one buffer per module in debug mode (for taps)
     // the modules of a width class run as a chain inside one launch (ds_internal.h FusedChain): a workgroup that is already
     // in module 5 must not write into the buffer a slower workgroup still reads module 4's (stride-2 pooled, differently
@@ -838,40 +826,6 @@ int build_plan(ds_handle* h, int n, Plan* plan)
                        : h->lstm_variant == DS_LSTM_TILING_LDS1 ? 101 : h->lstm_variant == DS_LSTM_TILING_LDS2 ? 102
                        : (n <= 1024 ? 101 : 102);
         const size_t step = (size_t)h->Bp32 * HU;                          // floats of one time step in H (bf16 h: half)
-        if (h->lstm_persist) {
-            // the whole BiLSTM as ONE persistent launch (ds_kernels.hip lstm_persistent_bf16_kernel)
-            LstmPersist P;
-            memset(&P, 0, sizeof P);
-            double flops = 0;
-            for (int dir = 0; dir < 2; ++dir)
-                for (int l = 0; l < NLAYER; ++l) {
-                    LstmPersistLayer& Y = P.lay[dir][l];
-                    Y.Bp = h->lstm_n[dir][l].Bp;
-                    Y.kg_stride = (2 * h->lstm_n[dir][l].K + 63) / 64 * 64 / 16;
-                    Y.bias = h->lstm_n[dir][l].bias;
-                    Y.table = l == 0 ? h->lstm_table[dir] : nullptr;
-                    Y.wfeat = h->lstm_wfeat[dir];
-                    Y.H = h->cur->H[dir][l];
-                    for (int sidx = 0; sidx < T; ++sidx) flops += 2.0 * n * 4 * HID * ((l > 0 ? HID : 0) + (sidx > 0 ? HID : 0));
-                }
-            P.hlast[0] = h->cur->hlast[0]; P.hlast[1] = h->cur->hlast[1];
-            P.codes = h->cur->d_kmer; P.means = h->cur->d_means; P.stds = h->cur->d_stds; P.lens = h->cur->d_sanums;
-            P.sync = h->cur->lp_sync;
-            P.step_floats = (long long)step;
-            P.timeout_ticks = 200000000ull;              // 2 s of s_memrealtime (100 MHz): a forward takes milliseconds
-            P.n = n; P.mtiles = mtiles; P.T = T; P.nmb = (mtiles + 3) / 4;
-            Op op{};
-            op.kind = OP_LSTMP; op.stream = 1; op.stage = st;
-            op.launch_index = (int)plan->lstm_persist.size();
-            op.a = std::min(6 * P.nmb * 8, h->lp_grid);      // workgroups: all co-resident
-            op.flops = flops;
-            plan->lstm_persist.push_back(P);
-            rnn.push_back(op);
-            if (first_plan) {
-                h->stages[st].launches += 1;
-                h->stages[st].flops_per_site += flops / n;
-            }
-        } else
         for (int d = 0; d < T + NLAYER - 1; ++d) {
             LstmLaunch L;
             memset(&L, 0, sizeof L);
@@ -1024,13 +978,6 @@ int issue_op(ds_handle* h, Plan& plan, const Op& op, hipStream_t s)
     case OP_LSTM:
         HIPCHK(h, launch_lstm_cells(op.c, plan.lstm_launches[op.launch_index], s));
         break;
-    case OP_LSTMP: {
-        const LstmPersist& P = plan.lstm_persist[op.launch_index];
-        HIPCHK(h, hipMemsetAsync(P.sync, 0, lstm_persist_sync_words(P.nmb) * sizeof(unsigned), s));
-        HIPCHK(h, launch_lstm_persistent(P, op.a, s));
-        HIPCHK(h, hipMemcpyAsync(h->cur->lp_abort_host, P.sync + LP_ABORT, sizeof(unsigned), hipMemcpyDeviceToHost, s));
-        break;
-    }
     case OP_STEM23:
         if (op.a) HIPCHK(h, launch_stem23_bf16(op.sa, s));
         else HIPCHK(h, launch_stem23(op.sa, s));
@@ -1130,7 +1077,6 @@ int kernel_class(const Op& op)
     case OP_AVGPOOL: return K_AVGPOOL;
     case OP_HEAD: return K_HEAD;
     case OP_PACKEV: return K_PACKEV;
-    case OP_LSTMP: return K_LSTM_PERSIST;
     case OP_LSTM: return op.c == 1 ? K_LSTM_CELL1 : op.c == 2 ? K_LSTM_CELL2 : op.c == 4 ? K_LSTM_CELL4 : op.c == 101 ? K_LSTM_LDS1
                : op.c == 211 ? K_LSTM_B11 : op.c == 212 ? K_LSTM_B12 : op.c == 222 ? K_LSTM_B22 : K_LSTM_LDS2;
     }
@@ -1327,8 +1273,6 @@ static int ds_create_impl(const ds_config* cfg, ds_handle** out)
     if (cfg->reserved[4] > 0) h->fuse_max_spt = cfg->reserved[4];
     if (cfg->reserved[5] > 0) h->fuse_min_tiles = cfg->reserved[5];
     h->lstm_frag = h->is_rnn && !h->lstm_bf16;
-    h->lstm_persist = h->lstm_bf16 && h->lstm_variant == DS_LSTM_TILING_PERSISTENT;
-    if (h->lstm_persist) h->use_graph = false;       // its launch must stay on the shared event-model stream (a graph node has no stream)
     h->Bp32 = (h->B + 31) / 32 * 32;
     h->JP = (h->J + 31) / 32 * 32;
     h->debug = cfg->reserved[0] != 0;
@@ -1339,24 +1283,12 @@ static int ds_create_impl(const ds_config* cfg, ds_handle** out)
     // (the bf16 modes: a 512-site forward is ~0.2 ms, four in flight measured 2.60 M sites/s against 2.51 M with eight)
     int nslots = cfg->reserved[1] > 0 ? cfg->reserved[1] : (h->B <= 1024 && !h->bf16 ? 8 : 4);
     nslots = std::max(1, std::min(nslots, 16));
-    if (h->lstm_persist) {
-        // every workgroup of the persistent BiLSTM launch must be resident at once (ds_kernels.hip): the grid is what the
-        // occupancy query admits, and only ONE such launch may be in flight -- the slots share an event-model stream, which
-        // the one-stream diagnostic mode cannot offer to more than one slot
-        if (h->serial) nslots = 1;
-        int cus = 0, per_cu = 0;
-        CK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, cfg->device));
-        CK(lstm_persistent_blocks_per_cu(&per_cu));
-        h->lp_grid = cus * std::max(1, std::min(per_cu, 3));
-        if (h->lp_grid < 64) { fail(nullptr, DS_ERR_INVALID, "DS_LSTM_TILING_PERSISTENT needs at least 64 co-resident workgroups"); ds_destroy(h); return DS_ERR_INVALID; }
-    }
     h->slots.resize(nslots);
     int rc = DS_OK;
     for (Slot& sl : h->slots) {
         h->cur = &sl;
         CK(hipStreamCreateWithFlags(&sl.s0, hipStreamNonBlocking));
-        if (h->lstm_persist && &sl != &h->slots[0]) { sl.s1 = h->slots[0].s1; sl.owns_s1 = false; }
-        else CK(hipStreamCreateWithFlags(&sl.s1, hipStreamNonBlocking));
+        CK(hipStreamCreateWithFlags(&sl.s1, hipStreamNonBlocking));
         CK(hipEventCreateWithFlags(&sl.ev_fork, hipEventDisableTiming));
         CK(hipEventCreateWithFlags(&sl.ev_join, hipEventDisableTiming));
         if (!rc) rc = alloc_workspace(h);
@@ -1391,13 +1323,12 @@ void ds_destroy(ds_handle* h)
             if (kv.second.graph) hipGraphExecDestroy(kv.second.graph);
             for (Op& op : kv.second.ops) { if (op.ev0) hipEventDestroy(op.ev0); if (op.ev1) hipEventDestroy(op.ev1); }
         }
-        if (sl.lp_abort_host) hipHostFree(sl.lp_abort_host);
         if (sl.pin_in) hipHostFree(sl.pin_in);
         if (sl.pin_act) hipHostFree(sl.pin_act);       // pin_pred points into it
         if (sl.ev_fork) hipEventDestroy(sl.ev_fork);
         if (sl.ev_join) hipEventDestroy(sl.ev_join);
         if (sl.s0) hipStreamDestroy(sl.s0);
-        if (sl.s1 && sl.owns_s1) hipStreamDestroy(sl.s1);
+        if (sl.s1) hipStreamDestroy(sl.s1);
     }
     for (void* p : h->allocs) hipFree(p);
     delete h;
@@ -1490,20 +1421,6 @@ static int ds_forward_device_impl(ds_handle* h, int32_t n, const int32_t* d_kmer
     return DS_OK;
 }
 
-// DS_LSTM_TILING_PERSISTENT: a dependency wait that ran into its time limit sets the abort word and every workgroup leaves;
-// the forward's outputs are then garbage and the caller must hear about it (called with the slots' streams drained)
-static int check_persist_abort(ds_handle* h, Slot* only = nullptr)
-{
-    for (Slot& sl : h->slots) {
-        if (!sl.lp_abort_host || (only && only != &sl)) continue;
-        if (*sl.lp_abort_host) {
-            *sl.lp_abort_host = 0;
-            return fail(h, DS_ERR_HIP, "persistent BiLSTM launch: a dependency wait timed out (outputs of this forward are invalid)");
-        }
-    }
-    return DS_OK;
-}
-
 int ds_sync(ds_handle* h)
 {
     if (!h) return DS_ERR_INVALID;
@@ -1511,7 +1428,6 @@ int ds_sync(ds_handle* h)
         HIPCHK(h, hipStreamSynchronize(sl.s0));
         HIPCHK(h, hipStreamSynchronize(sl.s1));
     }
-    if (h->lstm_persist) { int rc = check_persist_abort(h); if (rc) return rc; }
     if (h->profiling) return collect_stage_times(h);
     return DS_OK;
 }
@@ -1661,7 +1577,6 @@ static int ds_wait_impl(ds_handle* h, int32_t ticket, float* act, int32_t* pred)
         return fail(h, DS_ERR_INVALID, "ds_wait: no forward in flight for this ticket");
     Slot& sl = h->slots[ticket];
     HIPCHK(h, hipStreamSynchronize(sl.s0));
-    if (h->lstm_persist) { int rc = check_persist_abort(h, &sl); if (rc) { sl.submitted_n = -1; return rc; } }
     memcpy(act, sl.pin_act, (size_t)sl.submitted_n * h->C * 4);
     memcpy(pred, sl.pin_pred, (size_t)sl.submitted_n * 4);
     sl.submitted_n = -1;

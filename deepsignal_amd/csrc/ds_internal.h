@@ -95,31 +95,6 @@ struct LstmLaunch {
     int cls_tiles[2];          // workgroup tiles of the K = 512 cells and of the K = 256 cells (cells are sorted by K)
     unsigned long long* dbg;   // diagnostic (DS_TUNE_DEBUG_STAMPS): [DBG_MAX_WGS workgroups][8] time stamps of wave 0, null in normal runs
 };
-// ---- the whole bf16-operand BiLSTM of a forward as ONE persistent launch (lstm_persistent_bf16_kernel) ----
-struct LstmPersistLayer {
-    const float* Bp;      // packed bf16 weights of this (direction, layer), as LstmCell::Bp
-    const float* bias;    // [4][256]
-    const float* table;   // layer 0: folded embedding table or nullptr
-    const float* wfeat;   // layer 0: [3][1024]
-    float* H;             // h of every step [T][m-tiles][...] bf16 fragment-major (LstmCell::h_out of step t = H + t * step_floats)
-    int kg_stride, pad_;
-};
-struct LstmPersist {
-    LstmPersistLayer lay[2][3];
-    float* hlast[2];           // row-major fp32 [n][256]: top layer's final h (fw step T-1, bw step 0)
-    const int* codes;          // [n][T]
-    const float *means, *stds, *lens;
-    unsigned* sync;            // words: [0..7] per-XCD tickets, [LP_ABORT] abort flag, [LP_COUNTERS + (dir*3+layer)*nmb + mb] finished
-                               // column-group steps of that (direction, layer, m-block); zeroed before every launch
-    long long step_floats;     // floats between two time steps in H
-    unsigned long long timeout_ticks;   // s_memrealtime ticks (100 MHz) a dependency wait may take before the launch aborts
-    int n, mtiles, T, nmb;     // nmb = m-blocks of 128 sites
-};
-constexpr int LP_ABORT = 8, LP_COUNTERS = 16;
-inline size_t lstm_persist_sync_words(int nmb) { return (size_t)LP_COUNTERS + 6 * (size_t)nmb; }
-hipError_t launch_lstm_persistent(const LstmPersist& P, int grid, hipStream_t s);
-hipError_t lstm_persistent_blocks_per_cu(int* out);      // occupancy query for the launch above (256 threads, its dynamic LDS)
-
 // nt = 32-column n-tiles per wave (1, 2 or 4): the same bits for every nt (same K order per output element)
 hipError_t launch_lstm_cells(int nt, const LstmLaunch& L, hipStream_t s);      // L travels as a by-value kernel argument
 

@@ -1142,267 +1142,6 @@ __global__ __launch_bounds__(256, MTW * NTW >= 4 ? 2 : 3) void lstm_cell_bf16_ke
 #undef DS_LSTAMP
 }
 
-// ---------------------------------------------------------------------------------------------
-// The bf16-operand BiLSTM of one forward as ONE persistent launch (DS_PRECISION_BF16_ALL at >= 2048 sites per forward).
-//
-// lstm_cell_bf16_kernel runs a diagonal per launch: 19 launches, and at 4096 sites 45 % of a launch is outside the K loop
-// (entry, first operands from an L2 that does not hold what other XCDs wrote, bias / cell-state loads, gates, drain), the
-// fp32 cell state makes a round trip through HBM every step. Here a workgroup owns a STRAND -- (direction, layer, m-block of
-// 128 sites, group of 128 gate columns = 32 units) -- for all T steps: the cell state never leaves
-// registers, and the only thing between two steps of a strand is the hand-off of h:
-//   * dependencies never cross m-blocks: step s of (dir, l, mb) needs h_l(s-1) and h_{l-1}(s) of the SAME 128 sites, all 256
-//     units -- i.e. the eight column-group strands of (dir, l, mb) and of (dir, l-1, mb). Each strand, after its h slice of a
-//     step is stored, adds 1 to the counter of its (dir, l, mb); a step may start when the counters it needs have reached
-//     8 x (steps) -- per-m-block ready counters in global memory, no grid-wide barrier;
-//   * the hand-off follows MI355X_MICROARCH.md "inter-workgroup visibility": every h byte is stored sc1 (write-through), the
-//     storing waves wait vmcnt(0), the workgroup's barrier, ONE lane's agent-scope atomic add; the consumer polls the counter
-//     with an sc1 load (one lane), a workgroup barrier, then EVERY load of h is an sc1 load (LDS-DMA with the sc1 bit: L1 is
-//     bypassed; each h address is written once per launch and only read after its counter says so);
-//   * strands are handed out by ticket, per XCD (HW_REG_XCC_ID): XCD x serves the m-blocks x, x + 8, ..., in
-//     (m-block, layer, direction, column group) order, so the eight strands that read the same h fragments run on CUs behind
-//     one L2 (placement is SPEED only: a workgroup whose own list is empty takes tickets of another XCD's list);
-//   * forward progress: a ticket is only ever held by a running workgroup and tickets of a list are handed out in order; a
-//     strand waits only for strands of its own group of eight or of lower tickets of the same list, so the lowest unfinished
-//     group of a list always has all its members running or about to be taken by the next free workgroup. Needs more than
-//     56 co-resident workgroups (the grid is min(strands, 3 per CU)) and AT MOST ONE such launch in flight per GPU: the
-//     engine issues them on one stream shared by all its slots. Every wait is bounded (timeout -> abort flag -> every
-//     workgroup leaves, the host reports the error).
-// Same arithmetic, same K order per element as lstm_cell_bf16_kernel: the bits of the diagonal form (tests/test_gpu_bf16.py).
-// Roofline: operand delivery (L2 -> LDS, 64 B/clk per CU) ~ MFMA at three workgroups per CU; algorithmic FLOPs as the cells.
-//
-// MEASURED (round 4, MI355X, 4096 sites per forward, stand-alone): 899 us per forward against 688 us for the 19 diagonal
-// launches -- NOT the default (DS_LSTM_TILING_PERSISTENT selects it). Two design iterations, VERDICT r03's kill criterion:
-//   1. this form (sc1 hand-off, every request waited for): 899 us, 2.69 M sites/s against 3.24 M;
-//   2. plain h loads with counted waits, as the diagonal kernel pipelines them: 831 us -- and WRONG (a few stale m-tiles per
-//      forward: a plain load of another CU's freshly written line is stale without an agent-scope acquire, exactly as
-//      MI355X_MICROARCH.md warns), so its time is an upper bound on what an acquire-fence form could reach.
-// Why it loses: a strand's steps are a dependency CHAIN -- poll, accumulator init, first operands (which the sc1 stores have
-// just pushed out of every L2), loop, gates, drain, counter -- ~16 us of latency per step for ~7 us of loop, and at 198 VGPRs
-// only two workgroups share a CU to hide it, where the diagonal form runs three INDEPENDENT tiles per CU (squeezed to 168
-// VGPRs -- three per CU, 64 B of spills outside the loop -- it took 1033 us: more chains in flight contend for the same L2
-// and LDS-DMA queues, they do not hide each other's latency). 1536 strands / 512
-// resident x 17 steps x 16 us = 830 us. What would change the picture is a loader-wave / compute-wave split (exact
-// vmcnt(0) per loader wave gives back the two-stage prefetch) at three workgroups per CU: a third design, not attempted.
-__device__ __forceinline__ void glds16s_sc1(const void* gbase, unsigned lane_off, unsigned lds_dst)
-{
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 sc1\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(lane_off), "s"(gbase), "s"(lds_dst)
-                 : "memory");
-}
-__device__ __forceinline__ void gstore8_sc1(void* p, unsigned a, unsigned b)
-{
-    typedef unsigned int u2v __attribute__((ext_vector_type(2)));
-    const u2v v = {a, b};
-    asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
-}
-
-__global__ __launch_bounds__(256, 2) void lstm_persistent_bf16_kernel(const LstmPersist P_)
-{
-    const LstmPersist* const Pp = &P_;
-    constexpr int MTW = 2, NTW = 2, FRA = 4, FRB = 4, FR = 8, KGS = 2, NF = KGS * FR, LPS = NF / 4, STAGE = NF * 256;
-    extern __shared__ __attribute__((aligned(16))) float ring[];    // [3 * STAGE]
-    __shared__ int s_word[2];
-
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int mi = wave & 1, nj = wave >> 1;
-    const int half = lane >> 5, r31 = lane & 31;
-    const unsigned lane16 = (unsigned)lane * 16, lane4 = (unsigned)lane * 4;
-    const int n = Pp->n, T = Pp->T, nmb = Pp->nmb, mtiles = Pp->mtiles;
-    unsigned* const sync = Pp->sync;
-    const unsigned ring_lds = (unsigned)(size_t)(__attribute__((address_space(3))) float*)ring;
-    // HW_REG_XCC_ID (id 20), bits [3:0]: the XCD this workgroup runs on
-    const int xcd = (int)(__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 7u);
-
-    for (;;) {
-        // ---- next strand: own XCD's list first, then any other list (speed only)
-        if (threadIdx.x == 0) {
-            int got = -1;
-            for (int k = 0; k < 8 && got < 0; ++k) {
-                const int x = (xcd + k) & 7;
-                const int nk = x < nmb ? (nmb - x + 7) / 8 : 0;            // m-blocks x, x + 8, ... of this list
-                if (nk == 0) continue;
-                // a relaxed look first: exhausted lists are not hammered with atomics
-                if (__hip_atomic_load(sync + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)(nk * 48)) continue;
-                const unsigned tk = __hip_atomic_fetch_add(sync + x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (tk < (unsigned)(nk * 48)) got = x * 65536 + (int)tk;
-            }
-            s_word[0] = got;
-        }
-        __syncthreads();
-        const int tk = s_word[0];
-        __syncthreads();
-        if (tk < 0) break;
-        const int list = tk >> 16, idx = tk & 65535;
-        const int mb = list + 8 * (idx / 48), rr = idx % 48;
-        const int l = rr >> 4, dir = (rr >> 3) & 1, ng = rr & 7;
-        const LstmPersistLayer& Y = Pp->lay[dir][l];
-        unsigned* const cnt_own = sync + LP_COUNTERS + (dir * 3 + l) * nmb + mb;
-        const unsigned* const cnt_below = l > 0 ? sync + LP_COUNTERS + (dir * 3 + l - 1) * nmb + mb : nullptr;
-
-        // this wave's tiles: m-tiles mb * 4 + mi * 2 + i, n-tiles ng * 4 + nj * 2 + j
-        int mt[MTW];
-        bool valid[MTW];
-#pragma unroll
-        for (int i = 0; i < MTW; ++i) {
-            const int raw = mb * FRA + mi * MTW + i;
-            valid[i] = raw < mtiles;
-            mt[i] = valid[i] ? raw : mtiles - 1;
-        }
-        // DMA request j of this wave = fragment q = wave + 4 j of a stage: j even -> h fragment of m-tile mb * 4 + wave (k-step
-        // j / 2 of the stage), j odd -> weight fragment of n-tile ng * 4 + wave
-        const int am = min(mb * FRA + wave, mtiles - 1);
-        const char* const bsrc = reinterpret_cast<const char*>(Y.Bp) + (size_t)(ng * FRB + wave) * Y.kg_stride * 1024;
-
-        float4 cp[MTW][NTW];
-#pragma unroll
-        for (int i = 0; i < MTW; ++i)
-#pragma unroll
-            for (int j = 0; j < NTW; ++j) cp[i][j] = make_float4(0.f, 0.f, 0.f, 0.f);
-        bool aborted = false;
-        for (int sidx = 0; sidx < T; ++sidx) {
-            const int t = dir == 0 ? sidx : T - 1 - sidx;
-            const int tprev = dir == 0 ? t - 1 : t + 1;
-            const bool has_x = l > 0, has_h = sidx > 0;
-            // ---- accumulator init (its loads are in flight while lane 0 waits for the dependencies)
-            floatx16 acc[MTW][NTW];
-            {
-                LstmCell C;
-                C.bias = Y.bias; C.table = Y.table; C.wfeat = Y.wfeat; C.codes = Pp->codes; C.means = Pp->means; C.stds = Pp->stds;
-                C.lens = Pp->lens; C.t = t; C.use_feat = l == 0;
-#pragma unroll
-                for (int i = 0; i < MTW; ++i) {
-                    const int row = mt[i] * 32 + r31;
-                    const int rowc = row < n ? row : n - 1;
-#pragma unroll
-                    for (int j = 0; j < NTW; ++j) lstm_acc_init(C, (ng * FRB + nj * NTW + j) * 8 + 4 * half, rowc, T, acc[i][j]);
-                }
-            }
-            // ---- dependencies: h_{l-1}(sidx) and h_l(sidx - 1) of this m-block, all eight column groups
-            if (threadIdx.x == 0) {
-                int ok = 1;
-                const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-                for (int which = 0; which < 2 && ok; ++which) {
-                    const unsigned* p = which == 0 ? (has_x ? cnt_below : nullptr) : (has_h ? cnt_own : nullptr);
-                    const unsigned need = which == 0 ? 8u * (unsigned)(sidx + 1) : 8u * (unsigned)sidx;
-                    if (!p) continue;
-                    for (unsigned it = 0;; ++it) {
-                        if (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= need) break;
-                        if ((it & 15u) == 15u) {
-                            if (__hip_atomic_load(sync + LP_ABORT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { ok = 0; break; }
-                            if (__builtin_amdgcn_s_memrealtime() - t0 > Pp->timeout_ticks) {
-                                __hip_atomic_store(sync + LP_ABORT, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                ok = 0;
-                                break;
-                            }
-                        }
-                        __builtin_amdgcn_s_sleep(4);
-                    }
-                }
-                s_word[1] = ok;
-            }
-            __syncthreads();
-            if (s_word[1] == 0) { aborted = true; break; }      // uniform
-            // every compiler-visible load is retired before the counted LDS-DMA requests start (see lstm_cell_bf16_kernel)
-#pragma unroll
-            for (int i = 0; i < MTW; ++i)
-#pragma unroll
-                for (int j = 0; j < NTW; ++j) asm volatile("" : "+v"(acc[i][j]));
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-
-            const int KS = (has_x ? 16 : 0) + (has_h ? 16 : 0);
-            const int nstages = KS / KGS;
-            // h operands: k-steps [0, 16) = x rows (layer below, this step) when present, then the h rows (this layer, previous step)
-            const char* const ax = has_x ? reinterpret_cast<const char*>(Pp->lay[dir][l - 1].H + (size_t)t * Pp->step_floats) : nullptr;
-            const char* const ah = has_h ? reinterpret_cast<const char*>(Y.H + (size_t)tprev * Pp->step_floats) : nullptr;
-            auto request = [&](int st, int slot) __attribute__((always_inline)) {
-                const unsigned dst = __builtin_amdgcn_readfirstlane(ring_lds + (slot * STAGE + wave * 256) * 4);
-#pragma unroll
-                for (int j = 0; j < LPS; ++j) {
-                    const int ks = st * KGS + (j >> 1);
-                    if ((j & 1) == 0) {
-                        const char* base = (has_x && ks < 16) ? ax + (size_t)ks * 1024 : ah + (size_t)(ks - (has_x ? 16 : 0)) * 1024;
-                        glds16s_sc1(base + (size_t)am * LSTM_MT_BYTES_BF16, lane16, dst + j * 4096);
-                    } else {
-                        glds16s(bsrc + (size_t)ks * 1024, lane16, dst + j * 4096);
-                    }
-                }
-            };
-            if (nstages > 0) request(0, 0);
-            if (nstages > 1) request(1, 1);
-            const float* const fa0 = ring + (mi * MTW) * 256 + lane4;
-            const float* const fb0 = ring + (FRA + nj * NTW) * 256 + lane4;
-            auto stage = [&](int st, auto slot_c) __attribute__((always_inline)) {
-                constexpr int SLOT = decltype(slot_c)::value;
-                // EVERY request is waited for, not "all but the next stage's": sc1 LDS-DMA requests do not retire in issue order
-                // -- neither with respect to plain ones nor among themselves -- so a counted vmcnt let a stage through before
-                // its h fragment had landed (whole m-tiles wrong from some step on, a few per forward; measured). The price is
-                // a prefetch distance of one stage instead of two.
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
-                if (st + 2 < nstages) request(st + 2, (SLOT + 2) % 3);
-#pragma unroll
-                for (int kgi = 0; kgi < KGS; ++kgi) {
-                    float4 a[MTW], b[NTW];
-#pragma unroll
-                    for (int i = 0; i < MTW; ++i) a[i] = *reinterpret_cast<const float4*>(fa0 + SLOT * STAGE + (kgi * FR + i) * 256);
-#pragma unroll
-                    for (int j = 0; j < NTW; ++j) b[j] = *reinterpret_cast<const float4*>(fb0 + SLOT * STAGE + (kgi * FR + j) * 256);
-#pragma unroll
-                    for (int i = 0; i < MTW; ++i)
-#pragma unroll
-                        for (int j = 0; j < NTW; ++j) acc[i][j] = mfma_bf_early(b[j], a[i], acc[i][j]);
-                }
-            };
-            for (int st = 0; st < nstages;) {
-                stage(st, LdsSlot<0>{}); if (++st >= nstages) break;
-                stage(st, LdsSlot<1>{}); if (++st >= nstages) break;
-                stage(st, LdsSlot<2>{}); ++st;
-            }
-
-            // ---- gates; c stays in registers; h: bf16 fragment-major, stored write-through (sc1)
-            float* const hout = Y.H + (size_t)t * Pp->step_floats;
-            float* const hrow = (l == 2 && sidx == T - 1) ? Pp->hlast[dir] : nullptr;
-#pragma unroll
-            for (int i = 0; i < MTW; ++i) {
-                const int row = mt[i] * 32 + r31;
-#pragma unroll
-                for (int j = 0; j < NTW; ++j) {
-                    const int ntile = ng * FRB + nj * NTW + j;
-                    float4 cn, hn;
-                    lstm_gates(acc[i][j], cp[i][j], cn, hn);
-                    cp[i][j] = cn;
-                    if (!valid[i]) continue;
-                    char* const hb = reinterpret_cast<char*>(hout) + (size_t)mt[i] * LSTM_MT_BYTES_BF16 + (unsigned)(ntile >> 1) * 1024 +
-                                     (unsigned)(((ntile & 1) * 32 + r31) * 16 + half * 8);
-                    gstore8_sc1(hb, pack_bf2(hn.x, hn.y), pack_bf2(hn.z, hn.w));
-                    if (hrow && row < n) {
-                        const v4f hr = {hn.x, hn.y, hn.z, hn.w};
-                        *(__attribute__((address_space(1))) v4f*)(hrow + (size_t)row * 256 + ntile * 8 + 4 * half) = hr;
-                    }
-                }
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's h bytes have left the CU
-            __syncthreads();                                      // ... every wave's; the ring is free for the next step
-            if (threadIdx.x == 0) __hip_atomic_fetch_add(cnt_own, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        if (aborted) break;
-    }
-}
-
-hipError_t lstm_persistent_blocks_per_cu(int* out)
-{
-    return hipOccupancyMaxActiveBlocksPerMultiprocessor(out, lstm_persistent_bf16_kernel, 256, 3 * 2 * 8 * 1024);
-}
-
-hipError_t launch_lstm_persistent(const LstmPersist& P, int grid, hipStream_t s)
-{
-    if (P.n <= 0 || grid <= 0) return hipSuccess;
-    hipLaunchKernelGGL(lstm_persistent_bf16_kernel, dim3(grid), dim3(256), 3 * 2 * 8 * 1024, s, P);
-    return hipGetLastError();
-}
-
 hipError_t launch_lstm_cells(int nt, const LstmLaunch& L, hipStream_t s)
 {
     const int ncell = L.ncell, mtiles = L.mtiles;

@@ -85,9 +85,6 @@ typedef struct ds_config {
 #define DS_LSTM_TILING_WIDE 2    /* four n-tiles per wave          */
 #define DS_LSTM_TILING_LDS1 3    /* fp32 cells: operands shared through LDS, 64 x 64 workgroup tile  */
 #define DS_LSTM_TILING_LDS2 4    /* fp32 cells: operands shared through LDS, 64 x 128 workgroup tile */
-#define DS_LSTM_TILING_PERSISTENT 5   /* DS_PRECISION_BF16_ALL: the whole BiLSTM of a forward as ONE persistent launch (cell state in
-                                         registers, per-m-block ready counters between the steps); the handle then issues its forwards
-                                         eagerly (no captured graph) and runs every slot's BiLSTM on one shared stream              */
 
 /* Replaces Model(...) + tf.Session(): call_modifications.py:203-209. */
 int ds_create(const ds_config *cfg, ds_handle **out);

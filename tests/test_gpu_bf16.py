@@ -271,52 +271,3 @@ def test_bf16_all_other_geometries_and_ragged_batches(geom, batch):
     assert np.array_equal(a2, act[sel]) and np.array_equal(p2, pred[sel])
     eng.close()
 
-
-def test_persistent_bilstm_gives_the_bits_of_the_diagonal_launches(balanced_weights):
-    """Engine(lstm_tiling="persistent"): the whole bf16-operand BiLSTM of a forward as ONE launch (a workgroup keeps a
-    (direction, layer, 128-site block, 32-unit group) for all 17 steps, cell state in registers, h handed from step to step
-    through per-block ready counters with sc1 stores / loads; ds_kernels.hip lstm_persistent_bf16_kernel). Same arithmetic
-    and K order as the 19 diagonal launches, so: every LSTM tap and the outputs bit for bit, on a ragged batch, on a full
-    one, on a sub-batch, and with four forwards in flight (all slots' persistent launches share one stream). Slower than
-    the diagonal form (899 against 688 us at 4096 sites), hence opt-in; the test keeps it honest."""
-    import torch
-    names = ("lstm_fw_l0", "lstm_bw_l0", "lstm_fw_l1", "lstm_bw_l1", "lstm_fw_l2", "lstm_bw_l2")
-    keys = ("kmer", "means", "stds", "sanums", "signals")
-    feats = synth.synthetic_features(4096, seed=71)
-    args = [feats[k] for k in keys]
-    m = 2100
-    taps = {}
-    for tag, kw in (("diagonal", {}), ("persistent", {"lstm_tiling": "persistent"})):
-        e = _engine(balanced_weights, max_batch=4096, precision="bf16_all", debug=True, slots=1, **kw)
-        a, p = e.run(*(x[:m] for x in args))
-        taps[tag] = (a, p, {n_: e.intermediate(n_, (m, 17, 256)) for n_ in names})
-        e.close()
-    for n_ in names:
-        assert np.array_equal(taps["diagonal"][2][n_], taps["persistent"][2][n_]), n_
-    assert np.array_equal(taps["diagonal"][0], taps["persistent"][0]) and np.array_equal(taps["diagonal"][1], taps["persistent"][1])
-    ref = _engine(balanced_weights, max_batch=4096, precision="bf16_all")
-    a_ref, p_ref = ref.run(*args)
-    ref.close()
-    assert 0.2 < p_ref.mean() < 0.8
-    e = _engine(balanced_weights, max_batch=4096, precision="bf16_all", lstm_tiling="persistent")
-    assert e.slots >= 2
-    a_full, p_full = e.run(*args)
-    a_sub, p_sub = e.run(*(x[100:177] for x in args))
-    assert np.array_equal(a_full, a_ref) and np.array_equal(p_full, p_ref)
-    assert np.array_equal(a_sub, a_ref[100:177]) and np.array_equal(p_sub, p_ref[100:177])
-    # 24 device-resident forwards over the slots, inputs rotating over four different batches
-    dev = torch.device("cuda", 0)
-    B = 1024
-    d = {k: torch.from_numpy(feats[k]).to(dev) for k in keys}
-    act = torch.zeros((24, B, 2), dtype=torch.float32, device=dev)
-    pred = torch.zeros((24, B), dtype=torch.int32, device=dev)
-    for i in range(24):
-        b = (i % 4) * B
-        e.run_device(B, *(d[k][b:b + B].data_ptr() for k in keys), act[i].data_ptr(), pred[i].data_ptr())
-    e.sync()
-    torch.cuda.synchronize()
-    got = act.cpu().numpy()
-    for i in range(24):
-        b = (i % 4) * B
-        assert np.array_equal(got[i], a_ref[b:b + B]), "forward %d" % i
-    e.close()

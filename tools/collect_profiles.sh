@@ -35,8 +35,6 @@ cp $(ls $OUT/bwrite/*/*counter_collection.csv | head -1) $OUT/bf16_write_size_co
 # BASELINE configs[3] at its stated size on this build, one GPU: 10 M sites sustained, fp32 / 512 and bf16_all / 4096
 python3 tools/config4.py --sites 10000000 --batch 512 --precision fp32 --telemetry > $OUT/config4_1gpu.jsonl 2> $OUT/config4.err
 python3 tools/config4.py --sites 10000000 --batch 4096 --precision bf16_all --telemetry >> $OUT/config4_1gpu.jsonl 2>> $OUT/config4.err
-# the persistent BiLSTM variant against the diagonal launches (bit-equality, stand-alone time, step rate)
-timeout 400 python3 tools/lstm_persist_probe.py 4096 30 > $OUT/lstm_persistent_probe.txt 2>&1
 rm -rf $OUT/strace $OUT/trace $OUT/fetch $OUT/write $OUT/mfma $OUT/btrace $OUT/bfetch $OUT/bwrite
 cat $OUT/bf16_all_4096_pmc_traffic.txt | head -12
 ls -la $OUT

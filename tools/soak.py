@@ -2,7 +2,8 @@
 every result compared bit for bit with a reference pass over the same sites. Exercises the slot rotation, the bounded
 plan cache (hundreds of distinct sizes), graph capture for recurring sizes and the ragged-tail kernels.
 
-usage: python tools/soak.py [seconds] [precision] [max_batch]"""
+usage: python tools/soak.py [seconds] [precision] [max_batch] [lstm_tiling]
+(with an lstm_tiling override the reference pass comes from a default engine: every tiling must give its bits)"""
 import os, sys, time
 sys.path.insert(0, os.getcwd())
 import numpy as np, torch
@@ -15,9 +16,17 @@ B = int(sys.argv[3]) if len(sys.argv) > 3 else 512          # max_batch of the e
 POOL = max(8192, 4 * B)
 keys = ("kmer", "means", "stds", "sanums", "signals")
 feats = synth.synthetic_features(POOL, seed=77)
-eng = Engine(max_batch=B, precision=prec)
-eng.load_weights(W.random_weights(seed=5, lstm_bias_std=0.1))
-ref_act, ref_pred = eng.run(*(feats[k] for k in keys))
+tiling = sys.argv[4] if len(sys.argv) > 4 else "auto"
+w = W.random_weights(seed=5, lstm_bias_std=0.1)
+if tiling != "auto":
+    ref_eng = Engine(max_batch=B, precision=prec)
+    ref_eng.load_weights(w)
+    ref_act, ref_pred = ref_eng.run(*(feats[k] for k in keys))
+    ref_eng.close()
+eng = Engine(max_batch=B, precision=prec, lstm_tiling=tiling)
+eng.load_weights(w)
+if tiling == "auto":
+    ref_act, ref_pred = eng.run(*(feats[k] for k in keys))
 dev = torch.device("cuda", 0)
 d = {k: torch.from_numpy(feats[k]).to(dev) for k in keys}
 rng = np.random.default_rng(1)
@@ -54,5 +63,5 @@ while time.time() - t0 < secs:
             bad += int(not (np.array_equal(oa.cpu().numpy(), ref_act[s:s + n]) and np.array_equal(op.cpu().numpy(), ref_pred[s:s + n])))
     it += 1
 eng.close()
-print("soak %s: %.0f s, %d rounds, %d sites, %d mismatching calls" % (prec, time.time() - t0, it, sites, bad))
+print("soak %s (max_batch %d, lstm_tiling %s): %.0f s, %d rounds, %d sites, %d mismatching calls" % (prec, B, tiling, time.time() - t0, it, sites, bad))
 sys.exit(1 if bad else 0)
