@@ -158,3 +158,30 @@ def test_model_variants_two_statements_agree(variant):
     assert o_taps["joint"].shape[1] == d.joint == (5520 if variant["is_cnn"] else 0) + (512 if variant["is_rnn"] else 0)
     with pytest.raises(ValueError):
         spec.net_dims(is_cnn=False, is_rnn=False)
+
+
+def test_stress_golden_vectors_and_balanced_heads():
+    """The trained-regime fixture (tests/golden/make_stress_golden.py): the float64 oracle reproduces the committed outputs, the
+    fp32 oracle sits within 1e-4 of them (3 - 5e-5 measured: the noise floor tests/test_gpu_stress.py holds the HIP path to),
+    both labels occur, the LSTM saturates, and both committed heads are what weights.centred_head makes of the oracle's fc1."""
+    import os
+    from deepsignal_amd import synth, weights as W
+    from oracle import oracle
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "stress_golden.npz"))
+    w = W.stress_weights(int(g["stress_seed"]), head=g["stress_head"])
+    feats = {k: g["in_" + k] for k in ("kmer", "means", "stds", "sanums", "signals")}
+    a64, p64, t64 = oracle.forward(w, feats, "f64", taps=True)
+    assert np.abs(a64 - g["act"]).max() < 1e-9 and (p64 == g["pred"]).all()
+    assert np.abs(t64["logits"] - g["logits"]).max() < 1e-6
+    a32, p32 = oracle.forward(w, feats, "f32")
+    assert np.abs(a32 - g["act"]).max() <= 1e-4
+    assert 0.25 < g["pred"].mean() < 0.75 and np.abs(g["logits"]).max() > 8.0
+    assert np.abs(t64["lstm_fw_l2"]).max() > 0.9
+    # the heads: regenerated from the oracle's fc1 of the probe batch, bit for bit
+    for tag, wset, seed, std in (("stress", W.stress_weights(int(g["stress_seed"])), int(g["stress_seed"]), float(g["stress_logit_std"])),
+                                 ("small", W.random_weights(seed=int(g["small_seed"]), lstm_bias_std=float(g["small_lstm_bias_std"])),
+                                  int(g["small_seed"]), float(g["small_logit_std"]))):
+        probe = synth.synthetic_features(96, seed=seed + 2)
+        _, _, taps = oracle.forward(wset, probe, "f64", taps=True)
+        head = W.centred_head(taps["fc1"], wset["dense_1/kernel"][:, 0], std, seed + 3)
+        assert np.array_equal(head, g[tag + "_head"]), tag
