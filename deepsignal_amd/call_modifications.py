@@ -166,6 +166,7 @@ def load_model_weights(model_path: str, kmer_len: int, cent_signals_len: int, cl
     return None
 
 
+COLLECTIVE_TIMEOUT_S = 600.0      # process-group timeout of a multi-GPU call_mods (see _distributed_context)
 ENGINE_BATCH = {"fp32": 512, "bf16": 4096, "bf16_all": 4096}      # sites per forward the engine is created for (see make_engine)
 
 
@@ -200,12 +201,16 @@ def _distributed_context(dist):
     import torch.distributed as tdist
     local = int(os.environ.get("LOCAL_RANK", os.environ.get("RANK", "0")))
     if not tdist.is_initialized():
+        import datetime
         import torch
+        # an explicit timeout on every collective of the job: a peer that never joins (crashed rank, wrong WORLD_SIZE) ends
+        # the run with an error -- RCCL's watchdog aborts the process, gloo raises -- instead of hanging the row gather
+        timeout = datetime.timedelta(seconds=COLLECTIVE_TIMEOUT_S)
         if torch.cuda.device_count() > 0:
             torch.cuda.set_device(local)
-            tdist.init_process_group("nccl")           # RCCL over xGMI
+            tdist.init_process_group("nccl", timeout=timeout)           # RCCL over xGMI
         else:
-            tdist.init_process_group("gloo")
+            tdist.init_process_group("gloo", timeout=timeout)
     return tdist, tdist.get_rank(), tdist.get_world_size(), local
 
 
