@@ -206,11 +206,18 @@ def _distributed_context(dist):
         # an explicit timeout on every collective of the job: a peer that never joins (crashed rank, wrong WORLD_SIZE) ends
         # the run with an error -- RCCL's watchdog aborts the process, gloo raises -- instead of hanging the row gather
         timeout = datetime.timedelta(seconds=COLLECTIVE_TIMEOUT_S)
-        if torch.cuda.device_count() > 0:
+        ngpu = torch.cuda.device_count()
+        # DS_DIST_BACKEND=gloo (read by this Python harness only, never by the library): the collectives on host tensors and
+        # the ranks dealt round-robin over the GPUs that exist -- how the launcher route is tested with two ranks on the one
+        # GPU of a test box; the product default is one rank per GPU on RCCL
+        backend = os.environ.get("DS_DIST_BACKEND") or ("nccl" if ngpu > 0 else "gloo")
+        if backend == "nccl":
             torch.cuda.set_device(local)
             tdist.init_process_group("nccl", timeout=timeout)           # RCCL over xGMI
         else:
-            tdist.init_process_group("gloo", timeout=timeout)
+            if ngpu > 0:
+                local = local % ngpu
+            tdist.init_process_group(backend, timeout=timeout)
     return tdist, tdist.get_rank(), tdist.get_world_size(), local
 
 

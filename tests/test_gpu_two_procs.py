@@ -123,3 +123,17 @@ def test_bench_timed_windows_across_two_ranks_on_one_gpu(tmp_path):
     assert r["value"] > 1e5          # two engines sharing one GPU: about the one-GPU rate in total
     with open(os.path.join(str(tmp_path), "bench_two_ranks_one_gpu.json"), "w") as f:
         f.write(lines[0])
+
+
+def test_the_cli_itself_under_the_launcher_with_two_ranks(job):
+    """INTEGRATION.md's multi-GPU command line, verbatim but for the rank count: `python -m torch.distributed.run --nproc-per-node
+    2 -m deepsignal_amd.deepsignal call_mods -i ... -m ... -o ...` -- argument parsing, the launcher environment picked up by
+    call_mods (`_distributed_context`), engines created per rank, the sharded route, rank 0's file. DS_DIST_BACKEND=gloo puts
+    the collectives on host tensors and both ranks on GPU 0 (a test box has one GPU; the product default is RCCL, one rank
+    per GPU)."""
+    out = os.path.join(job["tmp"], "cli_two_ranks.tsv")
+    res, dt = _launch(2, ["-m", "deepsignal_amd.deepsignal", "call_mods", "--input_path", job["tsv"], "--model_path", job["wfile"],
+                          "--result_file", out], timeout=600, extra_env={"DS_DIST_BACKEND": "gloo"})
+    assert res.returncode == 0, res.stderr.decode()[-3000:]
+    assert open(out, "rb").read() == open(job["plain"], "rb").read()
+    assert res.stdout.decode().count("call_mods costs") == 1            # rank 0 reports, the other rank stays quiet
