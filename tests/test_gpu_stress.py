@@ -217,3 +217,28 @@ def test_extreme_logits_do_not_break_sigmoid_or_argmax(stress_weights):
         assert (pred[far] == np.argmax(t64["logits"], axis=1)[far]).all()
         assert float(np.abs(act - a64).max()) <= 2e-3        # logits' fp32 noise x 40 moves the few unsaturated outputs
         eng.close()
+
+
+@pytest.mark.parametrize("variant", [dict(kmer_len=9, signal_len=100), dict(kmer_len=21, signal_len=128), dict(is_cnn=False),
+                                     dict(is_rnn=False), dict(is_base=False)])
+def test_trained_regime_on_other_geometries_and_model_variants(variant):
+    """The stress scale (LSTM kernels x 3.5, bias std 0.6, hot BN channels) on the CLI's other shapes (--kmer_len /
+    --cent_signals_len, deepsignal.py:258-263) and on the Model(is_cnn, is_rnn, is_base) switches (model.py:28-29,59-75,89-95):
+    the head is centred here, from the float64 oracle's fc1 of a probe batch, so both labels occur; same bars as above."""
+    from deepsignal_amd import weights as W
+    from oracle import oracle
+    geom = {k: v for k, v in variant.items() if k in ("kmer_len", "signal_len")}
+    w = W.stress_weights(777, **variant)
+    probe = synth.synthetic_features(96, seed=778, **geom)
+    _, _, taps = oracle.forward(w, probe, "f64", taps=True, **variant)
+    W.install_head(w, W.centred_head(taps["fc1"], w["dense_1/kernel"][:, 0], 3.5, 779))
+    n = 200
+    feats = synth.synthetic_features(n, seed=780, **geom)
+    a64, p64 = oracle.forward(w, feats, "f64", **variant)
+    a32, _ = oracle.forward(w, feats, "f32", **variant)
+    for fold in (True, False):
+        eng = _engine(w, max_batch=256, fold_fc=fold, **variant)
+        act, pred = eng.run(*(feats[k] for k in KEYS))
+        d_act, d_pn, share = _check_outputs_f64(act, pred, a64, p64)
+        eng.close()
+        print("\n%s fold=%s: |d act| %.2e (fp32 oracle %.2e), label-1 share %.2f" % (variant, fold, d_act, float(np.abs(a32 - a64).max()), share))
