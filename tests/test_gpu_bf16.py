@@ -271,3 +271,37 @@ def test_bf16_all_other_geometries_and_ragged_batches(geom, batch):
     assert np.array_equal(a2, act[sel]) and np.array_equal(p2, pred[sel])
     eng.close()
 
+
+
+@pytest.mark.parametrize("precision", ["bf16", "bf16_all"])
+def test_bf16_layerwise_vs_emulated_statement_on_the_stress_set(stress_weights, precision):
+    """The exactness bar of the first test of this file -- every stored tensor within a few bf16 ulps of the CPU statement that
+    rounds at the engine's rounding points -- on the trained-regime weights: larger activations (hot BN channels), saturating
+    LSTM gates. The sigmoid outputs are NOT held to 3e-3 here: one flipped bf16 rounding upstream moves a centred read-out by
+    ~1e-2 (that is the tolerance-vs-fp32 story of the test above); the taps are what shows the implementation is right."""
+    n = 64
+    feats = synth.synthetic_features(n, seed=321)
+    eng = _engine(stress_weights, max_batch=160, debug=True, precision=precision)
+    act, pred = eng.run(feats["kmer"], feats["means"], feats["stds"], feats["sanums"], feats["signals"])
+    e_act, e_pred, taps = torch_statement.forward_bf16(stress_weights, feats, return_taps=True, lstm_bf16=precision == "bf16_all")
+    bad, worst = {}, {}
+    for name, ref in taps.items():
+        if name in ("fc1", "logits", "joint"):
+            continue
+        got = eng.intermediate(name, ref.shape)
+        err = float(np.abs(got - ref).max())
+        if name.startswith("lstm_") and precision == "bf16":
+            tol, mean_tol = 5e-5, None                                   # fp32 BiLSTM (saturating: fp32 noise ~1e-5)
+        else:
+            u = _ulp(max(1.0, float(np.abs(ref).max())))
+            tol, mean_tol = EMU_TAP_TOL_ULPS * u, EMU_TAP_MEAN_ULPS * u
+        worst[name] = (err, tol)
+        if not err <= tol:
+            bad[name] = (err, tol)
+        if mean_tol is not None and not float(np.abs(got - ref).mean()) <= mean_tol:
+            bad[name + ":mean"] = (float(np.abs(got - ref).mean()), mean_tol)
+    print("\n%s stress taps (max err, tol):" % precision, {k: ("%.2e" % v[0], "%.2e" % v[1]) for k, v in worst.items() if k in ("stem_conv3", "module1", "module6", "module11", "lstm_fw_l2")})
+    print("   outputs: max |d act| vs the emulation %.3e, share of sites within 1e-6: %.2f" % (float(np.abs(act - e_act).max()), float((np.abs(act - e_act).max(axis=1) < 1e-6).mean())))
+    assert not bad, bad
+    assert np.isfinite(act).all() and float(np.abs(act - e_act).max()) <= 0.1
+    eng.close()
