@@ -701,8 +701,14 @@ def main():
         if not args.no_host_path:
             fm["pcie_inclusive"] = pcie_inclusive(engf, feats, max(K, 64), BATCH)
             fm["ds_forward_blocking"] = forward_blocking(engf, feats, BATCH)
-            fm["e2e_tsv"] = e2e_tsv(engf, feats, 163840, BATCH)
-            result["e2e_tsv"] = dict(fm["e2e_tsv"], engine="default (folded joint model), as `deepsignal call_mods` runs")
+            # end to end as the CLI runs it: call_mods creates its engine for ENGINE_BATCH sites per forward whatever --batch_size
+            # says (a site's result does not depend on its batch mates) and fills whole engine batches across queue items
+            from deepsignal_amd import call_modifications as _cm
+            enge = Engine(device=gpu_index, max_batch=_cm.ENGINE_BATCH["fp32"])
+            enge.load_weights(w)
+            fm["e2e_tsv"] = e2e_tsv(enge, feats, 163840, BATCH)
+            enge.close()
+            result["e2e_tsv"] = dict(fm["e2e_tsv"], engine="default (folded joint model), created as `deepsignal call_mods` creates it")
         result["fast_mode_folded"] = fm
         engf.close()
     eng.close()

@@ -167,7 +167,10 @@ def load_model_weights(model_path: str, kmer_len: int, cent_signals_len: int, cl
 
 
 COLLECTIVE_TIMEOUT_S = 600.0      # process-group timeout of a multi-GPU call_mods (see _distributed_context)
-ENGINE_BATCH = {"fp32": 512, "bf16": 4096, "bf16_all": 4096}      # sites per forward the engine is created for (see make_engine)
+# sites per forward the engine is created for (see make_engine). TSV -> TSV on MI355X, 327,680 rows (tools/e2e_profile.py): fp32
+# 505 / 504 / 526 / 532 k sites/s at 512 / 1024 / 2048 / 4096 (fewer, larger H2D copies and Python round trips per site; the
+# resident-input rate itself gains 2 %); bf16_all 1.3 M at 512 against 1.9 M at 4096
+ENGINE_BATCH = {"fp32": 4096, "bf16": 4096, "bf16_all": 4096}
 
 
 def make_engine(model_path: str, kmer_len: int, cent_signals_len: int, class_num: int, batch_size: int,
@@ -178,8 +181,8 @@ def make_engine(model_path: str, kmer_len: int, cent_signals_len: int, class_num
     weights = load_model_weights(model_path, kmer_len, cent_signals_len, class_num, is_cnn, is_rnn, is_base)
     # `batch_size` is the reference's rows-per-sess.run (call_modifications.py:157-166); a site's result does not depend on
     # its batch mates (tests: the same bits alone, in a sub-batch, in a full batch), so the engine is sized for the batch the
-    # GPU wants -- ENGINE_BATCH -- and the row pipeline fills THAT: 512 sites keep the fp32 engine at its rate, the bf16 modes
-    # need 4096 (3.3 M against 2.6 M sites/s)
+    # GPU wants -- ENGINE_BATCH -- and the row pipeline fills THAT (the bf16 modes need 4096 sites for their 3.3 M sites/s, 2.6 M at
+    # 512; fp32 end to end gains 5 % from the larger copies)
     eng = Engine(kmer_len=kmer_len, signal_len=cent_signals_len, class_num=class_num, device=device,
                  max_batch=max(batch_size, ENGINE_BATCH.get(precision, batch_size)), is_cnn=is_cnn, is_rnn=is_rnn,
                  is_base=is_base, precision=precision)
