@@ -503,6 +503,11 @@ def call_mods(input_path, model_path, result_file, kmer_len, cent_signals_len,
     start = time.time()
     f5 = _unpack_f5_args(f5_args, f5_batch_num)
     dist, rank, world, local = _distributed_context(dist)
+    if precision != "fp32" and rank == 0 and engine is None:
+        # measured, DESIGN.md section 9: harmless on random-init weights, NOT on weights at a trained model's scale
+        print("note: --precision %s stores activations as bf16: on trained-scale weights expect probabilities to move by ~0.02 (up "
+              "to ~0.2) and a few per cent of the calls nearest the threshold to change label; fp32 is the reference numerics"
+              % precision, file=sys.stderr)
     device = None
     if dist is not None and (world > 1 or force_sharded) and dist.get_backend() == "nccl":
         import torch
