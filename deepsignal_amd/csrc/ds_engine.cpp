@@ -41,6 +41,7 @@ struct PackedGemm {      // device-resident packed weights of one GEMM
     float* Bp = nullptr;
     float* bias = nullptr;
     int K = 0, N = 0;
+    float* Bps = nullptr;   // DS_PRECISION_BF16X3: the same matrix as three bf16 term panels (pack_b_split)
 };
 
 enum OpKind { OP_GEMM, OP_STEM1, OP_MAXPOOL, OP_AVGPOOL, OP_HEAD, OP_FUSED, OP_PACKEV, OP_LSTM, OP_STEM23, OP_HEADF };
@@ -70,7 +71,7 @@ struct Op {
 
 // per-kernel accumulators (one entry per __global__ function / template instantiation)
 enum KernelClass { K_GEMM_CONV = 0, K_GEMM_FC, K_GEMM_LSTM, K_GEMM_CONV_WIDE, K_GEMM_CONV_POOL, K_GEMM_FC_DENSE, K_GEMM_LSTM_DENSE, K_FUSED1, K_FUSED2, K_FUSED3, K_STEM1, K_MAXPOOL, K_AVGPOOL, K_HEAD,
-                   K_GEMM_BCONV, K_GEMM_BCONV_POOL, K_GEMM_BFC, K_GEMM_BFC_DENSE, K_PACKEV, K_GEMM_BLSTM, K_GEMM_BLSTM_DENSE, K_FUSEDB1, K_FUSEDB2, K_FUSEDB3, K_GEMM_LSTM_T, K_GEMM_LSTM_T_DENSE, K_GEMM_BLSTM_T, K_GEMM_BLSTM_T_DENSE, K_LSTM_CELL1, K_LSTM_CELL2, K_LSTM_CELL4, K_LSTM_LDS1, K_LSTM_LDS2, K_STEM23, K_HEADF, K_LSTM_B11, K_LSTM_B12, K_LSTM_B22, K_STEM23B, K_COUNT };
+                   K_GEMM_BCONV, K_GEMM_BCONV_POOL, K_GEMM_BFC, K_GEMM_BFC_DENSE, K_PACKEV, K_GEMM_BLSTM, K_GEMM_BLSTM_DENSE, K_FUSEDB1, K_FUSEDB2, K_FUSEDB3, K_GEMM_LSTM_T, K_GEMM_LSTM_T_DENSE, K_GEMM_BLSTM_T, K_GEMM_BLSTM_T_DENSE, K_LSTM_CELL1, K_LSTM_CELL2, K_LSTM_CELL4, K_LSTM_LDS1, K_LSTM_LDS2, K_STEM23, K_HEADF, K_LSTM_B11, K_LSTM_B12, K_LSTM_B22, K_STEM23B, K_FUSEDS1, K_FUSEDS2, K_FUSEDS3, K_COUNT };
 const char* const kKernelNames[K_COUNT] = {"gemm_kernel<1,2,4,1,0,0,1,1>", "gemm_kernel<1,3,4,1,0,0,2,1>", "gemm_kernel<1,4,4,1,1,0,1,1>",
                                            "gemm_kernel<2,2,2,2,0,0,1,1>", "gemm_kernel<1,2,4,1,0,1,1,1>", "gemm_kernel<1,3,4,1,0,2,2,1>",
                                            "gemm_kernel<1,4,4,1,1,2,1,1>", "inception_fused_kernel<1>",
@@ -85,7 +86,8 @@ const char* const kKernelNames[K_COUNT] = {"gemm_kernel<1,2,4,1,0,0,1,1>", "gemm
                                            "gemm_kernel<1,1,4,1,2,0,3,1,bf16>", "gemm_kernel<1,1,4,1,2,2,3,1,bf16>",
                                            "lstm_cell_kernel<1>", "lstm_cell_kernel<2>", "lstm_cell_kernel<4>",
                                            "lstm_cell_lds_kernel<1>", "lstm_cell_lds_kernel<2>", "stem23_kernel", "head_folded_kernel",
-                                           "lstm_cell_bf16_kernel<1,1>", "lstm_cell_bf16_kernel<1,2>", "lstm_cell_bf16_kernel<2,2>", "stem23_bf16_kernel"};
+                                           "lstm_cell_bf16_kernel<1,1>", "lstm_cell_bf16_kernel<1,2>", "lstm_cell_bf16_kernel<2,2>", "stem23_bf16_kernel",
+                                           "inception_fused_split_kernel<1>", "inception_fused_split_kernel<2>", "inception_fused_split_kernel<3>"};
 struct KernelStat {
     int64_t launches = 0;
     double total_ms = 0;
@@ -153,6 +155,8 @@ struct ds_handle {
     int B = 512;
     bool is_cnn = true, is_rnn = true, is_base = true;   // model.py:28-29,59-75,89-95
     bool bf16 = false;    // DS_PRECISION_BF16: bf16 conv + FC operands (fp32 accumulate), fp32 BiLSTM
+    bool split = false;   // DS_PRECISION_BF16X3: fp32 activations / weights carried as three bf16 terms through the bf16 matrix pipe
+                          // (six products per MAC, fp32 accumulate) in the fused inception chains; everything else as fp32
     int lstm_variant = 0;     // ds_config.reserved[3] as given (DS_LSTM_TILING_*)
     // per-handle tuning / diagnostic knobs, all from ds_config.reserved[2..5] (include/deepsignal_hip.h)
     bool no_fused = false;    // DS_TUNE_NO_FUSED: layer-granular inception modules instead of the fused kernel
@@ -288,6 +292,38 @@ std::vector<float> pack_b_bf16(int K, int N, const std::function<float(int, int)
     return raw;
 }
 
+// Split-operand packing (DS_PRECISION_BF16X3, ds_split.hip): every weight w as three bf16 terms t0 = bf16(w), t1 = bf16(w - t0),
+// t2 = bf16(w - t0 - t1) (the differences are exact in fp32, the terms sum to w exactly); layout [ntile][kstep of 16][term][lane][8 bf16],
+// i.e. pack_b_bf16's fragments with the three terms of a k-step next to each other (3 KiB per wave and k-step, contiguous).
+std::vector<float> pack_b_split(int K, int N, const std::function<float(int, int)>& w_in)
+{
+    const int Kp = (K + 63) / 64 * 64;
+    const int ntiles = (N + 31) / 32, ks = Kp / 16;
+    std::vector<uint16_t> out((size_t)ntiles * ks * 3 * 64 * 8, 0);
+    for (int nt = 0; nt < ntiles; ++nt)
+        for (int g = 0; g < ks; ++g)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int col = nt * 32 + (lane & 31);
+                if (col >= N) continue;
+                const int k0 = g * 16 + 8 * (lane >> 5);
+                for (int q = 0; q < 8; ++q) {
+                    if (k0 + q >= K) continue;
+                    float r = w_in(k0 + q, col);
+                    for (int t = 0; t < 3; ++t) {
+                        const uint16_t b = f32_to_bf16(r);
+                        out[((((size_t)nt * ks + g) * 3 + t) * 64 + lane) * 8 + q] = b;
+                        uint32_t u = (uint32_t)b << 16;
+                        float f;
+                        memcpy(&f, &u, 4);
+                        r -= f;
+                    }
+                }
+            }
+    std::vector<float> raw(out.size() / 2);
+    memcpy(raw.data(), out.data(), out.size() * 2);
+    return raw;
+}
+
 struct FoldedConv {     // BN folded into the kernel: y = conv(x, w') + b'   (layers.py:80-84)
     int k, cin, cout;
     std::vector<float> w;   // [k*cin][cout]
@@ -327,7 +363,7 @@ int fold_conv(ds_handle* h, const std::string& scope, const std::string& conv, c
 }
 
 // upload a GEMM whose columns are the concatenation of several folded convs with identical K
-int upload_concat(ds_handle* h, const std::vector<const FoldedConv*>& parts, PackedGemm* pg)
+int upload_concat(ds_handle* h, const std::vector<const FoldedConv*>& parts, PackedGemm* pg, bool split_panel = false)
 {
     const int K = parts[0]->k * parts[0]->cin;
     int N = 0;
@@ -350,6 +386,7 @@ int upload_concat(ds_handle* h, const std::vector<const FoldedConv*>& parts, Pac
     pg->K = h->bf16 ? (K + 1) / 2 : K; pg->N = N;
     int rc = upload(h, &pg->Bp, packed);
     if (rc) return rc;
+    if (split_panel && (rc = upload(h, &pg->Bps, pack_b_split(K, N, wfun)))) return rc;
     return upload(h, &pg->bias, bias);
 }
 
@@ -391,11 +428,11 @@ int finalize_weights(ds_handle* h)
         // the five 1x1 convs that read the module input share one GEMM: [b2 | b5s | b3a | b4a | b5a]
         if ((rc = upload_concat(h, {&b2, &b5s, &b3a, &b4a, &b5a}, &h->m_s1[m]))) return rc;
         if ((rc = upload_concat(h, {&b1}, &h->m_b1[m]))) return rc;
-        if ((rc = upload_concat(h, {&b5s, &b2, &b3a, &b4a, &b5a, &b1}, &h->m_f1[m]))) return rc;
-        if ((rc = upload_concat(h, {&b3b}, &h->m_b3b[m]))) return rc;
-        if ((rc = upload_concat(h, {&b4b}, &h->m_b4b[m]))) return rc;
-        if ((rc = upload_concat(h, {&b5b}, &h->m_b5b[m]))) return rc;
-        if ((rc = upload_concat(h, {&b5c}, &h->m_b5c[m]))) return rc;
+        if ((rc = upload_concat(h, {&b5s, &b2, &b3a, &b4a, &b5a, &b1}, &h->m_f1[m], h->split))) return rc;
+        if ((rc = upload_concat(h, {&b3b}, &h->m_b3b[m], h->split))) return rc;
+        if ((rc = upload_concat(h, {&b4b}, &h->m_b4b[m], h->split))) return rc;
+        if ((rc = upload_concat(h, {&b5b}, &h->m_b5b[m], h->split))) return rc;
+        if ((rc = upload_concat(h, {&b5c}, &h->m_b5c[m], h->split))) return rc;
     }
     }
     if (h->is_rnn) {
@@ -710,11 +747,15 @@ int build_plan(ds_handle* h, int n, Plan* plan)
             op.fa.X = x; op.fa.Y = y; op.fa.n_sites = n; op.fa.W = W; op.fa.cin = bf ? 128 : cin; op.fa.spt = best_spt;   // bf16: row pitch in units
             op.fa.pool_win = pend_pool_win; op.fa.pool_pad = pend_pool_pad;
             pend_pool_win = 0;
-            op.fa.Bp1 = h->m_f1[m].Bp; op.fa.bias1 = h->m_f1[m].bias;
-            op.fa.Bp3b = h->m_b3b[m].Bp; op.fa.bias3b = h->m_b3b[m].bias;
-            op.fa.Bp4b = h->m_b4b[m].Bp; op.fa.bias4b = h->m_b4b[m].bias;
-            op.fa.Bp5b = h->m_b5b[m].Bp; op.fa.bias5b = h->m_b5b[m].bias;
-            op.fa.Bp5c = h->m_b5c[m].Bp; op.fa.bias5c = h->m_b5c[m].bias;
+            // DS_PRECISION_BF16X3: the split-operand kernel (ds_split.hip) on the three-term panels; a module whose input is
+            // not a whole number of 16-channel chunks of 240 / 256 channels does not exist in this network
+            const bool sp = h->split && (cin == 240 || cin == 256) && inception_fused_split_lds_bytes(op.tm, W, best_spt) <= 160 * 1024;
+            op.d = sp ? 3 : 0;
+            op.fa.Bp1 = sp ? h->m_f1[m].Bps : h->m_f1[m].Bp; op.fa.bias1 = h->m_f1[m].bias;
+            op.fa.Bp3b = sp ? h->m_b3b[m].Bps : h->m_b3b[m].Bp; op.fa.bias3b = h->m_b3b[m].bias;
+            op.fa.Bp4b = sp ? h->m_b4b[m].Bps : h->m_b4b[m].Bp; op.fa.bias4b = h->m_b4b[m].bias;
+            op.fa.Bp5b = sp ? h->m_b5b[m].Bps : h->m_b5b[m].Bp; op.fa.bias5b = h->m_b5b[m].bias;
+            op.fa.Bp5c = sp ? h->m_b5c[m].Bps : h->m_b5c[m].Bp; op.fa.bias5c = h->m_b5c[m].bias;
             op.fa.dbg = h->dbg_stamps ? h->dbg_stamps + (size_t)m * 1024 * 16 : nullptr;
             op.fa.write_rows = 1;
             op.flops = 2.0 * M * ((double)cin * 240 + 96 * 48 + 160 * 48 + 96 * 64 + 64 * 48);
@@ -724,7 +765,7 @@ int build_plan(ds_handle* h, int n, Plan* plan)
             // chain (ds_internal.h FusedChain). Stage times of a chain are booked on its first module.
             Op* prev = (!cnn.empty() && cnn.back().kind == OP_FUSED) ? &cnn.back() : nullptr;
             if (prev && prev->fc.nmod < FUSED_CHAIN_MAX && op.fa.pool_win == 0 && prev->fa.W == W && prev->fa.spt == best_spt &&
-                prev->tm == op.tm && prev->fc.m[prev->fc.nmod - 1].Y == op.fa.X && op.fa.Y != prev->fc.m[0].X && !h->serial_modules) {
+                prev->tm == op.tm && prev->d == op.d && prev->fc.m[prev->fc.nmod - 1].Y == op.fa.X && op.fa.Y != prev->fc.m[0].X && !h->serial_modules) {
                 // bf16: rows of a chain's inner modules never leave the CU (unless the taps of debug mode want them)
                 if (bf && !h->debug) prev->fc.m[prev->fc.nmod - 1].write_rows = 0;
                 prev->fc.m[prev->fc.nmod++] = op.fa;
@@ -785,7 +826,7 @@ int build_plan(ds_handle* h, int n, Plan* plan)
         x = y; cin = INC_OUT;
         if (m == 2 || m == 7) {   // maxpool_layer2/3                            layers.py:211-213,224-226
             const int wout = m == 2 ? h->wb : h->wc, pad = m == 2 ? h->pl_pool2 : h->pl_pool3;
-            if (!h->no_fused && wout <= 96 && !h->debug_keep_pool) {
+            if (!h->no_fused && wout <= 96 && !h->debug_keep_pool && !h->split) {      // (the split-operand kernel reads plain rows)
                 pend_pool_win = W; pend_pool_pad = pad;      // folded into module m+2's staging: no launch, no buffer
             } else {
                 Op op{};
@@ -987,6 +1028,7 @@ int issue_op(ds_handle* h, Plan& plan, const Op& op, hipStream_t s)
         break;
     case OP_FUSED:
         if (h->bf16) HIPCHK(h, launch_inception_fused_bf16(op.tm, op.fc, s));
+        else if (op.d == 3) HIPCHK(h, launch_inception_fused_split(op.tm, op.fc, s));
         else HIPCHK(h, launch_inception_fused(op.tm, op.fc, s));
         break;
     case OP_HEAD:
@@ -1069,6 +1111,7 @@ int kernel_class(const Op& op)
                : op.cfg == CFG_BFC_DENSE ? K_GEMM_BFC_DENSE : K_GEMM_CONV_WIDE;
     case OP_FUSED:
         if (op.fa.cin == 128) return op.tm == 1 ? K_FUSEDB1 : op.tm == 2 ? K_FUSEDB2 : K_FUSEDB3;   // bf16 rows: pitch in units
+        if (op.d == 3) return op.tm == 1 ? K_FUSEDS1 : op.tm == 2 ? K_FUSEDS2 : K_FUSEDS3;          // split operands (three terms)
         return op.tm == 1 ? K_FUSED1 : op.tm == 2 ? K_FUSED2 : K_FUSED3;
     case OP_STEM1: return K_STEM1;
     case OP_STEM23: return op.a ? K_STEM23B : K_STEM23;
@@ -1236,8 +1279,11 @@ static int ds_create_impl(const ds_config* cfg, ds_handle** out)
     *out = nullptr;
     if (!(cfg->is_cnn || cfg->is_rnn))
         return fail(nullptr, DS_ERR_INVALID, "at least one of is_cnn/is_rnn should be True");      // model.py:28-29
-    if (cfg->precision != DS_PRECISION_FP32 && cfg->precision != DS_PRECISION_BF16 && cfg->precision != DS_PRECISION_BF16_ALL)
-        return fail(nullptr, DS_ERR_UNSUPPORTED, "precision must be DS_PRECISION_FP32, DS_PRECISION_BF16 or DS_PRECISION_BF16_ALL");
+    if (cfg->precision != DS_PRECISION_FP32 && cfg->precision != DS_PRECISION_BF16 && cfg->precision != DS_PRECISION_BF16_ALL &&
+        cfg->precision != DS_PRECISION_BF16X3)
+        return fail(nullptr, DS_ERR_UNSUPPORTED, "precision must be DS_PRECISION_FP32, DS_PRECISION_BF16, DS_PRECISION_BF16_ALL or DS_PRECISION_BF16X3");
+    if (cfg->precision == DS_PRECISION_BF16X3 && (cfg->reserved[2] & DS_TUNE_NO_FUSED))
+        return fail(nullptr, DS_ERR_UNSUPPORTED, "DS_PRECISION_BF16X3 runs the fused inception kernels only (DS_TUNE_NO_FUSED asks for the layer-granular fp32 path)");
     if (cfg->kmer_len < 1 || cfg->kmer_len > 255 || (cfg->kmer_len & 1) == 0)
         return fail(nullptr, DS_ERR_INVALID, "kmer_len must be odd and in [1,255]");
     if (cfg->signal_len < 16 || cfg->class_num < 1 || cfg->class_num > 16)
@@ -1262,6 +1308,7 @@ static int ds_create_impl(const ds_config* cfg, ds_handle** out)
     h->J = (h->is_rnn ? 2 * HID : 0) + (h->is_cnn ? h->SF : 0);     // layers.py:248-255
     h->bf16 = cfg->precision == DS_PRECISION_BF16 || cfg->precision == DS_PRECISION_BF16_ALL;
     h->lstm_bf16 = cfg->precision == DS_PRECISION_BF16_ALL && h->is_rnn;
+    h->split = cfg->precision == DS_PRECISION_BF16X3;
     // tuning / diagnostic knobs live in the handle's own config (no process-global state): reserved[2] = flags,
     // reserved[3] = LSTM tiling override, reserved[4] / [5] = fused-module tile bounds
     const int32_t flags = cfg->reserved[2];
@@ -1279,6 +1326,7 @@ static int ds_create_impl(const ds_config* cfg, ds_handle** out)
 #define CK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { fail(nullptr, DS_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); ds_destroy(h); return DS_ERR_HIP; } } while (0)
     CK(hipSetDevice(cfg->device));
     CK(configure_fused_kernels());
+    CK(configure_split_kernels());
     // reserved[1] = forwards in flight (pipeline slots); 0 -> default
     // (the bf16 modes: a 512-site forward is ~0.2 ms, four in flight measured 2.60 M sites/s against 2.51 M with eight)
     int nslots = cfg->reserved[1] > 0 ? cfg->reserved[1] : (h->B <= 1024 && !h->bf16 ? 8 : 4);

@@ -49,7 +49,7 @@ class DsConfig(ctypes.Structure):
 
 # ds_config.precision (include/deepsignal_hip.h): "bf16" = bf16 conv + FC operands with fp32 accumulation, fp32 BiLSTM;
 # "bf16_all" = also bf16 h / weight operands in the LSTM matmuls (fp32 accumulate, gates, cell state)
-PRECISIONS = {"fp32": 0, "bf16": 1, "bf16_all": 2}
+PRECISIONS = {"fp32": 0, "bf16": 1, "bf16_all": 2, "bf16x3": 3}
 TUNE_NO_FUSED, TUNE_SERIAL, TUNE_DEBUG_STAMPS, TUNE_NO_FOLD_FC, TUNE_NO_CHAIN = 1, 2, 4, 8, 16     # ds_config.reserved[2]
 LSTM_TILINGS = {"auto": 0, "narrow": 1, "wide": 2, "lds1": 3, "lds2": 4}     # ds_config.reserved[3]
 

@@ -37,6 +37,14 @@ extern "C" {
  * accumulation, gate non-linearities and the cell state c stay fp32, and the layer-0 input projection stays an
  * fp32 table lookup ("fp32 LSTM state/accumulate" reading of configs[2]). */
 #define DS_PRECISION_BF16_ALL 2
+/* fp32-class results on the bf16 matrix pipe: fp32 activations and weights are carried as THREE bf16 terms
+ * (t0 = bf16(x), t1 = bf16(x - t0), t2 = bf16(x - t0 - t1): 24 significant bits, exact) and a product is the fp32-accumulated
+ * sum of six bf16 x bf16 term products (the three dropped ones lie below 2^-24 of it). gfx950 runs fp32 MFMAs at 1/16 of the
+ * bf16 rate and has no tf32 form, so six products cost 0.375 of the native fp32 matrix time. Stored activations, biases, ReLU,
+ * pools, the residual add, gates and the head are fp32 as in DS_PRECISION_FP32, and the mode is held to the SAME parity bars as
+ * DS_PRECISION_FP32 (tests/test_gpu_split.py; CPU statement oracle/torch_statement.py::forward_split). Which layers run
+ * split is listed by ds_version() / DESIGN.md section 11; the rest runs the DS_PRECISION_FP32 kernels. */
+#define DS_PRECISION_BF16X3 3
 
 typedef struct ds_handle ds_handle;
 
@@ -49,7 +57,7 @@ typedef struct ds_config {
     int32_t is_rnn;
     int32_t is_base;
     int32_t device;       /* HIP device ordinal */
-    int32_t precision;    /* DS_PRECISION_FP32 | DS_PRECISION_BF16 | DS_PRECISION_BF16_ALL */
+    int32_t precision;    /* DS_PRECISION_FP32 | DS_PRECISION_BF16 | DS_PRECISION_BF16_ALL | DS_PRECISION_BF16X3 */
     int32_t max_batch;    /* largest n per device pass (workspaces are sized for it); larger n is looped */
     int32_t reserved[7];  /* reserved[0] != 0: debug mode — keep every module output for ds_get_intermediate;
                              reserved[1]: forwards in flight for ds_forward_device / ds_submit (pipeline slots, each

@@ -1,4 +1,4 @@
-"""VGPRs, scratch and static LDS of every kernel in deepsignal_amd/csrc/ds_kernels.hip (hipcc -S, device only, ~40 s).
+"""VGPRs, scratch and static LDS of every kernel in deepsignal_amd/csrc/*.hip (hipcc -S, device only, ~40 s; DS_KERNEL_SOURCES="ds_split.hip" restricts the files).
 
 Two of the numbers carry a property the 512-site throughput depends on ("Sharing a CU"): the fused inception
 module must stay at <= 184 VGPRs and the BiLSTM cell kernel at <= 96 (88 today), so that two module waves and one cell
@@ -12,12 +12,15 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
 
 def kernel_resources():
-    src = os.path.join(ROOT, "deepsignal_amd", "csrc", "ds_kernels.hip")
+    text = ""
+    only = os.environ.get("DS_KERNEL_SOURCES", "ds_kernels.hip ds_split.hip").split()
     with tempfile.TemporaryDirectory() as tmp:
-        out = os.path.join(tmp, "k.s")
-        subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-unused-value", "--cuda-device-only", "-S",
-                        "-x", "hip", "-o", out, src], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-        text = open(out).read()
+        for i, name in enumerate(only):
+            src = os.path.join(ROOT, "deepsignal_amd", "csrc", name)
+            out = os.path.join(tmp, "k%d.s" % i)
+            subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-unused-value", "--cuda-device-only", "-S",
+                            "-x", "hip", "-o", out, src], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            text += open(out).read()
     res = {}
     for m in re.finditer(r"\.amdhsa_kernel (\S+)\n(.*?)\.end_amdhsa_kernel", text, re.S):
         body = m.group(2)

@@ -3,9 +3,12 @@ sys.path.insert(0, os.getcwd())
 import numpy as np
 from deepsignal_amd import synth, weights as W
 from deepsignal_amd.engine import Engine
+"""In-kernel phase stamps of the fused inception kernels. usage: python tools/stamps.py [precision=fp32] [batch=512]"""
+prec = sys.argv[1] if len(sys.argv) > 1 else "fp32"
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 512
 w = W.random_weights(seed=1)
-e = Engine(max_batch=512, serial=True, debug_stamps=True); e.load_weights(w)
-f = synth.synthetic_features(512, seed=2)
+e = Engine(max_batch=B, serial=True, debug_stamps=True, precision=prec); e.load_weights(w)
+f = synth.synthetic_features(B, seed=2)
 args = [f[k] for k in ("kmer", "means", "stds", "sanums", "signals")]
 for _ in range(3): e.run(*args)
 names = ["(n)", "zero+stage0", "sync", "P1epi", "sync", "P2a", "sync", "P2b"]
