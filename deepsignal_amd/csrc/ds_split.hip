@@ -70,6 +70,7 @@ constexpr int S_LDP = 208;      // staged chunk row: 6 x 32 B + 16
 constexpr int S_LD1 = 592;      // T1 row: 3 terms x 96 channels x 2 B + 16
 constexpr int S_LD2 = 400;      // T2 row: 3 terms x 64 channels x 2 B + 16
 constexpr int S_LDY = 400;      // b1|b2 output tile row: 96 floats + 4
+constexpr int S_LDR = 80;       // raw fp32 chunk row: 16 floats + 16 B
 constexpr int S_T1P = 192;      // bytes between the terms of a T1 row
 constexpr int S_T2P = 128;      // ... of a T2 row
 
@@ -110,9 +111,69 @@ __device__ __forceinline__ void fuseds_conv_unit(const char* T1, int rm, int cby
     }
 }
 
+// the same conv on NM m-tiles at once: one set of weights, NM accumulators. ONE fragment buffer: the three reads of the next
+// (tap, k-step, m-tile) are issued right behind the six MFMAs of the current one -- which have taken their operands by then -- and
+// land while those run (192 cycles of MFMA per group against ~100 of LDS latency); without this order hipcc issues a group's reads
+// directly in front of its MFMAs and every group waits for the LDS (6.8 k cycles for 108 MFMAs with one wave per SIMD active).
+template <int NTAPS, int NM>
+__device__ __forceinline__ void fuseds_conv_units(const char* T1, const int (&rm)[NM], int cbyte, int lane, const float4 (&ub)[30], floatx16 (&acc)[NM])
+{
+    const char* base[NM];
+#pragma unroll
+    for (int m = 0; m < NM; ++m) base[m] = T1 + (rm[m] - NTAPS / 2) * S_LD1 + cbyte + (lane >> 5) * 16;
+    float4 a0 = *reinterpret_cast<const float4*>(base[0]);
+    float4 a1 = *reinterpret_cast<const float4*>(base[0] + S_T1P);
+    float4 a2 = *reinterpret_cast<const float4*>(base[0] + 2 * S_T1P);
+#pragma unroll
+    for (int t = 0; t < NTAPS; ++t)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int q = (t * 2 + j) * 3;
+            const float4 w[3] = {ub[q], ub[q + 1], ub[q + 2]};
+#pragma unroll
+            for (int m = 0; m < NM; ++m) {
+                acc[m] = mfma3_lo(w, a0, a1, a2, acc[m]);
+                acc[m] = mfma3_hi(w, a0, a1, acc[m]);
+                // next group: (t, j, m + 1), or m-tile 0 of the next k-step / tap
+                const int mn = m + 1 < NM ? m + 1 : 0;
+                const int jn = m + 1 < NM ? j : (j + 1) & 1;
+                const int tn = (m + 1 < NM || j == 0) ? t : t + 1;
+                if (tn < NTAPS) {
+                    const char* arow = base[mn] + tn * S_LD1 + jn * 32;
+                    a0 = *reinterpret_cast<const float4*>(arow);
+                    a1 = *reinterpret_cast<const float4*>(arow + S_T1P);
+                    a2 = *reinterpret_cast<const float4*>(arow + 2 * S_T1P);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+}
+
 #ifndef DS_SPLIT_VD
-#define DS_SPLIT_VD 2       // register stages of the stagers' row loads (chunk c + VD is requested at step c)
+#define DS_SPLIT_VD 4       // register stages of the stagers' row loads (chunk c + VD is requested at step c)
 #endif
+#ifndef DS_SPLIT_BD
+#define DS_SPLIT_BD 2       // register stages of a wave's P1 weight fragments (chunk c + BD - 1 is requested at step c)
+#endif
+#ifndef DS_SPLIT_SW0
+#define DS_SPLIT_SW0 0          // the two waves whose phase stamps a debug build records (tools/stamps.py prints them as "wave 0" / "wave 7")
+#define DS_SPLIT_SW1 7
+#endif
+#ifndef DS_SPLIT_BISECT
+#define DS_SPLIT_BISECT 0       // timing-only bisect builds of P1 (results WRONG): 1 no transform / LDS writes, 2 no row loads, 4 no barrier in the
+#endif                          // chunk loop, 8 no weight loads, 16 no fragment reads
+#ifndef DS_SPLIT_WNT
+#define DS_SPLIT_WNT 0          // 1: P1 weight fragments by non-temporal loads
+#endif
+#if DS_SPLIT_WNT
+#define DS_SPLIT_WLOAD(p) gload4_nt(p)
+#else
+#define DS_SPLIT_WLOAD(p) gload4(p)
+#endif
+#ifndef DS_SPLIT_READS_FIRST
+#define DS_SPLIT_READS_FIRST 1
+#endif
+template <int R> struct SplitRole { static constexpr int value = R; };
 
 template <int TM>
 __global__ __launch_bounds__(512, 2) void inception_fused_split_kernel(const FusedChain c)
@@ -123,6 +184,7 @@ __global__ __launch_bounds__(512, 2) void inception_fused_split_kernel(const Fus
     char* const Pst = sm;                                // [2][TR32][S_LDP] staged chunks
     char* const Ys = sm;                                 // [TR32][S_LDY] b1|b2 output tile, aliases the staged chunks once P1 is done
     char* const T2 = sm + 2 * TR32 * S_LDP;              // [TR32][S_LD2]
+    char* const Raw = T2;                                // [2][TR32][S_LDR] raw fp32 chunks during P1 (T2 is written in P2a)
     char* const T1 = T2 + TR32 * S_LD2;                  // [spt*(W+4)+5][S_LD1] (5 spare rows: a dump row for padding rows + its halo)
     const int W = c.m[0].W, spt = c.m[0].spt;            // the same for every module of a chain (ds_internal.h FusedChain)
     int* const rowmap = reinterpret_cast<int*>(T1 + (spt * (W + 4) + 5) * S_LD1);      // [TR32] tile row -> T1 row
@@ -148,8 +210,8 @@ __global__ __launch_bounds__(512, 2) void inception_fused_split_kernel(const Fus
     const int tid = tid_opaque, lane = tid & 63, wave = wave_opaque;
     const int cin = a.cin;
     const gptr1w Yg = (gptr1w)(a.Y + grow0 * 240);     // wave-uniform base; per-lane offsets stay 32-bit
-    const bool stamp = a.dbg != nullptr && lane == 0 && (wave == 0 || wave == 7) && blockIdx.x < DBG_MAX_WGS;
-#define DS_STAMP(i) do { if (stamp) (a.dbg + ((size_t)blockIdx.x * 2 + (wave == 7)) * 8)[i] = __builtin_amdgcn_s_memtime(); } while (0)
+    const bool stamp = a.dbg != nullptr && lane == 0 && (wave == DS_SPLIT_SW0 || wave == DS_SPLIT_SW1) && blockIdx.x < DBG_MAX_WGS;
+#define DS_STAMP(i) do { if (stamp) (a.dbg + ((size_t)blockIdx.x * 2 + (wave == DS_SPLIT_SW1)) * 8)[i] = __builtin_amdgcn_s_memtime(); } while (0)
     DS_STAMP(0);
     if (tid >= 256 && tid < 448) {
         const int q = tid - 256;
@@ -157,13 +219,12 @@ __global__ __launch_bounds__(512, 2) void inception_fused_split_kernel(const Fus
     }
 
     // ---- P1 staging cursor: thread -> (row, 16-byte slot of the chunk's 64 B); rows past the tile end re-read row TRv-1
-    const bool stager = tid < TR32 * 4;
-    const int sr = tid >> 2, sq = tid & 3;
+    const int sr = tid >> 2, sq = tid & 3;              // waves 0 .. 2 TM - 1 stage: TR32 x 4 slots
     const int rr = sr < TRv ? sr : TRv - 1;
     const int wr = rr % W;
     const float* pc = a.X + (grow0 + rr) * cin + sq * 4;
-    const int om = wr > 0 ? -cin : 0;             // previous / next row of the same site, or the own row at a site edge
-    const int op = wr < W - 1 ? cin : 0;
+    const int om = wr > 0 ? -S_LDR : 0;           // previous / next row of the same site in the raw LDS copy, or the own row at a site edge
+    const int op = wr < W - 1 ? S_LDR : 0;
     // this wave's P1 weights: n-tile `wave`, 16 k-steps x 3 terms of 1 KiB (K padded to 256 in the pack)
     const float* bp = a.Bp1 + ((size_t)wave * 16 * 3 * 64 + lane) * 4;
 
@@ -190,36 +251,64 @@ __global__ __launch_bounds__(512, 2) void inception_fused_split_kernel(const Fus
 
     const int nchunks = cin / KC;      // 15 or 16
     __builtin_assume(nchunks >= 15 && nchunks <= 16);
-    {
+    // The staging waves (the first 2 TM: one 16-byte slot per thread) and the others run two instantiations of the loop, so that
+    // inside either no vector-memory instruction sits under a per-thread condition: hipcc counts s_waitcnt vmcnt conservatively
+    // across such a branch (as if the loads had not been issued), which made every step wait for the row loads it had just
+    // requested -- 46 k cycles of P1 instead of ~20 k.
+    auto run_p1 = [&](auto role_tag) __attribute__((always_inline)) {
+        // ROLE 1: a staging wave (waves 0 .. 2 TM - 1: TR32 x 4 sixteen-byte slots, one per thread). ROLE 0: the others.
+        // A CU's vector-memory path delivers ~32 B/clk and a step has 1,152 cycles of MFMA: the 24 KB of weight
+        // fragments per step already take two thirds of that, so a chunk's rows are loaded from global memory ONCE (6 KB) -- the
+        // two neighbour rows branch 1's pool needs come out of a raw fp32 copy of the chunk in LDS (Raw, which lives in T2's
+        // region: T2 is not in use during P1). Chunk k: requested at step k - VD, raw copy written at step k - 2, transformed
+        // (3-tap max, terms) at step k - 1 into the staged buffer, consumed by the MFMAs of step k; every hand-over crosses one of
+        // the per-step barriers.
+        constexpr int ROLE = decltype(role_tag)::value;
+        constexpr bool STG = ROLE != 0;
         constexpr int VD = DS_SPLIT_VD;
-        float4 vo[VD], vm[VD], vn[VD];      // own / previous / next row, 16 B each
-        float4 bq[2][3];
+        constexpr int BD = DS_SPLIT_BD;
+        float4 vo[VD];                      // the stager's 16 B of its row, chunks in flight
+        float4 bq[BD][3];
         float4 af[2][3][TM];
+#if DS_SPLIT_BISECT
+        {
+            const float4 z = make_float4(__uint_as_float(tid), 1.f, 2.f, 3.f);
+            for (int i = 0; i < VD; ++i) vo[i] = z;
+            for (int i = 0; i < BD; ++i) bq[i][0] = bq[i][1] = bq[i][2] = z;
+            for (int i = 0; i < 2; ++i) for (int p = 0; p < 3; ++p) for (int mt = 0; mt < TM; ++mt) af[i][p][mt] = z;
+        }
+#endif
         // waves 6, 7 (branch 1) read the pooled half of a staged row
         const char* const fsrc = Pst + rlane * S_LDP + (lane >> 5) * 16 + (wave >= 6 ? 96 : 0);
         char* const sdst = Pst + sr * S_LDP + sq * 8;
+        char* const rdst = Raw + sr * S_LDR + sq * 16;
         auto load_a = [&](int V) __attribute__((always_inline)) {
-            if (stager) {
-                vo[V] = gload4(pc); vm[V] = gload4(pc + om); vn[V] = gload4(pc + op);
-                pc += KC;
-            }
+            if (STG && !(DS_SPLIT_BISECT & 2)) { vo[V] = gload4(pc); pc += KC; }
         };
-        auto store_a = [&](int X, int V) __attribute__((always_inline)) {
-            if (stager) {
+        auto raw_a = [&](int X, int V) __attribute__((always_inline)) {
+            if (STG && !(DS_SPLIT_BISECT & 1)) *reinterpret_cast<float4*>(rdst + X * TR32 * S_LDR) = vo[V];
+        };
+        auto store_a = [&](int X) __attribute__((always_inline)) {
+            if (STG && !(DS_SPLIT_BISECT & 1)) {
+                const char* r = rdst + X * TR32 * S_LDR;
+                const float4 o = *reinterpret_cast<const float4*>(r);
+                const float4 m = *reinterpret_cast<const float4*>(r + om);
+                const float4 n = *reinterpret_cast<const float4*>(r + op);
                 char* d = sdst + X * TR32 * S_LDP;
                 uint2 t0, t1, t2;
-                split3x4(vo[V].x, vo[V].y, vo[V].z, vo[V].w, t0, t1, t2);
+                split3x4(o.x, o.y, o.z, o.w, t0, t1, t2);
                 *reinterpret_cast<uint2*>(d) = t0; *reinterpret_cast<uint2*>(d + 32) = t1; *reinterpret_cast<uint2*>(d + 64) = t2;
-                split3x4(fmaxf(fmaxf(vo[V].x, vm[V].x), vn[V].x), fmaxf(fmaxf(vo[V].y, vm[V].y), vn[V].y),
-                         fmaxf(fmaxf(vo[V].z, vm[V].z), vn[V].z), fmaxf(fmaxf(vo[V].w, vm[V].w), vn[V].w), t0, t1, t2);
+                split3x4(fmaxf(fmaxf(o.x, m.x), n.x), fmaxf(fmaxf(o.y, m.y), n.y), fmaxf(fmaxf(o.z, m.z), n.z), fmaxf(fmaxf(o.w, m.w), n.w), t0, t1, t2);
                 *reinterpret_cast<uint2*>(d + 96) = t0; *reinterpret_cast<uint2*>(d + 128) = t1; *reinterpret_cast<uint2*>(d + 160) = t2;
             }
         };
         auto load_b = [&](int Bi) __attribute__((always_inline)) {
-            bq[Bi][0] = gload4(bp); bq[Bi][1] = gload4(bp + 256); bq[Bi][2] = gload4(bp + 512);
+            if (DS_SPLIT_BISECT & 8) return;
+            bq[Bi][0] = DS_SPLIT_WLOAD(bp); bq[Bi][1] = DS_SPLIT_WLOAD(bp + 256); bq[Bi][2] = DS_SPLIT_WLOAD(bp + 512);
             bp += 768;
         };
         auto read_frags = [&](int X) __attribute__((always_inline)) {
+            if (DS_SPLIT_BISECT & 16) return;
 #pragma unroll
             for (int mt = 0; mt < TM; ++mt) {
                 const char* q = fsrc + X * TR32 * S_LDP + mt * 32 * S_LDP;
@@ -229,58 +318,62 @@ __global__ __launch_bounds__(512, 2) void inception_fused_split_kernel(const Fus
         };
 #pragma unroll
         for (int i = 0; i < VD; ++i) load_a(i);                  // chunks 0 .. VD - 1
-        load_b(0);
-        store_a(0, 0);
+#pragma unroll
+        for (int i = 0; i < BD - 1; ++i) load_b(i);              // weight fragments of chunks 0 .. BD - 2
+        raw_a(0, 0);
+        raw_a(1, 1 % VD);
+        lds_barrier();
+        store_a(0);
         lds_barrier();
         read_frags(0);
 #pragma unroll
         for (int cc = 0; cc < 16; ++cc) {
             if (cc < nchunks) {                                   // wave-uniform; only cc = 15 is really conditional
                 const int X = cc & 1;
-                const bool has1 = cc + 1 < nchunks;
-                if (cc + VD < nchunks) load_a(cc % VD);           // chunk cc + VD into the stage chunk cc left (consumed at step cc - 1)
-                if (has1) load_b(X ^ 1);
-                if (has1) store_a(X ^ 1, (cc + 1) % VD);
+                const bool has1 = cc + 1 < nchunks, has2 = cc + 2 < nchunks;
+                if (has2) raw_a(X, (cc + 2) % VD);                // the raw copy chunk cc lived in was last read at step cc - 1
+                if (cc + VD < nchunks) load_a(cc % VD);           // chunk cc + VD into the register stage chunk cc left two steps ago
+                if (cc + BD - 1 < nchunks) load_b((cc + BD - 1) % BD);
+                if (has1) store_a(X ^ 1);
 #pragma unroll
-                for (int mt = 0; mt < TM; ++mt) acc[mt] = mfma3_lo(bq[X], af[X][0][mt], af[X][1][mt], af[X][2][mt], acc[mt]);
+                for (int mt = 0; mt < TM; ++mt) acc[mt] = mfma3_lo(bq[cc % BD], af[X][0][mt], af[X][1][mt], af[X][2][mt], acc[mt]);
                 __builtin_amdgcn_sched_barrier(0);
-                lds_barrier();
+                if (!(DS_SPLIT_BISECT & 4)) lds_barrier();
                 if (has1) read_frags(X ^ 1);
 #pragma unroll
-                for (int mt = 0; mt < TM; ++mt) acc[mt] = mfma3_hi(bq[X], af[X][0][mt], af[X][1][mt], acc[mt]);
+                for (int mt = 0; mt < TM; ++mt) acc[mt] = mfma3_hi(bq[cc % BD], af[X][0][mt], af[X][1][mt], acc[mt]);
+#if DS_SPLIT_READS_FIRST
+                if (has1) __builtin_amdgcn_sched_group_barrier(0x100, 3 * TM, 0);      // the next chunk's fragment reads lead the half-step
+#endif
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-    }
+    };
+    if (wave < 2 * TM) run_p1(SplitRole<1>{}); else run_p1(SplitRole<0>{});      // wave-uniform
     DS_STAMP(1);
     lds_barrier();   // all fragment reads of the staging area are done before the output tile aliases it
     DS_STAMP(2);
 
-    // ---- static wave -> unit assignment of P2 (wave-uniform), as inception_fused_kernel. kind: 0 none, 1 b5b, 2 b3b, 3 b4b.
-    int a1k = 0, a1m = 0, a1n = 0, a2k = 0, a2m = 0, a2n = 0;      // P2a units
-    int b1k = 0, b1m = 0, b1n = 0, b2k = 0, b2m = 0, b2n = 0;      // P2b units (waves 0,1 run the residual tail first)
-    if (TM == 3) {
-        if (wave < 6) { a1k = 1; a1m = wave % 3; a1n = wave / 3; }
-        else { a1k = 2; a1m = 0; a1n = wave - 6; }
-        if (wave >= 2) { b1k = 3; b1m = (wave - 2) % 3; b1n = (wave - 2) / 3; }
-        if (wave >= 4) { b2k = 2; b2m = 1 + ((wave - 4) >> 1); b2n = (wave - 4) & 1; }
-    } else if (TM == 2) {
-        if (wave < 4) { a1k = 1; a1m = wave & 1; a1n = wave >> 1; }
-        else { a1k = 2; a1m = wave & 1; a1n = (wave - 4) >> 1; }
-        if (wave >= 2 && wave < 6) { b1k = 3; b1m = (wave - 2) & 1; b1n = (wave - 2) >> 1; }
-    } else {
-        if (wave < 2) { a1k = 1; a1n = wave; }
-        else if (wave < 4) { a1k = 2; a1n = wave - 2; }
-        else if (wave < 6) { a1k = 3; a1n = wave - 4; }
-    }
-    auto unit_Bp = [&](int k) { return k == 1 ? a.Bp5b : k == 2 ? a.Bp3b : a.Bp4b; };
-    auto unit_taps = [&](int k) { return k == 3 ? 5 : 3; };
-    float4 pf[30];                                   // prefetched weights of the next unit
+    // ---- P2 jobs (wave-uniform). A CU's vector-memory path is the scarce resource of this kernel (~32 B/clk against 24 KB of P1
+    // weight fragments per 1,152-cycle step), so the second-stage convs are dealt by (conv, n-tile) and a wave takes ITS weight
+    // fragments (18 or 30 KiB) through all the m-tiles it owns -- the unit table of inception_fused_kernel, one (conv, m-tile,
+    // n-tile) per wave, re-loaded them per m-tile: 420 KB per module and tile against 216 KB here:
+    //   waves 0, 1   P2a: b5b (1x3, 32 -> 64), n-tile = wave, all m-tiles -> T2;      P2b: the residual tail on the stem accumulators
+    //   waves 2, 3   P2a: b3b (1x3, 32 -> 48), n-tile = wave - 2, all m-tiles
+    //   waves 4, 5   P2a: the b1|b2 tile's stores (with waves 6, 7);                   P2b: b4b (1x5, 32 -> 48), n-tile = wave - 4, m-tile 0
+    //   waves 6, 7   P2a: the b1|b2 tile's stores;                                     P2b: b4b, n-tile = wave - 6, m-tiles 1 .. TM - 1
+    // MFMAs per SIMD and phase at TM = 3: P2a 108 | 108 | 108 | 108, P2b 72 + 60 | 72 + 60 | 120 | 120.
+    float4 pf[30];                                   // this wave's unit weights
     // (defined on every path: a register array that is only loaded under a wave-uniform condition is "undefined on some
     // paths", and hipcc keeps such a value live around the whole module loop)
 #pragma unroll
     for (int g = 0; g < 30; ++g) pf[g] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (a1k) fuseds_unit_prefetch(unit_Bp(a1k), unit_taps(a1k), a1n, lane, pf);
+    // Vector-memory operations retire in issue order (one vmcnt counter for loads and stores) and hipcc counts conservatively
+    // across control flow, so a weight fragment requested BEHIND a store is only usable once that store is acknowledged: every
+    // wave requests its weights here, in front of all its stores.
+    if (wave < 2) fuseds_unit_prefetch(a.Bp5b, 3, wave, lane, pf);
+    else if (wave < 4) fuseds_unit_prefetch(a.Bp3b, 3, wave - 2, lane, pf);
+    else fuseds_unit_prefetch(a.Bp4b, 5, (wave - 4) & 1, lane, pf);
 
     // ---- P1 epilogue (bias already inside acc): route the 256 columns. b3a | b4a | b5a go to T1 as terms, b1|b2 through an
     // fp32 LDS tile and leave as whole 384-B row segments; the b5 stem stays in the accumulators of waves 0, 1.
@@ -314,65 +407,75 @@ __global__ __launch_bounds__(512, 2) void inception_fused_split_kernel(const Fus
     DS_STAMP(3);
     lds_barrier();   // T1 and the b1|b2 tile complete
     DS_STAMP(4);
-    for (int idx = tid; idx < TR32 * 24; idx += 512) {
-        const int row = idx / 24, q = idx - row * 24;
-        if (row < TRv) {
-            const float4 v = *reinterpret_cast<const float4*>(Ys + row * S_LDY + q * 16);
-            v4f o = {v.x, v.y, v.z, v.w};
-            *(__attribute__((address_space(1))) v4f*)(Yg + (unsigned)(row * 240 + q * 4)) = o;
-        }
-    }
-
-    auto run_unit = [&](int kind, int mt, int nt) __attribute__((always_inline)) {
-        floatx16 u;
-        const float* bsrc = Bs + (kind == 1 ? 0 : kind == 2 ? 64 : 128) + nt * 32 + h4;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const float4 t = *reinterpret_cast<const float4*>(bsrc + 8 * g);
-            u[4 * g] = t.x; u[4 * g + 1] = t.y; u[4 * g + 2] = t.z; u[4 * g + 3] = t.w;
-        }
-        const int row = mt * 32 + rlane;
-        const int rm = rowmap[row];
-        if (kind == 1) {          // 1x3, 32 -> 64, ReLU, to T2 as terms                  layers.py:127-131
-            fuseds_conv_unit<3>(T1, rm, 128, lane, pf, u);
-            char* d = T2 + row * S_LD2 + (nt * 32 + h4) * 2;
+    // a job: conv KIND (1 b5b, 2 b3b, 3 b4b) on NM m-tiles from m0, n-tile nt, the weights in pf; the NM accumulator chains are
+    // interleaved (a single unit is a chain of dependent LDS reads and MFMAs, i.e. latency)
+    auto run_job = [&](auto kind_tag, auto nm_tag, int m0, int nt) __attribute__((always_inline)) {
+        constexpr int KIND = decltype(kind_tag)::value, NM = decltype(nm_tag)::value;
+        if constexpr (NM > 0) {
+            floatx16 u[NM];
+            const float* bsrc = Bs + (KIND == 1 ? 0 : KIND == 2 ? 64 : 128) + nt * 32 + h4;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                uint2 t0, t1, t2;
-                split3x4(relu_f(u[4 * g]), relu_f(u[4 * g + 1]), relu_f(u[4 * g + 2]), relu_f(u[4 * g + 3]), t0, t1, t2);
-                *reinterpret_cast<uint2*>(d + 16 * g) = t0;
-                *reinterpret_cast<uint2*>(d + 16 * g + S_T2P) = t1;
-                *reinterpret_cast<uint2*>(d + 16 * g + 2 * S_T2P) = t2;
-            }
-        } else {
-            // kind 2: 1x3, 32 -> 48, ReLU, to Y[96,144)   layers.py:106-110
-            // kind 3: 1x5, 32 -> 48, ReLU, to Y[144,192)  layers.py:115-119
-            if (kind == 2) fuseds_conv_unit<3>(T1, rm, 0, lane, pf, u);
-            else fuseds_conv_unit<5>(T1, rm, 64, lane, pf, u);
-            const int ybase = kind == 2 ? 96 : 144;
-            if (row < TRv) {
+                const float4 t = *reinterpret_cast<const float4*>(bsrc + 8 * g);
 #pragma unroll
-                for (int g = 0; g < 4; ++g)
-                    if (nt * 32 + 8 * g < 48) {      // wave-uniform: 48 output channels = n-tile 0 and half of n-tile 1
-                        v4f o = {relu_f(u[4 * g]), relu_f(u[4 * g + 1]), relu_f(u[4 * g + 2]), relu_f(u[4 * g + 3])};
-                        *(__attribute__((address_space(1))) v4f*)(Yg + (unsigned)(row * 240 + ybase + nt * 32 + 8 * g + h4)) = o;
+                for (int m = 0; m < NM; ++m) { u[m][4 * g] = t.x; u[m][4 * g + 1] = t.y; u[m][4 * g + 2] = t.z; u[m][4 * g + 3] = t.w; }
+            }
+            int rm[NM];
+#pragma unroll
+            for (int m = 0; m < NM; ++m) rm[m] = rowmap[(m0 + m) * 32 + rlane];
+            // T1 channels: b3a 0..31, b4a 32..63, b5a 64..95
+            fuseds_conv_units<KIND == 3 ? 5 : 3, NM>(T1, rm, KIND == 1 ? 128 : KIND == 2 ? 0 : 64, lane, pf, u);
+#pragma unroll
+            for (int m = 0; m < NM; ++m) {
+                const int row = (m0 + m) * 32 + rlane;
+                if (KIND == 1) {          // 1x3, 32 -> 64, ReLU, to T2 as terms                  layers.py:127-131
+                    char* d = T2 + row * S_LD2 + (nt * 32 + h4) * 2;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        uint2 t0, t1, t2;
+                        split3x4(relu_f(u[m][4 * g]), relu_f(u[m][4 * g + 1]), relu_f(u[m][4 * g + 2]), relu_f(u[m][4 * g + 3]), t0, t1, t2);
+                        *reinterpret_cast<uint2*>(d + 16 * g) = t0;
+                        *reinterpret_cast<uint2*>(d + 16 * g + S_T2P) = t1;
+                        *reinterpret_cast<uint2*>(d + 16 * g + 2 * S_T2P) = t2;
                     }
+                } else {
+                    // KIND 2: 1x3, 32 -> 48, ReLU, to Y[96,144)   layers.py:106-110
+                    // KIND 3: 1x5, 32 -> 48, ReLU, to Y[144,192)  layers.py:115-119
+                    const int ybase = KIND == 2 ? 96 : 144;
+                    if (row < TRv) {
+#pragma unroll
+                        for (int g = 0; g < 4; ++g)
+                            if (nt * 32 + 8 * g < 48) {      // wave-uniform: 48 output channels = n-tile 0 and half of n-tile 1
+                                v4f o = {relu_f(u[m][4 * g]), relu_f(u[m][4 * g + 1]), relu_f(u[m][4 * g + 2]), relu_f(u[m][4 * g + 3])};
+                                *(__attribute__((address_space(1))) v4f*)(Yg + (unsigned)(row * 240 + ybase + nt * 32 + 8 * g + h4)) = o;
+                            }
+                    }
+                }
             }
         }
     };
 
     // ---- P2a
-    if (a1k) run_unit(a1k, a1m, a1n);
-    if (a2k) {
-        fuseds_unit_prefetch(unit_Bp(a2k), unit_taps(a2k), a2n, lane, pf);
-        run_unit(a2k, a2m, a2n);
-    }
-    // weights of the first P2b job are requested before the barrier (the tail's twelve fragments travel in the unit registers)
     if (wave < 2) {
+        run_job(SplitRole<1>{}, SplitRole<TM>{}, 0, wave);
+        // the tail's twelve weight fragments travel in the unit registers (behind the job's MFMAs; its results are LDS writes)
 #pragma unroll
         for (int g = 0; g < 12; ++g) pf[g] = gload4(a.Bp5c + ((size_t)(wave * 12 + g) * 64 + lane) * 4);
-    } else if (b1k) {
-        fuseds_unit_prefetch(unit_Bp(b1k), unit_taps(b1k), b1n, lane, pf);
+    } else if (wave < 4) {
+        run_job(SplitRole<2>{}, SplitRole<TM>{}, 0, wave - 2);
+    } else {
+        // the b1|b2 tile leaves as whole 384-byte row segments, by the four waves whose second-stage job waits for P2b; every
+        // thread issues the same number of stores (slots past the tile's last one repeat it)
+        constexpr int NFL = (TR32 * 24 + 255) / 256;
+        const int last = TRv * 24 - 1, t4 = tid - 256;
+#pragma unroll
+        for (int i = 0; i < NFL; ++i) {
+            const int idx = min(t4 + i * 256, last);
+            const int row = idx / 24, q = idx - row * 24;
+            const float4 v = *reinterpret_cast<const float4*>(Ys + row * S_LDY + q * 16);
+            v4f o = {v.x, v.y, v.z, v.w};
+            *(__attribute__((address_space(1))) v4f*)(Yg + (unsigned)(row * 240 + q * 4)) = o;
+        }
     }
     DS_STAMP(5);
     lds_barrier();   // T2 complete
@@ -382,17 +485,27 @@ __global__ __launch_bounds__(512, 2) void inception_fused_split_kernel(const Fus
     if (wave < 2) {
         // branch 5 tail: 1x1 64 -> 48 (BN, no ReLU) accumulated on top of the stem conv held in acc,
         // then relu(stem + tail)                                                         layers.py:132-138
-#pragma unroll
-        for (int mt = 0; mt < TM; ++mt) {
-            const char* base = T2 + (mt * 32 + rlane) * S_LD2 + (lane >> 5) * 16;
+        {
+            const char* const tb = T2 + rlane * S_LD2 + (lane >> 5) * 16;
+            float4 a0 = *reinterpret_cast<const float4*>(tb);
+            float4 a1 = *reinterpret_cast<const float4*>(tb + S_T2P);
+            float4 a2 = *reinterpret_cast<const float4*>(tb + 2 * S_T2P);
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const float4 a0 = *reinterpret_cast<const float4*>(base + g * 32);
-                const float4 a1 = *reinterpret_cast<const float4*>(base + S_T2P + g * 32);
-                const float4 a2 = *reinterpret_cast<const float4*>(base + 2 * S_T2P + g * 32);
                 const float4 w[3] = {pf[3 * g], pf[3 * g + 1], pf[3 * g + 2]};
-                acc[mt] = mfma3_lo(w, a0, a1, a2, acc[mt]);
-                acc[mt] = mfma3_hi(w, a0, a1, acc[mt]);
+#pragma unroll
+                for (int mt = 0; mt < TM; ++mt) {
+                    acc[mt] = mfma3_lo(w, a0, a1, a2, acc[mt]);
+                    acc[mt] = mfma3_hi(w, a0, a1, acc[mt]);
+                    const int mn = mt + 1 < TM ? mt + 1 : 0, gn = mt + 1 < TM ? g : g + 1;
+                    if (gn < 4) {      // the next group's fragments, behind this group's MFMAs (see fuseds_conv_units)
+                        const char* q = tb + mn * 32 * S_LD2 + gn * 32;
+                        a0 = *reinterpret_cast<const float4*>(q);
+                        a1 = *reinterpret_cast<const float4*>(q + S_T2P);
+                        a2 = *reinterpret_cast<const float4*>(q + 2 * S_T2P);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
         }
 #pragma unroll
@@ -408,12 +521,10 @@ __global__ __launch_bounds__(512, 2) void inception_fused_split_kernel(const Fus
                     }
             }
         }
-    } else {
-        if (b1k) run_unit(b1k, b1m, b1n);
-        if (b2k) {
-            fuseds_unit_prefetch(unit_Bp(b2k), unit_taps(b2k), b2n, lane, pf);
-            run_unit(b2k, b2m, b2n);
-        }
+    } else if (wave >= 6) {
+        run_job(SplitRole<3>{}, SplitRole<TM - 1>{}, 1, wave - 6);
+    } else if (wave >= 4) {
+        run_job(SplitRole<3>{}, SplitRole<1>{}, 0, wave - 4);
     }
     DS_STAMP(7);
 #undef DS_STAMP

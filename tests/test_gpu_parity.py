@@ -14,6 +14,9 @@ pytestmark = pytest.mark.gpu
 
 INTERMEDIATE_RTOL = 2e-5
 ACT_ATOL = 1e-5
+# DS_PRECISION_BF16X3 (fp32 operands as three bf16 terms on the bf16 matrix pipe, six products per MAC) is held to the SAME
+# bars as native fp32: the tolerances above are not widened for it.
+FP32_CLASS = ["fp32", "bf16x3"]
 
 
 def _engine(weights, **kw):
@@ -35,11 +38,12 @@ def _check_outputs(act, pred, o_act, o_pred):
     assert (pred[decided] == o_pred[decided]).all()
 
 
+@pytest.mark.parametrize("precision", FP32_CLASS)
 @pytest.mark.parametrize("n", [1, 24, 130])
-def test_layerwise_parity_vs_oracle(small_weights, n):
+def test_layerwise_parity_vs_oracle(small_weights, n, precision):
     from oracle import oracle
     feats = synth.synthetic_features(n, seed=100 + n)
-    eng = _engine(small_weights, max_batch=160, debug=True)
+    eng = _engine(small_weights, max_batch=160, debug=True, precision=precision)
     act, pred = eng.run(feats["kmer"], feats["means"], feats["stds"], feats["sanums"], feats["signals"])
     o_act, o_pred, taps = oracle.forward(small_weights, feats, "f32", taps=True)
     worst = {}
@@ -54,12 +58,13 @@ def test_layerwise_parity_vs_oracle(small_weights, n):
     eng.close()
 
 
-def test_batch_512_and_ragged_tail(small_weights):
+@pytest.mark.parametrize("precision", FP32_CLASS)
+def test_batch_512_and_ragged_tail(small_weights, precision):
     """n > max_batch is looped inside ds_forward; last chunk is partial (call_modifications.py:157-166)."""
     from oracle import oracle
     n = 512 + 37
     feats = synth.synthetic_features(n, seed=5)
-    eng = _engine(small_weights, max_batch=512)
+    eng = _engine(small_weights, max_batch=512, precision=precision)
     act, pred = eng.run(feats["kmer"], feats["means"], feats["stds"], feats["sanums"], feats["signals"])
     sel = np.r_[0:40, 500:549]
     sub = {k: v[sel] for k, v in feats.items()}
@@ -105,7 +110,8 @@ def test_graph_and_eager_agree_and_are_deterministic(small_weights):
     eng.close()
 
 
-def test_edge_inputs(small_weights):
+@pytest.mark.parametrize("precision", FP32_CLASS)
+def test_edge_inputs(small_weights, precision):
     """All-N k-mers, zero-padded (short) signal windows, extreme event lengths, empty batch."""
     from oracle import oracle
     feats = synth.synthetic_features(16, seed=11)
@@ -115,7 +121,7 @@ def test_edge_inputs(small_weights):
     feats["sanums"][3, :] = 200.0
     feats["means"][4, :] = 5.0
     feats["means"][5, :] = -5.0
-    eng = _engine(small_weights, max_batch=64)
+    eng = _engine(small_weights, max_batch=64, precision=precision)
     args = [feats[k] for k in ("kmer", "means", "stds", "sanums", "signals")]
     act, pred = eng.run(*args)
     o_act, o_pred = oracle.forward(small_weights, feats, "f32")
@@ -207,7 +213,7 @@ def test_pipelined_device_forwards_match_blocking(small_weights):
 
 @pytest.mark.parametrize("geom", [dict(kmer_len=9, signal_len=100), dict(kmer_len=21, signal_len=128),
                                   dict(kmer_len=5, signal_len=40)])
-@pytest.mark.parametrize("precision", ["fp32", "bf16_all"])
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3", "bf16_all"])
 def test_other_kmer_and_signal_lengths(geom, precision):
     """--kmer_len / --cent_signals_len are free parameters of the reference CLI (deepsignal.py:258-263): widths,
     SAME paddings, the joint width and every tile shape follow them."""
@@ -217,7 +223,7 @@ def test_other_kmer_and_signal_lengths(geom, precision):
     feats = synth.synthetic_features(70, seed=8, **geom)
     eng = _engine(w, max_batch=128, debug=True, precision=precision, **geom)
     act, pred = eng.run(feats["kmer"], feats["means"], feats["stds"], feats["sanums"], feats["signals"])
-    if precision == "fp32":
+    if precision in FP32_CLASS:
         o_act, o_pred, taps = oracle.forward(w, feats, "f32", taps=True, **geom)
         for name, ref in taps.items():
             got = eng.intermediate(name, ref.shape)
@@ -253,7 +259,7 @@ def test_short_signals_at_big_batches(geom, batch):
     eng.close()
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16", "bf16_all"])
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3", "bf16", "bf16_all"])
 def test_a_batch_of_8192_gives_the_bits_of_batches_of_512(small_weights, precision):
     """Every tiling decision the planner takes from the batch size (sites per fused-module tile, BiLSTM tile shapes, the
     bf16 module chain that keeps its rows in LDS, grids of > 65,535 workgroups) must leave a site's bits alone: one forward

@@ -1,0 +1,85 @@
+"""DS_PRECISION_BF16X3 on the GPU: fp32 operands carried as three bf16 terms through the bf16 matrix pipe (six products per
+MAC, fp32 accumulate; deepsignal_amd/csrc/ds_split.hip). Reference arithmetic: layers.py:87-139 (inception_layer),
+layers.py:205-232 (the eleven modules).
+
+The mode is held to the bars of native fp32 -- tests/test_gpu_parity.py and tests/test_gpu_stress.py run their layer-wise,
+ragged-batch, edge-input, other-geometry and trained-regime checks once per precision of FP32_CLASS with the tolerances
+unchanged. This file adds what is specific to the mode:
+
+  * exactness against the CPU statement of the SAME arithmetic (oracle/torch_statement.py::forward_split rounds where the
+    engine rounds): only the fp32 summation order differs, so the bar is tighter than the fp32-oracle bar;
+  * the split kernels really ran (a silent fall-back to the native fp32 kernels would pass every parity test);
+  * chained launch == one launch per module, bit for bit;
+  * configurations the mode does not implement are refused loudly.
+"""
+import numpy as np
+import pytest
+
+from deepsignal_amd import synth
+
+pytestmark = pytest.mark.gpu
+KEYS = ("kmer", "means", "stds", "sanums", "signals")
+SPLIT_SCOPE = ("modules",)            # what DS_PRECISION_BF16X3 runs split (ds_version() / DESIGN.md section 11)
+STATEMENT_RTOL = 6e-6                 # engine vs the CPU statement of the same arithmetic, relative to the tensor's scale
+
+
+def _engine(weights, **kw):
+    from deepsignal_amd.engine import Engine
+    eng = Engine(**kw)
+    eng.load_weights(weights)
+    return eng
+
+
+@pytest.mark.parametrize("which", ["small", "stress"])
+def test_split_engine_against_the_cpu_statement_of_the_same_arithmetic(request, which):
+    from oracle import torch_statement
+    w = request.getfixturevalue(which + "_weights")
+    n = 96
+    feats = synth.synthetic_features(n, seed=4100)
+    eng = _engine(w, max_batch=128, debug=True, precision="bf16x3")
+    act, pred = eng.run(*(feats[k] for k in KEYS))
+    s_act, s_pred, taps = torch_statement.forward_split(w, feats, terms=3, scope=SPLIT_SCOPE, return_taps=True)
+    worst = {}
+    for name, ref in taps.items():
+        if not (name.startswith("module") or name == "signal_feat"):
+            continue
+        got = eng.intermediate(name, ref.shape)
+        scale = max(1.0, float(np.abs(ref).max()))
+        worst[name] = float(np.abs(got - ref).max()) / scale
+    print("\n%s: engine vs forward_split, relative to the tensor's scale: %s" % (which, {k: "%.1e" % v for k, v in worst.items()}))
+    bad = {k: v for k, v in worst.items() if not v <= STATEMENT_RTOL}
+    assert not bad, bad
+    assert np.abs(act - s_act).max() <= (1e-5 if which == "small" else 1e-4)
+    eng.close()
+
+
+def test_the_split_kernels_are_the_ones_that_run(small_weights):
+    feats = synth.synthetic_features(96, seed=4101)
+    eng = _engine(small_weights, max_batch=96, precision="bf16x3")
+    eng.set_graph(False)
+    eng.set_profiling(1)
+    eng.run(*(feats[k] for k in KEYS))
+    ran = {k["name"]: k["launches"] for k in eng.kernel_stats() if k["launches"]}
+    eng.close()
+    assert any(name.startswith("inception_fused_split_kernel") for name in ran), ran
+    assert not any(name.startswith("inception_fused_kernel") or name.startswith("inception_fused_bf16") for name in ran), ran
+
+
+def test_split_chain_gives_the_bits_of_one_launch_per_module(small_weights):
+    feats = synth.synthetic_features(1333, seed=812)
+    args = [feats[k] for k in KEYS]
+    chained = _engine(small_weights, max_batch=1333, slots=1, precision="bf16x3")
+    a1, p1 = chained.run(*args)
+    a1s, p1s = chained.run(*(a[:77] for a in args))
+    chained.close()
+    single = _engine(small_weights, max_batch=1333, slots=1, precision="bf16x3", chain_modules=False)
+    a2, p2 = single.run(*args)
+    single.close()
+    assert np.array_equal(a1, a2) and np.array_equal(p1, p2)
+    assert np.array_equal(a1s, a1[:77]) and np.array_equal(p1s, p1[:77])
+
+
+def test_split_mode_refuses_what_it_does_not_implement(small_weights):
+    from deepsignal_amd.engine import Engine
+    with pytest.raises(RuntimeError, match="BF16X3"):
+        Engine(max_batch=64, precision="bf16x3", no_fused=True)

@@ -34,6 +34,9 @@ FLOOR_REL = 2e-6
 OUT_ATOL = 1e-4          # BASELINE.json north_star: outputs within 1e-4 of the reference
 LABEL_MARGIN = 1e-3
 KEYS = ("kmer", "means", "stds", "sanums", "signals")
+# DS_PRECISION_BF16X3 (three bf16 terms per fp32 operand, six products per MAC, fp32 accumulate) is an fp32-class evaluation and is
+# held to the bars of native fp32, unchanged
+FP32_CLASS = ["fp32", "bf16x3"]
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -87,14 +90,15 @@ def _fp32_noise(which, w):
     return _NOISE[which]
 
 
+@pytest.mark.parametrize("precision", FP32_CLASS)
 @pytest.mark.parametrize("which", ["balanced", "stress"])
 @pytest.mark.parametrize("n", [1, 130, 512])
-def test_layerwise_parity_in_the_trained_regime(request, which, n):
+def test_layerwise_parity_in_the_trained_regime(request, which, n, precision):
     from oracle import oracle
     w = request.getfixturevalue(which + "_weights")
     noise = _fp32_noise(which, w)
     feats = synth.synthetic_features(n, seed=900 + n)
-    eng = _engine(w, max_batch=512, debug=True)
+    eng = _engine(w, max_batch=512, debug=True, precision=precision)
     act, pred = eng.run(*(feats[k] for k in KEYS))
     a32, p32, t32 = oracle.forward(w, feats, "f32", taps=True)
     a64, p64, t64 = oracle.forward(w, feats, "f64", taps=True)
@@ -119,7 +123,7 @@ def test_layerwise_parity_in_the_trained_regime(request, which, n):
            "hip_d_act_vs_oracle_f32": float(np.abs(act - a32).max()),
            "label1_share": share, "logit_range": [float(t64["logits"].min()), float(t64["logits"].max())],
            "max_abs_h": float(np.abs(t64["lstm_fw_l2"]).max()), "taps": rows}
-    _record("%s_n%d_three_step" % (which, n), rec)
+    _record("%s_n%d_three_step%s" % (which, n, "" if precision == "fp32" else "_" + precision), rec)
     print("\n%s n=%d: HIP vs f64 |d act| %.2e |d p_norm| %.2e   (fp32 oracle vs f64: %.2e / %.2e; HIP vs fp32 oracle %.2e)  label-1 share %.2f"
           % (which, n, d_act, d_pn, rec["oracle_f32_d_act_vs_f64"], rec["oracle_f32_d_pnorm_vs_f64"], rec["hip_d_act_vs_oracle_f32"], share))
     worst = sorted(rows.items(), key=lambda kv: -kv[1]["hip_vs_f64"] / (kv[1]["oracle_f32_vs_f64"] + FLOOR_REL * kv[1]["max_abs"]))[:4]
@@ -129,20 +133,21 @@ def test_layerwise_parity_in_the_trained_regime(request, which, n):
     eng.close()
 
 
+@pytest.mark.parametrize("precision", FP32_CLASS)
 @pytest.mark.parametrize("which", ["balanced", "stress"])
-def test_default_engine_folded_joint_and_pipelined_slots(request, which):
+def test_default_engine_folded_joint_and_pipelined_slots(request, which, precision):
     """The product's default engine (joint model folded into one 6032 x 2 matrix, 8 slots, captured graphs) on the same
     sets: a ragged 549-site call, then the same sites alone and in a sub-batch give the same bits."""
     from oracle import oracle
     w = request.getfixturevalue(which + "_weights")
     n = 512 + 37
     feats = synth.synthetic_features(n, seed=31)
-    eng = _engine(w, max_batch=512)
+    eng = _engine(w, max_batch=512, precision=precision)
     act, pred = eng.run(*(feats[k] for k in KEYS))
     a64, p64 = oracle.forward(w, feats, "f64")
     d_act, d_pn, share = _check_outputs_f64(act, pred, a64, p64)
     a32, _ = oracle.forward(w, feats, "f32")
-    _record("%s_n549_folded" % which, {"max_abs_d_act_vs_f64": d_act, "max_abs_d_pnorm_vs_f64": d_pn, "label1_share": share,
+    _record("%s_n549_folded%s" % (which, "" if precision == "fp32" else "_" + precision), {"max_abs_d_act_vs_f64": d_act, "max_abs_d_pnorm_vs_f64": d_pn, "label1_share": share,
                                        "oracle_f32_d_act_vs_f64": float(np.abs(a32 - a64).max())})
     print("\n%s folded n=%d: |d act| %.2e |d p_norm| %.2e (fp32 oracle: %.2e), label-1 share %.2f"
           % (which, n, d_act, d_pn, float(np.abs(a32 - a64).max()), share))
@@ -153,12 +158,13 @@ def test_default_engine_folded_joint_and_pipelined_slots(request, which):
     eng.close()
 
 
-def test_stress_golden_vectors_replayed_on_the_gpu(stress_weights):
+@pytest.mark.parametrize("precision", FP32_CLASS)
+def test_stress_golden_vectors_replayed_on_the_gpu(stress_weights, precision):
     """The committed float64 vectors of the stress set (48 sites, all-N k-mer / truncated / all-zero windows among them)."""
     g = np.load(os.path.join(ROOT, "tests", "golden", "stress_golden.npz"))
     feats = {k: g["in_" + k] for k in KEYS}
     for fold in (True, False):
-        eng = _engine(stress_weights, max_batch=64, debug=not fold, fold_fc=fold)
+        eng = _engine(stress_weights, max_batch=64, debug=not fold, fold_fc=fold, precision=precision)
         act, pred = eng.run(*(feats[k] for k in KEYS))
         _check_outputs_f64(act, pred, g["act"], g["pred"])
         if not fold:
@@ -236,9 +242,9 @@ def test_trained_regime_on_other_geometries_and_model_variants(variant):
     feats = synth.synthetic_features(n, seed=780, **geom)
     a64, p64 = oracle.forward(w, feats, "f64", **variant)
     a32, _ = oracle.forward(w, feats, "f32", **variant)
-    for fold in (True, False):
-        eng = _engine(w, max_batch=256, fold_fc=fold, **variant)
+    for fold, precision in ((True, "fp32"), (False, "fp32"), (True, "bf16x3")):
+        eng = _engine(w, max_batch=256, fold_fc=fold, precision=precision, **variant)
         act, pred = eng.run(*(feats[k] for k in KEYS))
         d_act, d_pn, share = _check_outputs_f64(act, pred, a64, p64)
         eng.close()
-        print("\n%s fold=%s: |d act| %.2e (fp32 oracle %.2e), label-1 share %.2f" % (variant, fold, d_act, float(np.abs(a32 - a64).max()), share))
+        print("\n%s fold=%s %s: |d act| %.2e (fp32 oracle %.2e), label-1 share %.2f" % (variant, fold, precision, d_act, float(np.abs(a32 - a64).max()), share))
