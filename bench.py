@@ -30,6 +30,8 @@ Extra objects:
                       host buffers in, results out, n = 512 and n = 8192 per call
   e2e_tsv             feature TSV -> result TSV through call_mods (native reader + formatter + the default engine)
   configs2_bf16_batch4096   BASELINE configs[2]: bf16_all / bf16 throughput at batch 4096 and the conv path's HBM fraction
+  fp32_class_bf16x3   DS_PRECISION_BF16X3 (fp32 operands as three bf16 terms on the bf16 matrix pipe): the same steps, its own
+                      roofline (bf16 MFMA peak / 6 products per MAC), accuracy against the float64 oracle on the stress set
 """
 import argparse
 import json
@@ -357,6 +359,75 @@ def configs2_tolerance(Engine, w, local_rank, feats, keys):
     return out
 
 
+PEAK_BF16_MFMA_TFLOPS = 2500.0     # MI355X_MICROARCH.md, "Peak BF16/FP16 MFMA" (dense)
+SPLIT_PRODUCTS_PER_MAC = 6         # DS_PRECISION_BF16X3: three bf16 terms per operand, six term products per fp32-class MAC
+
+
+def bf16x3_leg(Engine, w, torch, make_step, timed_windows, local_rank, slots, lstm_tiling, steps):
+    """DS_PRECISION_BF16X3 beside the headline: the same 512-site steps, the same timed-window rules, on an
+    engine that carries fp32 operands as three bf16 terms through the bf16 matrix pipe (six products per MAC, fp32 accumulate) in
+    the layers ds_version() lists, everything else as the fp32 engine. Its own key with its own roofline: algorithmic FLOPs of the
+    split kernel per launch / stand-alone HIP-event duration against the bf16 MFMA peak / 6 products per MAC; the fp32-peak
+    fraction rides along (above 1 = faster than a perfect native-fp32 kernel could be). Accuracy in the same run: one 512-site
+    batch of the trained-regime stress set against the FLOAT64 CPU oracle, next to the native fp32 engine on the same batch."""
+    import numpy as np
+    from deepsignal_amd import synth, weights as W
+    from oracle import oracle
+    out = {"precision": "bf16x3", "what": "fp32 operands as three bf16 terms, six term products per MAC, fp32 accumulate "
+                                          "(include/deepsignal_hip.h DS_PRECISION_BF16X3; deepsignal_amd/csrc/ds_split.hip)"}
+    for key, fold in (("three_step", False), ("folded", True)):
+        e = Engine(device=local_rank, max_batch=BATCH, lstm_tiling=lstm_tiling, slots=slots, fold_fc=fold, precision="bf16x3")
+        e.load_weights(w)
+        wins = timed_windows(e, 3)
+        el = sorted(wins)[len(wins) // 2]
+        out[key] = {"value": round(steps * BATCH / el, 1) if steps else 0.0, "unit": "sites/s", "ms_per_step": round(1e3 * el / max(steps, 1), 4)}
+        if not fold:
+            step = make_step(e)
+            KP = min(steps, 50)
+            e.set_profiling(3)
+            e.reset_stage_times()
+            for i in range(KP):
+                step(i, i)
+            e.sync()
+            ks = {k["name"]: k for k in e.kernel_stats() if k["launches"]}
+            e.set_profiling(0)
+            out["kernels_us_per_step_alone"] = {n: round(1e3 * k["total_ms"] / max(KP, 1), 1) for n, k in ks.items()}
+            sp = [k for n, k in ks.items() if "split" in n]
+            if sp:
+                k = max(sp, key=lambda k_: k_["total_ms"])
+                per_launch = k["flops"] / k["launches"]
+                avg_ms = k["total_ms"] / k["launches"]
+                ach = per_launch / (avg_ms * 1e-3) / 1e12
+                peak = PEAK_BF16_MFMA_TFLOPS / SPLIT_PRODUCTS_PER_MAC
+                out["roofline"] = {"bound": "mfma", "kernel": k["name"], "launches_per_step": k["launches"] // max(KP, 1),
+                                   "avg_launch_us": round(avg_ms * 1e3, 2), "flops_per_launch": per_launch,
+                                   "achieved": round(ach, 2), "unit": "TFLOP/s (fp32-class MACs x 2)",
+                                   "peak": round(peak, 1), "frac": round(ach / peak, 4),
+                                   "peak_how": "bf16 dense MFMA peak %.0f TFLOP/s / %d term products per MAC" % (PEAK_BF16_MFMA_TFLOPS, SPLIT_PRODUCTS_PER_MAC),
+                                   "frac_of_fp32_mfma_peak": round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
+                                   "bf16_mfma_frac": round(ach * SPLIT_PRODUCTS_PER_MAC / PEAK_BF16_MFMA_TFLOPS, 4),
+                                   "measured": "stand-alone: every launch of the step on ONE stream, HIP events on that stream, eager replay of %d steps" % KP}
+        e.close()
+    g = np.load(os.path.join(ROOT, "tests", "golden", "stress_golden.npz"))
+    ws = W.stress_weights(int(g["stress_seed"]), head=g["stress_head"])
+    f = synth.synthetic_features(BATCH, seed=931)
+    args = [f[k] for k in ("kmer", "means", "stds", "sanums", "signals")]
+    a64, p64 = oracle.forward(ws, f, "f64")
+    acc = {"how": "one %d-site batch of the trained-regime stress set (tests/test_gpu_stress.py) through ds_forward per precision; "
+                  "d = |sigmoid outputs - float64 CPU oracle|; both engines with the three-step joint model" % BATCH}
+    for prec in ("fp32", "bf16x3"):
+        e = Engine(device=local_rank, max_batch=BATCH, slots=1, fold_fc=False, precision=prec)
+        e.load_weights(ws)
+        a, p_ = e.run(*args)
+        e.close()
+        d = np.abs(a.astype(np.float64) - a64)
+        acc[prec] = {"max_abs_d_act_vs_f64": float("%.3g" % d.max()), "mean_abs_d_act_vs_f64": float("%.3g" % d.mean()),
+                     "label_flip_rate_vs_f64": round(float((p_ != p64).mean()), 5)}
+    acc["label1_share_f64"] = round(float(p64.mean()), 4)
+    out["accuracy_stress_set"] = acc
+    return out
+
+
 def np_tile(a, n, off):
     """n rows of `a` starting at row `off`, wrapping around (contiguous copy)."""
     import numpy as np
@@ -416,6 +487,7 @@ def main():
     ap.add_argument("--no-host-path", action="store_true", help="skip the pcie_inclusive and e2e_tsv legs")
     ap.add_argument("--no-fast-mode", "--no-three-step", dest="no_fast_mode", action="store_true",
                     help="skip the fast_mode_folded leg (the default engine with the folded joint model)")
+    ap.add_argument("--no-split", action="store_true", help="skip the fp32_class_bf16x3 leg (DS_PRECISION_BF16X3 beside the headline)")
     ap.add_argument("--no-configs2", action="store_true", help="skip the BASELINE configs[2] leg (bf16 modes at batch 4096)")
     ap.add_argument("--lstm-tiling", default="auto", help="diagnostic: force a BiLSTM cell-kernel variant (Engine(lstm_tiling=...))")
     ap.add_argument("--slots", type=int, default=0, help="diagnostic: forwards in flight (0 = engine default, 8)")
@@ -712,6 +784,8 @@ def main():
         result["fast_mode_folded"] = fm
         engf.close()
     eng.close()
+    if solo and not args.no_split:
+        result["fp32_class_bf16x3"] = bf16x3_leg(Engine, w, torch, make_step, timed_windows, local_rank, args.slots, args.lstm_tiling, K)
     if solo and not args.no_configs2:
         result["configs2_bf16_batch4096"] = configs2_leg(Engine, w, torch, dev, local_rank, host_path=not args.no_host_path)
         if "e2e_tsv" in result["configs2_bf16_batch4096"].get("bf16_all", {}):

@@ -170,12 +170,27 @@ COLLECTIVE_TIMEOUT_S = 600.0      # process-group timeout of a multi-GPU call_mo
 # sites per forward the engine is created for (see make_engine). TSV -> TSV on MI355X, 327,680 rows (tools/e2e_profile.py): fp32
 # 505 / 504 / 526 / 532 k sites/s at 512 / 1024 / 2048 / 4096 (fewer, larger H2D copies and Python round trips per site; the
 # resident-input rate itself gains 2 %); bf16_all 1.3 M at 512 against 1.9 M at 4096
-ENGINE_BATCH = {"fp32": 4096, "bf16": 4096, "bf16_all": 4096}
+ENGINE_BATCH = {"fp32": 4096, "bf16": 4096, "bf16_all": 4096, "bf16x3": 4096}
+
+
+def engine_batch_for(batch_size: int, precision: str, engine_batch: int = 0) -> int:
+    """Sites per forward the engine is created for. Default: the larger of --batch_size and ENGINE_BATCH[precision]; an explicit
+    `engine_batch` (> 0: the CLI's --engine_batch, or the DS_ENGINE_BATCH environment variable read here, in the Python harness)
+    is taken as given -- the escape hatch for a small or shared GPU: device and pinned memory grow with it (about 1 GB per 512
+    sites over the engine's slots)."""
+    if engine_batch <= 0:
+        try:
+            engine_batch = int(os.environ.get("DS_ENGINE_BATCH", "0"))
+        except ValueError:
+            raise ValueError("DS_ENGINE_BATCH must be an integer")
+    if engine_batch > 0:
+        return engine_batch
+    return max(batch_size, ENGINE_BATCH.get(precision, batch_size))
 
 
 def make_engine(model_path: str, kmer_len: int, cent_signals_len: int, class_num: int, batch_size: int,
                 is_cnn: bool = True, is_rnn: bool = True, is_base: bool = True, device: int = 0,
-                precision: str = "fp32"):
+                precision: str = "fp32", engine_batch: int = 0):
     """Model(...) + Session + Saver.restore (reference call_modifications.py:203-212)."""
     from .engine import Engine
     weights = load_model_weights(model_path, kmer_len, cent_signals_len, class_num, is_cnn, is_rnn, is_base)
@@ -183,9 +198,18 @@ def make_engine(model_path: str, kmer_len: int, cent_signals_len: int, class_num
     # its batch mates (tests: the same bits alone, in a sub-batch, in a full batch), so the engine is sized for the batch the
     # GPU wants -- ENGINE_BATCH -- and the row pipeline fills THAT (the bf16 modes need 4096 sites for their 3.3 M sites/s, 2.6 M at
     # 512; fp32 end to end gains 5 % from the larger copies)
-    eng = Engine(kmer_len=kmer_len, signal_len=cent_signals_len, class_num=class_num, device=device,
-                 max_batch=max(batch_size, ENGINE_BATCH.get(precision, batch_size)), is_cnn=is_cnn, is_rnn=is_rnn,
-                 is_base=is_base, precision=precision)
+    want = engine_batch_for(batch_size, precision, engine_batch)
+    kw = dict(kmer_len=kmer_len, signal_len=cent_signals_len, class_num=class_num, device=device, is_cnn=is_cnn, is_rnn=is_rnn,
+              is_base=is_base, precision=precision)
+    try:
+        eng = Engine(max_batch=want, **kw)
+    except RuntimeError as exc:
+        # the GPU has no room for the large batch (another job's memory, a smaller device): the user's own batch size still works
+        if "hipMalloc" not in str(exc) or want <= batch_size:
+            raise
+        print("note: no device memory for an engine of %d sites per forward (%s); falling back to --batch_size %d"
+              % (want, exc, batch_size), file=sys.stderr)
+        eng = Engine(max_batch=batch_size, **kw)
     if weights is None:
         eng.load_weights_file(model_path)
     else:
@@ -487,7 +511,8 @@ def _call_mods_sharded(input_path, engine, batch_size, result_file, kmer_len, ce
 
 def call_mods(input_path, model_path, result_file, kmer_len, cent_signals_len,
               batch_size, learning_rate, class_num, nproc, is_gpu, is_rnn, is_base, is_cnn,
-              f5_args, engine=None, f5_batch_num=None, native_io=True, precision="fp32", dist=None, force_sharded=False):
+              f5_args, engine=None, f5_batch_num=None, native_io=True, precision="fp32", dist=None, force_sharded=False,
+              engine_batch=0):
     """The reference's call_mods (call_modifications.py:417-495), same signature and argument meaning.
 
     learning_rate / is_gpu are accepted for signature compatibility: inference ignores the learning rate
@@ -503,7 +528,7 @@ def call_mods(input_path, model_path, result_file, kmer_len, cent_signals_len,
     start = time.time()
     f5 = _unpack_f5_args(f5_args, f5_batch_num)
     dist, rank, world, local = _distributed_context(dist)
-    if precision != "fp32" and rank == 0 and engine is None:
+    if precision in ("bf16", "bf16_all") and rank == 0 and engine is None:
         # measured, DESIGN.md section 9: harmless on random-init weights, NOT on weights at a trained model's scale
         print("note: --precision %s stores activations as bf16: on trained-scale weights expect probabilities to move by ~0.02 (up "
               "to ~0.2) and a few per cent of the calls nearest the threshold to change label; fp32 is the reference numerics"
@@ -515,7 +540,8 @@ def call_mods(input_path, model_path, result_file, kmer_len, cent_signals_len,
     own = engine is None
     if own:
         engine = make_engine(model_path, kmer_len, cent_signals_len, class_num, batch_size,
-                             is_cnn=is_cnn, is_rnn=is_rnn, is_base=is_base, device=local, precision=precision)
+                             is_cnn=is_cnn, is_rnn=is_rnn, is_base=is_base, device=local, precision=precision,
+                             engine_batch=engine_batch)
     try:
         if os.path.isdir(input_path):
             nsites = _call_mods_from_fast5s(input_path, result_file, kmer_len, cent_signals_len, batch_size, f5, engine,

@@ -1230,20 +1230,29 @@ int run_resident(ds_handle* h, int n)
 // Every slot's plan and captured graph for the full batch, built when the weights are finalized: the first max_batch-sized
 // forward of a slot then costs what every later one costs (a caller that times its first `slots` calls -- bench.py with
 // --warmup smaller than the slot count -- would otherwise see plan building and graph capture inside its window).
-int prepare_slots(ds_handle* h)
+// An optimisation, not a requirement: the weights are finalized by then, so a plan or a capture that fails here (device memory
+// for the launch descriptors, a capture error) leaves the handle usable -- the slot builds its plan lazily at its first
+// forward, as every other batch size does, and THAT call reports the error if it persists. Serial / profiling handles
+// (DS_TUNE_SERIAL: stand-alone kernel timing under rocprofv3) skip it: they run eagerly and a capture would only add
+// activity to the trace.
+void prepare_slots(ds_handle* h)
 {
-    if (!h->use_graph || h->debug) return DS_OK;
+    if (!h->use_graph || h->debug || h->serial) return;
     Slot* keep = h->cur;
-    int rc = DS_OK;
+    const std::string err_before = h->err;
     for (Slot& sl : h->slots) {
         h->cur = &sl;
         Plan* plan = nullptr;
-        rc = get_plan(h, h->B, &plan);
+        int rc = get_plan(h, h->B, &plan);
         if (!rc) { plan->uses = 0; rc = ensure_graph(h, *plan); }
-        if (rc) break;
+        if (rc) {
+            fprintf(stderr, "deepsignal_amd: preparing a slot's full-batch plan failed (%s); plans will be built at the first forward\n",
+                    h->err.c_str());
+            h->err = err_before;
+            break;
+        }
     }
     h->cur = keep;
-    return rc;
 }
 
 }  // namespace
@@ -1269,7 +1278,11 @@ int guarded(ds_handle* h, F&& body)
 // ======================================= C ABI =======================================
 extern "C" {
 
-const char* ds_version(void) { return "deepsignal_amd 0.3 (gfx950; fp32 MFMA, bf16 conv + FC and bf16_all operand modes)"; }
+const char* ds_version(void)
+{
+    return "deepsignal_amd 0.4 (gfx950; fp32 MFMA, bf16 conv + FC and bf16_all operand modes; bf16x3 = fp32 operands as three bf16 "
+           "terms, six products per MAC, in: the eleven inception modules)";
+}
 
 const char* ds_last_error(const ds_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
 
@@ -1401,7 +1414,8 @@ static int ds_finalize_weights_impl(ds_handle* h)
     if (h->finalized) return fail(h, DS_ERR_INVALID, "weights already finalized");
     hipSetDevice(h->cfg.device);
     int rc = finalize_weights(h);
-    return rc ? rc : prepare_slots(h);
+    if (!rc) prepare_slots(h);
+    return rc;
 }
 
 static int ds_load_weights_impl(ds_handle* h, const char* path)

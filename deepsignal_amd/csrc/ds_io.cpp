@@ -437,7 +437,10 @@ const char* ds_tsv_error(const ds_tsv* t) { return t ? t->err.c_str() : "null re
 int64_t ds_tsv_locate(ds_tsv* t, int32_t max_reads)
 {
     if (!t || max_reads < 1) return DS_ERR_INVALID;
-    t->lines.clear();
+    if (!t->lines.empty()) {      // exactly one ds_tsv_parse_into() per successful ds_tsv_locate(): a second locate would drop the item
+        t->err = "ds_tsv_locate: the rows of the previous ds_tsv_locate() have not been parsed (ds_tsv_parse_into), or their parse failed";
+        return DS_ERR_INVALID;
+    }
     if (t->scanned < t->pos || t->pend_head > t->pend.size()) { t->scanned = t->pos; t->pend.clear(); t->pend_head = 0; }
     const char* prev_id = nullptr;
     size_t prev_len = 0;
@@ -476,11 +479,16 @@ int64_t ds_tsv_locate(ds_tsv* t, int32_t max_reads)
 // Parse the rows ds_tsv_locate() found into the CALLER's arrays (kmer int32[n,kmer_len], means / stds / lens
 // float[n,kmer_len], signals float[n,signal_len], labels int32[n]) on the team; the six sampleinfo columns go to the
 // reader's own buffer (ds_tsv_info / ds_tsv_info_offsets). Returns n, or a negative code on a malformed row.
-int64_t ds_tsv_parse_into(ds_tsv* t, int32_t* kmer, float* means, float* stds, float* lens, float* signals, int32_t* labels)
+int64_t ds_tsv_parse_into(ds_tsv* t, int64_t capacity_rows, int32_t* kmer, float* means, float* stds, float* lens, float* signals,
+                          int32_t* labels)
 {
     if (!t) return DS_ERR_INVALID;
     const size_t n = t->lines.size();
     if (n == 0) return 0;
+    if (capacity_rows < (int64_t)n) {
+        t->err = "ds_tsv_parse_into: the caller's arrays hold " + std::to_string(capacity_rows) + " rows, the located item has " + std::to_string(n);
+        return DS_ERR_INVALID;
+    }
     if (!kmer || !means || !stds || !lens || !signals || !labels) return DS_ERR_INVALID;
     const RowDest dest{kmer, means, stds, lens, signals, labels};
     // rows are dealt 16 at a time (~60 us of parsing): with 64-row grains a 1,000-row item was 16 grains, and 9 .. 15
@@ -533,7 +541,7 @@ int64_t ds_tsv_next(ds_tsv* t, int32_t max_reads)
     const size_t K = (size_t)t->kmer_len, S = (size_t)t->signal_len, m = (size_t)n;
     t->kmer.resize(m * K); t->means.resize(m * K); t->stds.resize(m * K); t->lens.resize(m * K);
     t->signals.resize(m * S); t->labels.resize(m);
-    return ds_tsv_parse_into(t, t->kmer.data(), t->means.data(), t->stds.data(), t->lens.data(), t->signals.data(), t->labels.data());
+    return ds_tsv_parse_into(t, n, t->kmer.data(), t->means.data(), t->stds.data(), t->lens.data(), t->signals.data(), t->labels.data());
 }
 
 int64_t ds_tsv_size(const ds_tsv* t) { return t ? (int64_t)t->size : DS_ERR_INVALID; }
@@ -585,6 +593,7 @@ int ds_tsv_set_range(ds_tsv* t, int64_t begin, int64_t end)
     t->pos = (size_t)begin;
     t->limit = (size_t)end;
     t->scanned = t->pos; t->pend.clear(); t->pend_head = 0;
+    t->lines.clear();              // a rewind also drops located-but-unparsed rows (and the error state a failed parse left)
     t->range_begin = (size_t)begin;
     t->line_no = 0;
     t->err.clear();

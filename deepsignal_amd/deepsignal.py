@@ -24,7 +24,7 @@ def main_call_mods(args):
     call_mods(args.input_path, args.model_path, args.result_file, args.kmer_len, args.cent_signals_len,
               args.batch_size, args.learning_rate, args.class_num, args.nproc, str2bool(args.is_gpu),
               str2bool(args.is_rnn), str2bool(args.is_base), str2bool(args.is_cnn), f5_args,
-              precision=args.precision)
+              precision=args.precision, engine_batch=args.engine_batch)
 
 
 def main_extraction(args):
@@ -72,14 +72,22 @@ def build_parser():
     g.add_argument("--model_path", "-m", required=True,
                    help="TensorFlow checkpoint prefix of a reference-trained model (<prefix>.index + .data-*), "
                         "or a DSAMDW01 weight file")
-    g.add_argument("--precision", default="fp32", choices=["fp32", "bf16", "bf16_all"],
-                   help="fp32 (reference numerics) or bf16 conv+FC operands with fp32 accumulate and fp32 BiLSTM")
+    g.add_argument("--precision", default="fp32", choices=["fp32", "bf16x3", "bf16", "bf16_all"],
+                   help="fp32 (reference numerics, native fp32 matrix instructions); bf16x3 (fp32-class results: fp32 operands carried "
+                        "as three bf16 terms on the bf16 matrix pipe, held to the fp32 parity bars); bf16 / bf16_all (bf16 conv+FC "
+                        "operands with fp32 accumulate: fast, probabilities good to ~1e-2 only)")
+    g.add_argument("--engine_batch", type=int, default=0,
+                   help="sites per GPU forward the engine is created for (default 0: the larger of --batch_size and 4096; results do "
+                        "not depend on it, device and pinned memory grow with it -- lower it on a small or shared GPU; the "
+                        "environment variable DS_ENGINE_BATCH does the same)")
     g.add_argument("--is_cnn", default="yes")
     g.add_argument("--is_rnn", default="yes")
     g.add_argument("--is_base", default="yes")
     g.add_argument("--kmer_len", "-x", type=int, default=17)
     g.add_argument("--cent_signals_len", "-y", type=int, default=360)
-    g.add_argument("--batch_size", "-b", type=int, default=512)
+    g.add_argument("--batch_size", "-b", type=int, default=512,
+                   help="the reference's rows per sess.run; here the granularity rows are handed to the engine in, NOT the sites per "
+                        "GPU forward (see --engine_batch): a site's result does not depend on its batch mates")
     g.add_argument("--learning_rate", "-l", type=float, default=0.001)
     g.add_argument("--class_num", "-c", type=int, default=2)
     g = p.add_argument_group("OUTPUT")

@@ -67,7 +67,7 @@ def _bind():
     lib.ds_tsv_next.restype = i64
     lib.ds_tsv_locate.argtypes = [vp, i32]
     lib.ds_tsv_locate.restype = i64
-    lib.ds_tsv_parse_into.argtypes = [vp, vp, vp, vp, vp, vp, vp]
+    lib.ds_tsv_parse_into.argtypes = [vp, i64, vp, vp, vp, vp, vp, vp]
     lib.ds_tsv_parse_into.restype = i64
     for name in ("kmer", "means", "stds", "lens", "signals", "labels", "info", "info_offsets"):
         f = getattr(lib, "ds_tsv_" + name)
@@ -148,7 +148,7 @@ class FeatureReader:
             kmer, labels = np.empty((n, K), np.int32), np.empty((n,), np.int32)
             means, stds, lens = (np.empty((n, K), np.float32) for _ in range(3))
             signals = np.empty((n, S), np.float32)
-            got = lib.ds_tsv_parse_into(h, kmer.ctypes.data, means.ctypes.data, stds.ctypes.data, lens.ctypes.data,
+            got = lib.ds_tsv_parse_into(h, n, kmer.ctypes.data, means.ctypes.data, stds.ctypes.data, lens.ctypes.data,
                                         signals.ctypes.data, labels.ctypes.data)
             if got != n:
                 raise ValueError("feature file: %s" % lib.ds_tsv_error(h).decode())

@@ -194,9 +194,14 @@ int64_t ds_tsv_next(ds_tsv *t, int32_t max_reads);
 /* The same in two steps, for a caller that owns the destination arrays (no copy out of the reader): ds_tsv_locate() finds
  * the rows of the next item and returns their number n; ds_tsv_parse_into() parses them into kmer int32[n,kmer_len],
  * means / stds / lens float[n,kmer_len], signals float[n,signal_len], labels int32[n] (the sampleinfo columns stay
- * behind ds_tsv_info / ds_tsv_info_offsets) and returns n, or a negative code on a malformed row. */
+ * behind ds_tsv_info / ds_tsv_info_offsets) and returns n, or a negative code on a malformed row.
+ * Contract: EXACTLY ONE ds_tsv_parse_into() per successful ds_tsv_locate() with n > 0. ds_tsv_locate() advances the reader, so a
+ * second locate while rows are pending is refused (DS_ERR_INVALID) instead of silently dropping the item; capacity_rows is the
+ * number of rows the caller's arrays hold and must be >= n (DS_ERR_INVALID otherwise, nothing written); after a parse error
+ * (malformed row) the located rows stay pending: ds_tsv_set_range() (a rewind) or ds_tsv_close() are the ways on. */
 int64_t ds_tsv_locate(ds_tsv *t, int32_t max_reads);
-int64_t ds_tsv_parse_into(ds_tsv *t, int32_t *kmer, float *means, float *stds, float *lens, float *signals, int32_t *labels);
+int64_t ds_tsv_parse_into(ds_tsv *t, int64_t capacity_rows, int32_t *kmer, float *means, float *stds, float *lens, float *signals,
+                          int32_t *labels);
 /* Multi-GPU call_mods (sites sharded BY READ): each rank parses only its own byte ranges of the file.
  * ds_tsv_align(t, pos) = the first read boundary at or after byte pos (start of the first line beginning at or after
  * pos whose read id differs from the line before it; 0 -> 0; file size when none follows), a function of the file

@@ -262,8 +262,19 @@ def test_locate_then_parse_into_equals_next(tmp_path):
         i += 1
     assert i == len(two_step) and sum(len(it.labels) for it in two_step) == len(reads)
     # nothing located: parse_into has nothing to do; null destination after a locate: refused
-    assert lib.ds_tsv_parse_into(rd._h, None, None, None, None, None, None) == 0
+    assert lib.ds_tsv_parse_into(rd._h, 0, None, None, None, None, None, None) == 0
     rd.set_range(0, rd.size)
     assert lib.ds_tsv_locate(rd._h, 1) == lens[0]
-    assert lib.ds_tsv_parse_into(rd._h, None, None, None, None, None, None) < 0
+    assert lib.ds_tsv_parse_into(rd._h, lens[0], None, None, None, None, None, None) < 0
+    # the contract of the two-step form (include/deepsignal_hip.h): one parse_into per locate -- a second locate while rows are
+    # pending is refused instead of dropping the item, and arrays too small for the item are refused before anything is written
+    assert lib.ds_tsv_locate(rd._h, 1) < 0 and b"have not been parsed" in lib.ds_tsv_error(rd._h)
+    n0 = lens[0]
+    kmer, labels = np.full((n0, K), -7, np.int32), np.empty((n0,), np.int32)
+    means, stds, ln = (np.empty((n0, K), np.float32) for _ in range(3))
+    sig = np.empty((n0, S), np.float32)
+    ptrs = [a.ctypes.data for a in (kmer, means, stds, ln, sig, labels)]
+    assert lib.ds_tsv_parse_into(rd._h, n0 - 1, *ptrs) < 0 and (kmer == -7).all()
+    assert lib.ds_tsv_parse_into(rd._h, n0, *ptrs) == n0 and np.array_equal(kmer, two_step[0].kmer[:n0])
+    assert lib.ds_tsv_locate(rd._h, 1) == lens[1]          # parsed: the reader moves on
     rd.close()

@@ -27,5 +27,9 @@ def test_cu_sharing_register_budgets():
                       ("lstm_cell_bf16_kernel<2, 2>", 168), ("lstm_cell_bf16_kernel<1, 1>", 96)):
         hit = [r for n, r in res.items() if name in n]
         assert len(hit) == 1 and hit[0]["vgprs"] <= cap, (name, hit)
+    # round 5: the split-operand fused chain runs ONE 512-thread workgroup per CU (2 waves per SIMD: <= 256 registers)
+    for tm in (1, 2, 3):
+        hit = [r for n, r in res.items() if "inception_fused_split_kernel<%d>" % tm in n]
+        assert len(hit) == 1 and hit[0]["vgprs"] <= 256, (tm, hit)
     # no kernel of the library may spill
     assert all(r["scratch_bytes"] == 0 for r in res.values()), {n: r for n, r in res.items() if r["scratch_bytes"]}

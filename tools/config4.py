@@ -73,15 +73,32 @@ def run_shard(sites, batch=512, precision="fp32", weights=None, pool_sites=4096,
     if dist is not None:
         dist.barrier(); torch.cuda.synchronize()
     tele = [gpu_telemetry()] if telemetry else None
+    mid = {}
+    sampler = None
+    if telemetry:
+        # the mid-run sample forks rocm-smi (a Python program: hundreds of ms). It runs on a helper thread that the timed loop
+        # only signals, so the feeding thread never waits for it; how long the sample took is recorded
+        import threading
+        go = threading.Event()
+
+        def _sample():
+            go.wait()
+            ts = time.perf_counter()
+            mid["sample"] = gpu_telemetry()
+            mid["seconds"] = round(time.perf_counter() - ts, 3)
+        sampler = threading.Thread(target=_sample, daemon=True)
+        sampler.start()
     t0 = time.perf_counter()
     for i in range(nsteps):
         step(i)
         if telemetry and i == nsteps // 2:
-            # (a ~10 ms host call in the middle of thousands of steps: the slots keep the GPU busy meanwhile)
-            tele.append(gpu_telemetry())
+            go.set()
     eng.sync()
     t_compute = time.perf_counter() - t0
     if telemetry:
+        go.set()
+        sampler.join()
+        tele.append(mid.get("sample"))
         tele.append(gpu_telemetry())
     # global site index of my j-th site: read my_reads[j // 20], position j % 20
     def index_of_rank(r, cnt):       # the sharding rule: rank r owns reads r, r + world, ...; 20 sites per read
@@ -101,9 +118,11 @@ def run_shard(sites, batch=512, precision="fp32", weights=None, pool_sites=4096,
     total = nreads * SITES_PER_READ
     rec = {"config": "configs[3]: per-read shard of %d synthetic sites, %d GPU(s), batch %d, %s" % (total, world, B, precision),
            "n_gpus": world, "sites": total, "seconds": round(elapsed, 3), "seconds_compute_max_rank": round(t_compute, 3),
-           "sites_per_s": round(total / elapsed, 1), "gather_bytes": total * 12, "pool_sites": NPOOL * B}
+           "sites_per_s": round(total / elapsed, 1), "sites_per_s_compute_only": round(total / t_compute, 1),
+           "seconds_gather": round(elapsed - t_compute, 3), "gather_bytes": total * 12, "pool_sites": NPOOL * B}
     if telemetry:
         rec["gpu_telemetry_before_mid_after"] = tele
+        rec["mid_sample_seconds_on_helper_thread"] = mid.get("seconds")
     return rec, g_act, g_pred, my_reads
 
 

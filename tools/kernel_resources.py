@@ -18,8 +18,9 @@ def kernel_resources():
         for i, name in enumerate(only):
             src = os.path.join(ROOT, "deepsignal_amd", "csrc", name)
             out = os.path.join(tmp, "k%d.s" % i)
-            subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-unused-value", "--cuda-device-only", "-S",
-                            "-x", "hip", "-o", out, src], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            extra = ["-fno-slp-vectorize"] if name == "ds_split.hip" else []      # as deepsignal_amd/csrc/Makefile builds it
+            subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-unused-value", "--cuda-device-only", "-S"] + extra +
+                           ["-x", "hip", "-o", out, src], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
             text += open(out).read()
     res = {}
     for m in re.finditer(r"\.amdhsa_kernel (\S+)\n(.*?)\.end_amdhsa_kernel", text, re.S):
