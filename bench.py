@@ -130,14 +130,18 @@ def _norm_kernel(s):
     return s.replace(" ", "").replace(",false>", ">").replace(",true>", ",bf16>")
 
 
-def _recorded_commit(path):
-    """Commit that last touched a profiles/ file (so a reader can tell which build the constant belongs to)."""
-    import subprocess
+def _build_of(rec):
+    """Which build a committed PMC constant belongs to: the identity tools/build_identity.py wrote into the file when the counters
+    were collected (commit of the snapshot + a hash of the kernel sources), next to the same hash of THIS run's sources."""
     try:
-        out = subprocess.run(["git", "log", "-1", "--format=%h", "--", path], cwd=ROOT, capture_output=True, text=True, timeout=10)
-        return out.stdout.strip() or None
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        from build_identity import sources_sha16
+        now = sources_sha16()
     except Exception:
-        return None
+        now = None
+    was = rec.get("sources_sha16")
+    return "collected at commit %s, sources %s; this run's sources %s%s" % (
+        rec.get("commit"), was, now, "" if was is None or now is None else (" (same)" if was == now else " (DIFFERENT build)"))
 
 
 def pmc_traffic(kernel_name, pattern="r[0-9][0-9]_pmc_traffic.json"):
@@ -152,8 +156,8 @@ def pmc_traffic(kernel_name, pattern="r[0-9][0-9]_pmc_traffic.json"):
             if _norm_kernel(name) == _norm_kernel(kernel_name):
                 return {"traffic": round(v["hbm_bytes_per_launch"]), "traffic_unit": "B/launch",
                         "traffic_fetch": round(v["fetch_bytes_per_launch"]), "traffic_write": round(v["write_bytes_per_launch"]),
-                        "traffic_source": "committed constant, NOT measured in this run: profiles/%s (recorded at commit %s; %s)"
-                                          % (os.path.basename(path), rec.get("commit") or _recorded_commit(path), rec["source"])}
+                        "traffic_source": "committed constant, NOT measured in this run: profiles/%s (%s; %s)"
+                                          % (os.path.basename(path), _build_of(rec), rec["source"])}
     except (OSError, ValueError, KeyError, TypeError):
         pass
     return {"traffic": None}
@@ -168,8 +172,8 @@ def pmc_mfma_busy(kernel_name):
         for name, v in rec["kernels"].items():
             if _norm_kernel(name) == _norm_kernel(kernel_name):
                 return {"mfma_busy_pmc": v["mfma_busy_frac_at_inkernel_clock"],
-                        "mfma_busy_source": "committed constant, NOT measured in this run: profiles/%s (recorded at commit %s)"
-                                            % (os.path.basename(path), rec.get("commit") or _recorded_commit(path))}
+                        "mfma_busy_source": "committed constant, NOT measured in this run: profiles/%s (%s)"
+                                            % (os.path.basename(path), _build_of(rec))}
     except (OSError, ValueError, KeyError, TypeError):
         pass
     return {"mfma_busy_pmc": None}
@@ -305,6 +309,8 @@ def configs2_leg(Engine, w, torch, dev, local_rank, host_path=True):
                               "kept in LDS from module to module)",
                     "us_per_step": round(c_ms * 1e3, 1), "algorithmic_bytes": c_bytes, "achieved": round(c_bytes / (c_ms * 1e-3) / 1e9, 1),
                     "unit": "GB/s", "peak": 8000.0, "frac": round(c_bytes / (c_ms * 1e-3) / 8e12, 4),
+                    "hbm_side_frac": None,      # counter-measured bytes / time / 8 TB/s (filled in below from the committed PMC pass)
+                    "bf16_mfma_frac": round(sum(k["flops"] for k in conv) / 6 / (c_ms * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4),
                     "how": "module-granular bytes (SURVEY.md 8d): 992 B per module row (512 in + 480 out, bf16) x 564 module rows per "
                            "site x 4096 sites / HIP-event duration, every launch on one stream. The kernel moves fewer bytes than that: "
                            "only a chain's first module reads rows from HBM and only its last one writes them (traffic_per_step)"}

@@ -119,6 +119,7 @@ struct Plan {
 // One in-flight forward: private workspace, stream pair, fork/join events and captured graphs.
 struct Slot {
     hipStream_t s0 = nullptr, s1 = nullptr;
+    bool owns_s1 = true;                 // false: DS_TUNE_SHARED_EVENT_STREAM -- s1 is slot 0's event-model stream
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     float* d_in = nullptr;               // [kmer | means | stds | sanums | signals] (the five pointers below point into it)
     int* d_kmer = nullptr;
@@ -163,6 +164,7 @@ struct ds_handle {
     bool fold_fc = false;     // joint model folded into one J x class_num matrix (fp32, not DS_TUNE_NO_FOLD_FC, not debug)
     bool serial = false;      // DS_TUNE_SERIAL: every launch of a forward on ONE stream (stand-alone kernel times)
     bool serial_modules = false;   // DS_TUNE_NO_CHAIN: one launch per inception module instead of one per width class
+    bool shared_s1 = false;        // DS_TUNE_SHARED_EVENT_STREAM: every slot's BiLSTM on slot 0's event-model stream, eager issue
     int fuse_max_spt = 8;     // sites per fused-module tile, upper bound
     int fuse_min_tiles = 128; // fused-module grids keep at least this many workgroups when the batch allows it
     bool lstm_bf16 = false;   // DS_PRECISION_BF16_ALL: additionally bf16 h / weight operands in the LSTM matmuls (fp32 accumulate,
@@ -1328,6 +1330,8 @@ static int ds_create_impl(const ds_config* cfg, ds_handle** out)
     h->no_fused = (flags & DS_TUNE_NO_FUSED) != 0;
     h->serial = (flags & DS_TUNE_SERIAL) != 0;
     h->serial_modules = (flags & DS_TUNE_NO_CHAIN) != 0;
+    h->shared_s1 = (flags & DS_TUNE_SHARED_EVENT_STREAM) != 0 && !h->serial;
+    if (h->shared_s1) h->use_graph = false;      // the launches must stay on the shared stream (a graph node has no stream)
     h->fold_fc = !(flags & DS_TUNE_NO_FOLD_FC) && cfg->reserved[0] == 0 && cfg->class_num <= 16;
     h->lstm_variant = cfg->reserved[3];
     if (cfg->reserved[4] > 0) h->fuse_max_spt = cfg->reserved[4];
@@ -1349,7 +1353,8 @@ static int ds_create_impl(const ds_config* cfg, ds_handle** out)
     for (Slot& sl : h->slots) {
         h->cur = &sl;
         CK(hipStreamCreateWithFlags(&sl.s0, hipStreamNonBlocking));
-        CK(hipStreamCreateWithFlags(&sl.s1, hipStreamNonBlocking));
+        if (h->shared_s1 && &sl != &h->slots[0]) { sl.s1 = h->slots[0].s1; sl.owns_s1 = false; }
+        else CK(hipStreamCreateWithFlags(&sl.s1, hipStreamNonBlocking));
         CK(hipEventCreateWithFlags(&sl.ev_fork, hipEventDisableTiming));
         CK(hipEventCreateWithFlags(&sl.ev_join, hipEventDisableTiming));
         if (!rc) rc = alloc_workspace(h);
@@ -1389,7 +1394,7 @@ void ds_destroy(ds_handle* h)
         if (sl.ev_fork) hipEventDestroy(sl.ev_fork);
         if (sl.ev_join) hipEventDestroy(sl.ev_join);
         if (sl.s0) hipStreamDestroy(sl.s0);
-        if (sl.s1) hipStreamDestroy(sl.s1);
+        if (sl.s1 && sl.owns_s1) hipStreamDestroy(sl.s1);
     }
     for (void* p : h->allocs) hipFree(p);
     delete h;
@@ -1888,7 +1893,7 @@ int ds_get_kernel_stat(ds_handle* h, int32_t index, char* name, int32_t name_cap
 int ds_set_graph(ds_handle* h, int32_t enable)
 {
     if (!h) return DS_ERR_INVALID;
-    h->use_graph = enable != 0;
+    h->use_graph = enable != 0 && !h->shared_s1;      // DS_TUNE_SHARED_EVENT_STREAM handles always issue eagerly
     return DS_OK;
 }
 

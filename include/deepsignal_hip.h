@@ -87,6 +87,10 @@ typedef struct ds_config {
 /* diagnostic (same bits out): bf16 modes launch every inception module on its own instead of chaining the modules of one
    width class (layers.py:205-232: 1-3, 4-8, 9-11) inside one launch */
 #define DS_TUNE_NO_CHAIN 16
+/* Diagnostic (tools/soak.py shared): every pipeline slot's event-model (BiLSTM) launches go to ONE stream shared by all slots and
+   forwards are issued eagerly (no captured graphs): the configuration in which round 4's persistent-BiLSTM experiment faulted
+   (DESIGN.md section 9). Results are unchanged (same bits); slower than the default. */
+#define DS_TUNE_SHARED_EVENT_STREAM 32
 /* ds_config.reserved[3] */
 #define DS_LSTM_TILING_AUTO 0    /* by forward size */
 #define DS_LSTM_TILING_NARROW 1  /* one 32-column n-tile per wave  */

@@ -8,7 +8,9 @@ high on dispatches shorter than about 0.3 ms" (the quotient GUI_ACTIVE / duratio
 s_memtime / s_memrealtime stamps give under this load (2.17 GHz, tools/lstm_stamps.py): busy cycles per SIMD over the
 cycles the SIMD actually had."""
 INKERNEL_CLOCK_GHZ = 2.17
-import csv, glob, collections, json, sys
+import csv, glob, collections, json, os, sys
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from build_identity import build_identity
 f = (glob.glob(sys.argv[1] + '/*/*counter_collection.csv') + glob.glob(sys.argv[1] + '/*counter_collection.csv'))[0]
 disp = collections.OrderedDict()
 for r in csv.DictReader(open(f)):
@@ -31,4 +33,4 @@ for name, a in agg.items():
     print('%-44s n %4d  mean %8.1f us  GUI_ACTIVE/duration %.2f GHz  MFMA pipe busy %5.1f %% (of GUI_ACTIVE)  %5.1f %% (of duration x %.2f GHz)' % (
         name, a['n'], a['dur_us'] / a['n'], a['gui'] / a['dur_us'] / 1e3, 100 * util, 100 * util2, INKERNEL_CLOCK_GHZ))
 if len(sys.argv) > 2:
-    json.dump({'source': 'rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -- python3 tools/probe_engine.py fp32 512 threestep (every launch on one stream)', 'kernels': out}, open(sys.argv[2], 'w'), indent=1)
+    json.dump({'source': 'rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -- python3 tools/probe_engine.py fp32 512 threestep (every launch on one stream)', 'kernels': out, **build_identity()}, open(sys.argv[2], 'w'), indent=1)

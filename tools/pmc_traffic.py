@@ -11,7 +11,11 @@ import collections
 import csv
 import glob
 import json
+import os
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from build_identity import build_identity  # noqa: E402
 
 
 def per_kernel(d, counter):
@@ -47,7 +51,7 @@ def main():
     if len(sys.argv) > 3:
         json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of bench.py; "
                              "FETCH_SIZE KiB x2 (gfx950 wide-read correction), WRITE_SIZE KiB x1",
-                   "kernels": out}, open(sys.argv[3], "w"), indent=1)
+                   "kernels": out, **build_identity()}, open(sys.argv[3], "w"), indent=1)
 
 
 if __name__ == "__main__":

@@ -3,7 +3,9 @@ set -u
 export TMPDIR=/tmp
 O=gpurun_out/ws; mkdir -p $O
 
-for cfg in "bf16_all 4096" "fp32 512 threestep"; do
+# usage: tools/wave_states.sh ["<probe_engine args>" ...]   (default: the bf16_all / 4096, fp32 / 512 and bf16x3 / 512 engines)
+if [ $# -eq 0 ]; then set -- "bf16_all 4096" "fp32 512 threestep" "bf16x3 512 threestep"; fi
+for cfg in "$@"; do
   tag=$(echo $cfg | tr ' ' '_')
   rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA --output-format csv -d $O/${tag}_p1 -- python3 tools/probe_engine.py $cfg > /dev/null 2> $O/${tag}_p1.err
   rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM --output-format csv -d $O/${tag}_p2 -- python3 tools/probe_engine.py $cfg > /dev/null 2> $O/${tag}_p2.err
