@@ -30,6 +30,8 @@ Extra objects:
                       host buffers in, results out, n = 512 and n = 8192 per call
   e2e_tsv             feature TSV -> result TSV through call_mods (native reader + formatter + the default engine)
   configs2_bf16_batch4096   BASELINE configs[2]: bf16_all / bf16 throughput at batch 4096 and the conv path's HBM fraction
+  e2e_tsv_sharded     N > 1 only: the product's multi-GPU route (by-read byte ranges of one feature TSV, per-rank engines, row text
+                      gathered to rank 0 through OrderedRowGather), with the host-only parse ceiling of the same ranges beside it
   fp32_class_bf16x3   DS_PRECISION_BF16X3 (fp32 operands as three bf16 terms on the bf16 matrix pipe): the same steps, its own
                       roofline (bf16 MFMA peak / 6 products per MAC), accuracy against the float64 oracle on the stress set
 """
@@ -140,6 +142,8 @@ def _build_of(rec):
     except Exception:
         now = None
     was = rec.get("sources_sha16")
+    if was is None and rec.get("commit") is None:
+        return "no build identity in the file (collected before round 5); this run's sources %s" % now
     return "collected at commit %s, sources %s; this run's sources %s%s" % (
         rec.get("commit"), was, now, "" if was is None or now is None else (" (same)" if was == now else " (DIFFERENT build)"))
 
@@ -441,6 +445,91 @@ def np_tile(a, n, off):
     return np.ascontiguousarray(a[idx])
 
 
+def write_feature_tsv(path, feats, rows):
+    """`rows` feature rows (12 columns, 20 sites per read) cycling over the synthetic sites of `feats`."""
+    from deepsignal_amd.utils.process_utils import code2base_dna
+    nuniq = min(rows, feats["kmer"].shape[0])
+    tails = []
+    for i in range(nuniq):          # columns 7..12 of a row; the first six are cheap and written per copy below
+        tails.append("\t".join(["".join(code2base_dna[int(c)] for c in feats["kmer"][i]),
+                                ",".join("%.6f" % x for x in feats["means"][i]), ",".join("%.6f" % x for x in feats["stds"][i]),
+                                ",".join(str(int(x)) for x in feats["sanums"][i]),
+                                ",".join("%.6f" % x for x in feats["signals"][i]), "1"]))
+    with open(path, "w") as f:
+        for i in range(rows):
+            f.write("chr1\t%d\t+\t%d\tread_%06d\tt\t%s\n" % (1000 + i, i, i // 20, tails[i % nuniq]))
+    return os.path.getsize(path)
+
+
+def e2e_tsv_sharded(Engine, w, feats, dist, rank, world, gpu_index, cdev, rows_per_rank, batch):
+    """The PRODUCT's multi-GPU route inside the scaling run: feature TSV -> result TSV through
+    call_mods(dist=...) -- every rank parses only its own byte ranges of ONE shared file (cut at read boundaries), runs them on its
+    own engine (created as `deepsignal call_mods` creates it), formats its own rows, and the row text travels to rank 0 through
+    sharding.OrderedRowGather's collectives (reference topology: call_modifications.py:461-476, README.rst:15). Weak scaling:
+    rows_per_rank x world rows. Also measured, so that a flat curve is attributable: the HOST-ONLY parse rate of the same byte
+    ranges with the same per-rank thread count (the ceiling the 16-CPU cgroup quota of a box puts on TSV -> TSV)."""
+    import contextlib
+    import shutil
+    import tempfile
+    import torch
+    from deepsignal_amd import call_modifications as cm, fastio
+    rows = rows_per_rank * world
+    box = [None]
+    if rank == 0:
+        tmpdir = tempfile.mkdtemp(prefix="ds_bench_sharded_")
+        size = write_feature_tsv(os.path.join(tmpdir, "features.tsv"), feats, rows)
+        box[0] = (tmpdir, size)
+    dist.broadcast_object_list(box, src=0)
+    tmpdir, size = box[0]
+    path, out = os.path.join(tmpdir, "features.tsv"), os.path.join(tmpdir, "calls.tsv")
+    threads = max(1, fastio.usable_cpus() // cm._local_world(world))
+    try:
+        # host-only: parse this rank's byte ranges (what _call_mods_sharded's reader does), nothing else
+        rd = fastio.FeatureReader(path, 17, 360, nthreads=threads)
+        per_rank = max(1, min(4096, rd.size // max(1, world * cm.SHARD_CHUNK_BYTES)))
+        cuts = rd.cut_points(world * per_rank)
+        t0 = time.perf_counter()
+        n_parsed = 0
+        for c in range(rank, world * per_rank, world):
+            rd.set_range(cuts[c], cuts[c + 1])
+            for item in rd.items(50):
+                n_parsed += len(item.labels)
+        t_parse = time.perf_counter() - t0
+        rd.close()
+        eng = Engine(device=gpu_index, max_batch=cm.ENGINE_BATCH["fp32"])
+        eng.load_weights(w)
+        times = []
+        with contextlib.redirect_stdout(sys.stderr):
+            for rep in range(2):               # rep 0 = warm-up (page cache, plans, pinned staging)
+                dist.barrier()
+                t0 = time.perf_counter()
+                n = cm.call_mods(path, "unused", out, 17, 360, batch, 0.001, 2, 1, True, True, True, True, None, engine=eng, dist=dist,
+                                 force_sharded=True)
+                dist.barrier()
+                times.append(time.perf_counter() - t0)
+        eng.close()
+        stat = torch.tensor([times[-1], t_parse, float(n_parsed)], dtype=torch.float64, device=cdev)
+        every = [torch.zeros_like(stat) for _ in range(world)]
+        dist.all_gather(every, stat)
+        every = [e.cpu().tolist() for e in every]
+        ok = (n == rows) and (rank != 0 or sum(1 for _ in open(out)) == rows)
+    finally:
+        dist.barrier()
+        if rank == 0:
+            shutil.rmtree(tmpdir, ignore_errors=True)
+    el = max(e[0] for e in every)
+    parse_rates = [e[2] / e[1] if e[1] > 0 else 0.0 for e in every]
+    return {"value": round(rows / el, 1), "unit": "sites/s", "rows": rows, "rows_per_rank": rows_per_rank, "input_MB": round(size / 1e6, 1),
+            "seconds": round(el, 3), "complete": bool(ok), "engine": "default (folded joint model), fp32, max_batch %d" % cm.ENGINE_BATCH["fp32"],
+            "parse_threads_per_rank": threads, "usable_cpus": fastio.usable_cpus(),
+            "host_parse_only": {"sites_per_s_per_rank": [round(r, 1) for r in parse_rates], "sites_per_s_all_ranks": round(sum(parse_rates), 1),
+                                "us_per_row_per_thread": round(1e6 * threads / max(parse_rates[0], 1e-9), 3),
+                                "what": "the same byte ranges through the native reader alone, same thread count: the ceiling of TSV -> TSV on "
+                                        "this box's host cores (all ranks parsing at once would share the CPU quota: the sum is an upper bound)"},
+            "path": "call_mods(dist=process group): by-read byte ranges -> native reader -> ds_submit / ds_wait -> native formatter -> "
+                    "OrderedRowGather (row text to rank 0 over %s) -> rank 0 writes in file order" % dist.get_backend()}
+
+
 def e2e_tsv(eng, feats, rows, batch):
     """Feature TSV -> result TSV through the product's call_mods (native reader on the usable host cores, engine through
     submit / wait, native row formatter): what a user's `deepsignal call_mods -i features.tsv` sustains on this box."""
@@ -493,6 +582,8 @@ def main():
     ap.add_argument("--no-host-path", action="store_true", help="skip the pcie_inclusive and e2e_tsv legs")
     ap.add_argument("--no-fast-mode", "--no-three-step", dest="no_fast_mode", action="store_true",
                     help="skip the fast_mode_folded leg (the default engine with the folded joint model)")
+    ap.add_argument("--sharded-rows-per-rank", type=int, default=40960,
+                    help="N > 1: rows per rank of the e2e_tsv_sharded leg (feature TSV -> result TSV through the sharded call_mods route)")
     ap.add_argument("--no-split", action="store_true", help="skip the fp32_class_bf16x3 leg (DS_PRECISION_BF16X3 beside the headline)")
     ap.add_argument("--no-configs2", action="store_true", help="skip the BASELINE configs[2] leg (bf16 modes at batch 4096)")
     ap.add_argument("--lstm-tiling", default="auto", help="diagnostic: force a BiLSTM cell-kernel variant (Engine(lstm_tiling=...))")
@@ -790,6 +881,11 @@ def main():
         result["fast_mode_folded"] = fm
         engf.close()
     eng.close()
+    if dist is not None and world > 1 and not args.no_host_path:
+        # every rank takes part (collectives inside); rank 0 reports
+        shard = e2e_tsv_sharded(Engine, w, feats, dist, rank, world, gpu_index, cdev, args.sharded_rows_per_rank, BATCH)
+        if rank == 0:
+            result["e2e_tsv_sharded"] = shard
     if solo and not args.no_split:
         result["fp32_class_bf16x3"] = bf16x3_leg(Engine, w, torch, make_step, timed_windows, local_rank, args.slots, args.lstm_tiling, K)
     if solo and not args.no_configs2:

@@ -109,7 +109,8 @@ def test_bench_timed_windows_across_two_ranks_on_one_gpu(tmp_path):
     inside every window), both engines on GPU 0, collectives on gloo (--backend gloo --share-gpu): one JSON line, both
     ranks' window times in it, 2 x K x 512 sites gathered per window."""
     res, dt = _launch(2, [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5", "--windows", "3",
-                          "--no-profile-pass", "--backend", "gloo", "--share-gpu", "--collective-timeout", "120"], timeout=900)
+                          "--no-profile-pass", "--backend", "gloo", "--share-gpu", "--collective-timeout", "120",
+                          "--sharded-rows-per-rank", "3000"], timeout=900)
     assert res.returncode == 0, res.stderr.decode()[-3000:]
     lines = [l for l in res.stdout.decode().splitlines() if l.startswith("{")]
     assert len(lines) == 1, res.stdout.decode()[-2000:]
@@ -121,6 +122,11 @@ def test_bench_timed_windows_across_two_ranks_on_one_gpu(tmp_path):
     # value = all ranks' sites / the slowest rank's time
     assert abs(r["ms_per_step"] - sorted(max(w_) for w_ in pr)[1]) < 1e-3
     assert r["value"] > 1e5          # two engines sharing one GPU: about the one-GPU rate in total
+    # the product's multi-GPU route inside the same run: TSV -> TSV through the sharded call_mods, every
+    # row written, the per-rank parse threads and the host-only parse ceiling stated
+    sh = r["e2e_tsv_sharded"]
+    assert sh["complete"] and sh["rows"] == 6000 and sh["value"] > 0 and sh["parse_threads_per_rank"] >= 1
+    assert len(sh["host_parse_only"]["sites_per_s_per_rank"]) == 2 and sh["host_parse_only"]["sites_per_s_all_ranks"] > 0
     with open(os.path.join(str(tmp_path), "bench_two_ranks_one_gpu.json"), "w") as f:
         f.write(lines[0])
 
