@@ -44,7 +44,7 @@ struct PackedGemm {      // device-resident packed weights of one GEMM
     float* Bps = nullptr;   // DS_PRECISION_BF16X3: the same matrix as three bf16 term panels (pack_b_split)
 };
 
-enum OpKind { OP_GEMM, OP_STEM1, OP_MAXPOOL, OP_AVGPOOL, OP_HEAD, OP_FUSED, OP_PACKEV, OP_LSTM, OP_STEM23, OP_HEADF };
+enum OpKind { OP_GEMM, OP_STEM1, OP_MAXPOOL, OP_AVGPOOL, OP_HEAD, OP_FUSED, OP_PACKEV, OP_LSTM, OP_STEM23, OP_HEADF, OP_DENSES };
 
 struct Op {
     OpKind kind;
@@ -61,6 +61,7 @@ struct Op {
     FusedChain fc{};                      // OP_FUSED, bf16 modes: consecutive modules of one width class in ONE launch
     Stem23Args sa{};                      // OP_STEM23
     HeadFoldedArgs ha{};                  // OP_HEADF
+    SplitDense sd{};                      // OP_DENSES
     int tm = 0;
     double flops = 0;                     // algorithmic FLOPs of this launch
     hipEvent_t ev0 = nullptr, ev1 = nullptr;   // profiling mode only
@@ -71,7 +72,7 @@ struct Op {
 
 // per-kernel accumulators (one entry per __global__ function / template instantiation)
 enum KernelClass { K_GEMM_CONV = 0, K_GEMM_FC, K_GEMM_LSTM, K_GEMM_CONV_WIDE, K_GEMM_CONV_POOL, K_GEMM_FC_DENSE, K_GEMM_LSTM_DENSE, K_FUSED1, K_FUSED2, K_FUSED3, K_STEM1, K_MAXPOOL, K_AVGPOOL, K_HEAD,
-                   K_GEMM_BCONV, K_GEMM_BCONV_POOL, K_GEMM_BFC, K_GEMM_BFC_DENSE, K_PACKEV, K_GEMM_BLSTM, K_GEMM_BLSTM_DENSE, K_FUSEDB1, K_FUSEDB2, K_FUSEDB3, K_GEMM_LSTM_T, K_GEMM_LSTM_T_DENSE, K_GEMM_BLSTM_T, K_GEMM_BLSTM_T_DENSE, K_LSTM_CELL1, K_LSTM_CELL2, K_LSTM_CELL4, K_LSTM_LDS1, K_LSTM_LDS2, K_STEM23, K_HEADF, K_LSTM_B11, K_LSTM_B12, K_LSTM_B22, K_STEM23B, K_FUSEDS1, K_FUSEDS2, K_FUSEDS3, K_COUNT };
+                   K_GEMM_BCONV, K_GEMM_BCONV_POOL, K_GEMM_BFC, K_GEMM_BFC_DENSE, K_PACKEV, K_GEMM_BLSTM, K_GEMM_BLSTM_DENSE, K_FUSEDB1, K_FUSEDB2, K_FUSEDB3, K_GEMM_LSTM_T, K_GEMM_LSTM_T_DENSE, K_GEMM_BLSTM_T, K_GEMM_BLSTM_T_DENSE, K_LSTM_CELL1, K_LSTM_CELL2, K_LSTM_CELL4, K_LSTM_LDS1, K_LSTM_LDS2, K_STEM23, K_HEADF, K_LSTM_B11, K_LSTM_B12, K_LSTM_B22, K_STEM23B, K_FUSEDS1, K_FUSEDS2, K_FUSEDS3, K_LSTM_S11, K_LSTM_S12, K_LSTM_S22, K_DENSE_SPLIT, K_COUNT };
 const char* const kKernelNames[K_COUNT] = {"gemm_kernel<1,2,4,1,0,0,1,1>", "gemm_kernel<1,3,4,1,0,0,2,1>", "gemm_kernel<1,4,4,1,1,0,1,1>",
                                            "gemm_kernel<2,2,2,2,0,0,1,1>", "gemm_kernel<1,2,4,1,0,1,1,1>", "gemm_kernel<1,3,4,1,0,2,2,1>",
                                            "gemm_kernel<1,4,4,1,1,2,1,1>", "inception_fused_kernel<1>",
@@ -87,7 +88,9 @@ const char* const kKernelNames[K_COUNT] = {"gemm_kernel<1,2,4,1,0,0,1,1>", "gemm
                                            "lstm_cell_kernel<1>", "lstm_cell_kernel<2>", "lstm_cell_kernel<4>",
                                            "lstm_cell_lds_kernel<1>", "lstm_cell_lds_kernel<2>", "stem23_kernel", "head_folded_kernel",
                                            "lstm_cell_bf16_kernel<1,1>", "lstm_cell_bf16_kernel<1,2>", "lstm_cell_bf16_kernel<2,2>", "stem23_bf16_kernel",
-                                           "inception_fused_split_kernel<1>", "inception_fused_split_kernel<2>", "inception_fused_split_kernel<3>"};
+                                           "inception_fused_split_kernel<1>", "inception_fused_split_kernel<2>", "inception_fused_split_kernel<3>",
+                                           "lstm_cell_split_kernel<1,1>", "lstm_cell_split_kernel<1,2>", "lstm_cell_split_kernel<2,2>",
+                                           "dense_split_kernel<2,2> (+ pack_joint_split_kernel)"};
 struct KernelStat {
     int64_t launches = 0;
     double total_ms = 0;
@@ -136,6 +139,7 @@ struct Slot {
     float *fc1o = nullptr, *logits = nullptr, *act = nullptr;
     int* pred = nullptr;
     float* joint = nullptr;              // bf16 mode: [B][JP] bf16 FC operand (event features | signal features | zero pad)
+    char* jsplit = nullptr;              // DS_PRECISION_BF16X3, three-step joint model: the joint rows as a fragment-major term image
 
     // ds_submit / ds_wait: pinned host staging of one batch (inputs in, 12 B/site out), allocated on first use
     char* pin_in = nullptr;
@@ -147,6 +151,12 @@ struct Slot {
     int last_n = 0;
 };
 
+// dense(J, J) with split operands moves 1.5x the operand bytes of the fp32 GEMM for 0.375x its matrix time; at 512 sites per forward
+// (188 tiles of 128 x 128) it is bound by operand delivery and no faster than the native fp32 GEMM (300 against 290 us), so the
+// planner keeps the fp32 GEMM below this many sites (ds_config.reserved[6] overrides; measured)
+#ifndef DS_SPLIT_DENSE_MIN_N
+#define DS_SPLIT_DENSE_MIN_N 2048
+#endif
 struct ds_handle {
     ds_config cfg{};
     std::string err;
@@ -156,6 +166,7 @@ struct ds_handle {
     int B = 512;
     bool is_cnn = true, is_rnn = true, is_base = true;   // model.py:28-29,59-75,89-95
     bool bf16 = false;    // DS_PRECISION_BF16: bf16 conv + FC operands (fp32 accumulate), fp32 BiLSTM
+    int split_dense_min_n = DS_SPLIT_DENSE_MIN_N;   // sites per forward from which dense(J, J) runs split (below: the native fp32 GEMM)
     bool split = false;   // DS_PRECISION_BF16X3: fp32 activations / weights carried as three bf16 terms through the bf16 matrix pipe
                           // (six products per MAC, fp32 accumulate) in the fused inception chains; everything else as fp32
     int lstm_variant = 0;     // ds_config.reserved[3] as given (DS_LSTM_TILING_*)
@@ -473,6 +484,7 @@ int finalize_weights(ds_handle* h)
                 std::vector<float> packed = h->lstm_bf16 ? pack_b_bf16(K, 4 * HID, wfun) : pack_b(K, 4 * HID, wfun);
                 pg.K = h->lstm_bf16 ? K / 2 : K; pg.N = 4 * HID;
                 if ((rc = upload(h, &pg.Bp, packed))) return rc;
+                if (h->split && (rc = upload(h, &pg.Bps, pack_b_split(K, 4 * HID, wfun)))) return rc;
                 if ((rc = upload(h, &pg.bias, bias->data))) return rc;
             }
             if (l == 0) {
@@ -537,6 +549,7 @@ int finalize_weights(ds_handle* h)
         std::vector<float> packed = h->bf16 ? pack_b_bf16(J, J, wfun) : pack_b(J, J, wfun);
         h->fc1.K = h->bf16 ? h->JP / 2 : J; h->fc1.N = J;
         if ((rc = upload(h, &h->fc1.Bp, packed))) return rc;
+        if (h->split && J % 16 == 0 && (rc = upload(h, &h->fc1.Bps, pack_b_split(J, J, wfun)))) return rc;
         h->fc1.bias = nullptr;
         if ((rc = upload(h, &h->fc2, w2->data))) return rc;
     }
@@ -564,13 +577,17 @@ int alloc_workspace(ds_handle* h)
     A(&h->cur->tmpA, B * h->wa * 96); A(&h->cur->tmpS, B * h->wa * 48); A(&h->cur->tmpB, B * h->wa * 64);
     A(&h->cur->sigfeat, B * h->SF);
     for (int d = 0; d < 2; ++d)
-        for (int l = 0; l < NLAYER; ++l) { A(&h->cur->H[d][l], (size_t)h->T * h->Bp32 * HID); A(&h->cur->Cst[d][l], (size_t)h->Bp32 * HID); }
+        for (int l = 0; l < NLAYER; ++l) {
+            // split cells keep h as three bf16 terms (6 bytes per unit) where the fp32 cells keep a float
+            A(&h->cur->H[d][l], (size_t)h->T * h->Bp32 * HID * (h->split ? 3 : 2) / 2); A(&h->cur->Cst[d][l], (size_t)h->Bp32 * HID);
+        }
     if (h->is_rnn)
         for (int d = 0; d < 2; ++d) A(&h->cur->hlast[d], B * HID);
     A(&h->cur->fc1o, B * h->J); A(&h->cur->logits, B * h->C);
     A(&h->cur->act, B * h->C + B);            // [act | pred]: one block, one D2H copy
     if (!rc) h->cur->pred = reinterpret_cast<int*>(h->cur->act + B * h->C);
     if (h->bf16) A(&h->cur->joint, B * (size_t)h->JP / 2);
+    if (h->split && !h->fold_fc && h->J % 16 == 0) A(&h->cur->jsplit, (size_t)(h->Bp32 / 32) * (h->J / 16) * 3 * 1024);
     // module outputs: ping-pong pair normally; one buffer per module in debug mode (for taps)
     // the modules of a width class run as a chain inside one launch (ds_internal.h FusedChain): a workgroup that is already
     // in module 5 must not write into the buffer a slower workgroup still reads module 4's (stride-2 pooled, differently
@@ -591,6 +608,12 @@ int alloc_workspace(ds_handle* h)
     }
     return rc;
 }
+
+// workgroup tile of the split-operand BiLSTM cells by sites per forward (measured on MI355X): the cells are
+// bound by operand delivery, so the widest tile that still fills the GPU wins
+#ifndef DS_SPLIT_LSTM_TILE
+#define DS_SPLIT_LSTM_TILE(n) ((n) >= 2048 ? 322 : 311)
+#endif
 
 int module_width(const ds_handle* h, int m) { return m < 3 ? h->wa : (m < 8 ? h->wb : h->wc); }
 
@@ -868,7 +891,10 @@ int build_plan(ds_handle* h, int n, Plan* plan)
                        : h->lstm_variant == DS_LSTM_TILING_NARROW ? 1 : h->lstm_variant == DS_LSTM_TILING_WIDE ? 4
                        : h->lstm_variant == DS_LSTM_TILING_LDS1 ? 101 : h->lstm_variant == DS_LSTM_TILING_LDS2 ? 102
                        : (n <= 1024 ? 101 : 102);
-        const size_t step = (size_t)h->Bp32 * HU;                          // floats of one time step in H (bf16 h: half)
+        const bool lsp = h->split;                                         // split cells (ds_split.hip): tile code 311 | 312 | 322
+        const int nt_split = h->lstm_variant == DS_LSTM_TILING_NARROW ? 311 : h->lstm_variant == DS_LSTM_TILING_LDS1 ? 312
+                             : h->lstm_variant == DS_LSTM_TILING_WIDE ? 322 : DS_SPLIT_LSTM_TILE(n);
+        const size_t step = lsp ? (size_t)h->Bp32 * HID * 3 / 2 : (size_t)h->Bp32 * HU;      // floats of one time step in H (bf16 h: half; split h: 3/2)
         for (int d = 0; d < T + NLAYER - 1; ++d) {
             LstmLaunch L;
             memset(&L, 0, sizeof L);
@@ -884,9 +910,10 @@ int build_plan(ds_handle* h, int n, Plan* plan)
                     LstmCell& C = L.cell[L.ncell++];
                     C.ax = l > 0 ? h->cur->H[dir][l - 1] + (size_t)t * step : nullptr;
                     C.ah = sidx > 0 ? h->cur->H[dir][l] + (size_t)tprev * step : nullptr;
-                    C.Bp = h->lstm_n[dir][l].Bp;
-                    // fp32: k-groups of 8 per n-tile panel (K padded to 32); bf16: k-steps of 16 (K padded to 64 elements)
-                    C.kg_stride = lbf ? (2 * h->lstm_n[dir][l].K + 63) / 64 * 64 / 16 : (h->lstm_n[dir][l].K + 31) / 32 * 32 / 8;
+                    C.Bp = lsp ? h->lstm_n[dir][l].Bps : h->lstm_n[dir][l].Bp;
+                    // fp32: k-groups of 8 per n-tile panel (K padded to 32); bf16 / split: k-steps of 16 (K padded to 64 elements)
+                    C.kg_stride = lsp ? (h->lstm_n[dir][l].K + 63) / 64 * 64 / 16
+                                  : lbf ? (2 * h->lstm_n[dir][l].K + 63) / 64 * 64 / 16 : (h->lstm_n[dir][l].K + 31) / 32 * 32 / 8;
                     C.bias = h->lstm_n[dir][l].bias;
                     C.table = l == 0 ? h->lstm_table[dir] : nullptr;
                     C.wfeat = h->lstm_wfeat[dir];
@@ -903,7 +930,8 @@ int build_plan(ds_handle* h, int n, Plan* plan)
                 return (a.ax != nullptr) + (a.ah != nullptr) > (b.ax != nullptr) + (b.ah != nullptr);
             });
             {   // workgroup tiles per work class, for lstm_logical_tile
-                const int per_cell = nt == 222 ? ((mtiles + 3) / 4) * 8 : nt == 212 ? ((mtiles + 1) / 2) * 8 : nt == 211 ? ((mtiles + 1) / 2) * 16
+                const int ntc = lsp ? nt_split - 100 : nt;      // the split tiles deal workgroups like the bf16 tiles of the same shape
+                const int per_cell = ntc == 222 ? ((mtiles + 3) / 4) * 8 : ntc == 212 ? ((mtiles + 1) / 2) * 8 : ntc == 211 ? ((mtiles + 1) / 2) * 16
                                      : nt > 100 ? ((mtiles + 1) / 2) * (16 / (nt - 100)) : ((mtiles + 3) / 4) * (32 / nt);
                 L.cls_tiles[0] = L.cls_tiles[1] = 0;
                 for (int i = 0; i < L.ncell; ++i) {
@@ -914,7 +942,7 @@ int build_plan(ds_handle* h, int n, Plan* plan)
             Op op{};
             op.kind = OP_LSTM; op.stream = 1; op.stage = st;
             op.launch_index = (int)plan->lstm_launches.size();
-            op.a = L.ncell; op.b = mtiles; op.c = nt;
+            op.a = L.ncell; op.b = mtiles; op.c = lsp ? nt_split : nt;
             op.flops = flops;
             plan->lstm_launches.push_back(L);
             rnn.push_back(op);
@@ -954,7 +982,22 @@ int build_plan(ds_handle* h, int n, Plan* plan)
         if (first_plan) h->stages[st].flops_per_site += 2.0 * h->J * h->C;
     } else {
     st = stage_id(h, "fc1", 0);
-    {
+    if (h->split && h->fc1.Bps && h->cur->jsplit && n >= h->split_dense_min_n) {
+        // dense(J, J) with split operands (ds_split.hip): the joint row's segments -> term image -> LDS-DMA ring GEMM
+        Op op{};
+        op.kind = OP_DENSES; op.stream = 0; op.stage = st;
+        SplitDense& d = op.sd;
+        int ns = 0;
+        if (h->is_rnn) { d.seg[ns] = h->cur->hlast[0]; d.len[ns++] = HID; d.seg[ns] = h->cur->hlast[1]; d.len[ns++] = HID; }
+        if (h->is_cnn) { d.seg[ns] = h->cur->sigfeat; d.len[ns++] = h->SF; }
+        for (; ns < 3; ++ns) { d.seg[ns] = h->cur->hlast[0] ? h->cur->hlast[0] : h->cur->sigfeat; d.len[ns] = 0; }
+        d.A = h->cur->jsplit; d.Bp = reinterpret_cast<const char*>(h->fc1.Bps); d.C = h->cur->fc1o;
+        d.n = n; d.N = h->J; d.mtiles = (n + 31) / 32; d.ntiles = (h->J + 31) / 32; d.ntiles_alloc = d.ntiles;
+        d.ksteps = h->J / 16; d.kg_stride = (h->J + 63) / 64 * 64 / 16;
+        op.flops = 2.0 * n * (double)h->J * h->J;
+        add_ew_op(tail, op);
+        if (first_plan) h->stages[st].flops_per_site += 2.0 * (double)h->J * h->J;
+    } else {
         GemmLaunch L{};
         GemmProblem P = base_problem(n, h->J, n, h->fc1);
         // joint = [fw h(T-1) | bw h(0) | signal features]: three A segments, no concat buffer (layers.py:171-172,250-252)
@@ -1019,7 +1062,11 @@ int issue_op(ds_handle* h, Plan& plan, const Op& op, hipStream_t s)
         HIPCHK(h, launch_pack_event_feat_bf16(h->cur->hlast[0], h->cur->hlast[1], h->cur->joint, n, h->JP, 0, s));
         break;
     case OP_LSTM:
-        HIPCHK(h, launch_lstm_cells(op.c, plan.lstm_launches[op.launch_index], s));
+        if (op.c >= 300) HIPCHK(h, launch_lstm_cells_split(op.c - 300, plan.lstm_launches[op.launch_index], s));
+        else HIPCHK(h, launch_lstm_cells(op.c, plan.lstm_launches[op.launch_index], s));
+        break;
+    case OP_DENSES:
+        HIPCHK(h, launch_dense_split(op.sd, s));
         break;
     case OP_STEM23:
         if (op.a) HIPCHK(h, launch_stem23_bf16(op.sa, s));
@@ -1122,7 +1169,9 @@ int kernel_class(const Op& op)
     case OP_AVGPOOL: return K_AVGPOOL;
     case OP_HEAD: return K_HEAD;
     case OP_PACKEV: return K_PACKEV;
-    case OP_LSTM: return op.c == 1 ? K_LSTM_CELL1 : op.c == 2 ? K_LSTM_CELL2 : op.c == 4 ? K_LSTM_CELL4 : op.c == 101 ? K_LSTM_LDS1
+    case OP_DENSES: return K_DENSE_SPLIT;
+    case OP_LSTM: if (op.c >= 300) return op.c == 311 ? K_LSTM_S11 : op.c == 312 ? K_LSTM_S12 : K_LSTM_S22;
+        return op.c == 1 ? K_LSTM_CELL1 : op.c == 2 ? K_LSTM_CELL2 : op.c == 4 ? K_LSTM_CELL4 : op.c == 101 ? K_LSTM_LDS1
                : op.c == 211 ? K_LSTM_B11 : op.c == 212 ? K_LSTM_B12 : op.c == 222 ? K_LSTM_B22 : K_LSTM_LDS2;
     }
     return K_HEAD;
@@ -1283,7 +1332,7 @@ extern "C" {
 const char* ds_version(void)
 {
     return "deepsignal_amd 0.4 (gfx950; fp32 MFMA, bf16 conv + FC and bf16_all operand modes; bf16x3 = fp32 operands as three bf16 "
-           "terms, six products per MAC, in: the eleven inception modules)";
+           "terms, six products per MAC, in: the eleven inception modules, the BiLSTM cells' recurrent and lower-layer products, dense(J, J) of the three-step joint model)";
 }
 
 const char* ds_last_error(const ds_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
@@ -1336,6 +1385,7 @@ static int ds_create_impl(const ds_config* cfg, ds_handle** out)
     h->lstm_variant = cfg->reserved[3];
     if (cfg->reserved[4] > 0) h->fuse_max_spt = cfg->reserved[4];
     if (cfg->reserved[5] > 0) h->fuse_min_tiles = cfg->reserved[5];
+    if (cfg->reserved[6] > 0) h->split_dense_min_n = cfg->reserved[6];
     h->lstm_frag = h->is_rnn && !h->lstm_bf16;
     h->Bp32 = (h->B + 31) / 32 * 32;
     h->JP = (h->J + 31) / 32 * 32;
@@ -1721,6 +1771,28 @@ int64_t ds_get_intermediate(ds_handle* h, const char* name, float* out, int64_t 
         if (l < 0 || l >= NLAYER) return fail(h, DS_ERR_INVALID, "bad lstm layer");
         const int64_t count = (int64_t)n * h->T * HID;
         if (count > capacity) return fail(h, DS_ERR_INVALID, "capacity too small");
+        if (h->split) {
+            // split cells keep h fragment-major in three bf16 terms: [T][m-tile][k-step s of 16 units][term][lane = 32 * half + r][8]
+            // holds term p of units 16 s + 8 half .. + 7 of site 32 * mtile + r (lstm_cell_split_kernel); h = the terms' sum, exactly
+            const size_t per_t = (size_t)h->Bp32 * HID * 3;
+            std::vector<uint16_t> tb((size_t)h->T * per_t);
+            if (hipMemcpy(tb.data(), h->cur->H[d][l], tb.size() * 2, hipMemcpyDeviceToHost) != hipSuccess) return fail(h, DS_ERR_HIP, "hipMemcpy D2H");
+            for (int i = 0; i < n; ++i)
+                for (int t = 0; t < h->T; ++t)
+                    for (int c = 0; c < HID; ++c) {
+                        float v = 0.0f;
+                        for (int p = 2; p >= 0; --p) {
+                            const size_t idx = (size_t)t * per_t + (size_t)(i / 32) * 32 * HID * 3 +
+                                               (((size_t)(c / 16) * 3 + p) * 64 + ((c % 16) / 8) * 32 + i % 32) * 8 + c % 8;
+                            const uint32_t u = (uint32_t)tb[idx] << 16;
+                            float f;
+                            memcpy(&f, &u, 4);
+                            v += f;
+                        }
+                        out[((size_t)i * h->T + t) * HID + c] = v;
+                    }
+            return count;
+        }
         if (h->lstm_bf16) {
             // bf16-operand cells keep h fragment-major in bf16: [T][m-tile][k-step s of 16 units][lane = 32 * half + r][8] holds
             // units 16 s + 8 half .. + 7 of site 32 * mtile + r (lstm_cell_bf16_kernel)

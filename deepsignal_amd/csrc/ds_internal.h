@@ -142,6 +142,21 @@ size_t inception_fused_bf16_lds_bytes(int tm, int W, int spt);
 hipError_t launch_inception_fused_split(int tm, const FusedChain& c, hipStream_t s);
 size_t inception_fused_split_lds_bytes(int tm, int W, int spt);
 hipError_t configure_split_kernels();
+// BiLSTM cells of one diagonal with split operands (ds_split.hip): h buffers are fragment-major term images
+// [m-tile][k-step of 16 units][term][64 lanes][8 bf16] (48 KiB per m-tile), C.Bp points at pack_b_split panels, kg_stride = k-steps per
+// n-tile panel; c, bias, table, the gates and h_row as in the fp32 cells. tile = 11 | 12 | 22: workgroup tile of 64 x 64 .. 128 x 128.
+hipError_t launch_lstm_cells_split(int tile, const LstmLaunch& L, hipStream_t s);
+// dense(J, J) of the three-step joint model with split operands: pack_joint_split_kernel writes the joint rows (three fp32 row
+// segments per site) as a fragment-major term image A, dense_split_kernel multiplies it with W1's pack_b_split panels into C [n][N]
+struct SplitDense {
+    const float* seg[3];   // joint row segments, row-major fp32 [n][len]; unused ones have len 0 (lengths: multiples of 8)
+    int len[3];
+    char* A;               // [mtiles][ksteps][3][1 KiB] workspace
+    const char* Bp;        // [ntiles_alloc][kg_stride][3][1 KiB]
+    float* C;              // [n][N] fp32
+    int n, N, mtiles, ntiles, ntiles_alloc, ksteps, kg_stride;
+};
+hipError_t launch_dense_split(const SplitDense& d, hipStream_t s);
 
 // conv_layer2 (1x1, 64 -> 128) + conv_layer3 (1x3, 128 -> 256), both with folded BN + ReLU        layers.py:192-203
 struct Stem23Args {

@@ -534,6 +534,406 @@ __global__ __launch_bounds__(512, 2) void inception_fused_split_kernel(const Fus
     }   // modules of the chain
 }
 
+// =====================================================================================================================
+// BiLSTM cells and the joint model's dense(J, J), split operands (stage 2 of the split-operand engine).
+//
+// Both are plain GEMMs whose operands already lie in global memory as 1 KiB MFMA-fragment images, so they share one main loop:
+// the structure of lstm_cell_bf16_kernel (ds_kernels.hip) -- workgroup tile 64 MTW rows x 64 NTW columns, 4 waves as 2 x 2,
+// fragments global -> LDS by LDS-DMA into a ring of three stages, requests two stages ahead, ONE barrier per stage behind a
+// counted vmcnt -- with every fragment in three terms: per k-step (16 k) a workgroup takes 3 (2 MTW + 2 NTW) KiB and issues
+// 6 MTW NTW MFMAs per wave. The activation operand is fragment-major with the three terms of a k-step next to each other,
+//     [m-tile of 32 rows][k-step of 16][term][64 lanes][8 bf16]      (lane (r, half) holds k = 16 s + 8 half .. + 7 of row 32 m + r),
+// which is what a cell's epilogue writes for h (split once, where it is produced) and what pack_joint_split_kernel writes for the
+// joint row; the weights are pack_b_split's panels [n-tile][k-step][term][64][8].
+// What bounds them is operand delivery (a CU's vector-memory path, ~32 B/clk): the fp32 cell kernel already sits on
+// that limit (197 MB per full diagonal in 22.7 us), so the split cells use the 128 x 128 tile -- 0.25 KiB per MFMA, where the
+// fp32 64 x 64 tile needs 0.25 KiB per fp32 MFMA of 1/12 the work.
+constexpr int SPLIT_KSTEP_BYTES = 3 * 1024;               // the three term fragments of one k-step
+constexpr int SPLIT_MT_BYTES = 16 * SPLIT_KSTEP_BYTES;    // one m-tile of a split h buffer (256 units = 16 k-steps)
+
+#ifndef DS_SPLIT_PIPED
+#define DS_SPLIT_PIPED 0        // 1: fragments double-buffered in registers (SplitRing::run; measured SLOWER: 342 against 310 us for dense(6032, 6032) at
+#endif                          // 512 sites -- the loop is bound by operand delivery, not by LDS latency), 0: one stage at a time
+#ifndef DS_SPLIT_KGS11
+#define DS_SPLIT_KGS11 1
+#endif
+#ifndef DS_SPLIT_KGS22
+#define DS_SPLIT_KGS22 1
+#endif
+template <int MTW, int NTW>
+struct SplitRing {
+    static constexpr int FRA = 2 * MTW, FRB = 2 * NTW;
+    static constexpr int NF1 = 3 * (FRA + FRB);              // 1 KiB fragments per k-step
+    // k-steps per ring stage (the fragments of a stage are dealt to four waves, so NF must be a multiple of 4): one barrier per KGS
+    // k-steps. DS_SPLIT_KGS11 / DS_SPLIT_KGS22: measured choices for the 64 x 64 and the 128 x 128 tile
+    static constexpr int KGS = (MTW == 1 && NTW == 1) ? DS_SPLIT_KGS11 : (MTW == 2 && NTW == 2) ? DS_SPLIT_KGS22 : (NF1 % 4 == 0 ? 1 : 2);
+    static constexpr int NF = KGS * NF1;
+    static constexpr int LPS = NF / 4;                       // LDS-DMA requests per wave and stage
+    static constexpr int STAGE = NF * 256;                   // floats
+    static constexpr size_t LDS_BYTES = (size_t)3 * STAGE * 4;
+    const char* src[LPS];
+    int kgi_[LPS];
+    bool is_a[LPS];
+    long dseg;
+    int s0;
+    unsigned ring_lds, lane16;
+    int wave;
+
+    // A operand: k-steps [0, s0) from a0, the rest from a1 (both [m-tile][k-step][term] images, m-tile stride a_mt bytes);
+    // this workgroup's m-tiles mt0 .. mt0 + FRA - 1 (clamped to mtiles - 1), n-tiles nt0 .. nt0 + FRB - 1 of panel B
+    __device__ __forceinline__ void init(float* ring, int wave_, int lane, const char* a0, const char* a1, int s0_, long a_mt, int mt0, int mtiles,
+                                         const char* B, int kg_stride, int nt0)
+    {
+        wave = wave_;
+        s0 = s0_;
+        lane16 = (unsigned)lane * 16;
+        ring_lds = (unsigned)(size_t)(__attribute__((address_space(3))) float*)ring;
+        dseg = (a1 - a0) - (long)s0_ * SPLIT_KSTEP_BYTES;
+#pragma unroll
+        for (int j = 0; j < LPS; ++j) {
+            const int q = wave_ + 4 * j, kgi = q / NF1, f = q - kgi * NF1;
+            kgi_[j] = kgi;
+            is_a[j] = f < 3 * FRA;
+            if (f < 3 * FRA) {
+                const int m = min(mt0 + f / 3, mtiles - 1);
+                src[j] = a0 + (size_t)m * a_mt + (size_t)kgi * SPLIT_KSTEP_BYTES + (f % 3) * 1024;
+            } else {
+                const int g = f - 3 * FRA;
+                src[j] = B + ((size_t)(nt0 + g / 3) * kg_stride + kgi) * SPLIT_KSTEP_BYTES + (g % 3) * 1024;
+            }
+        }
+    }
+    __device__ __forceinline__ void request(int st, int slot) const
+    {
+        const unsigned dst = __builtin_amdgcn_readfirstlane(ring_lds + (slot * STAGE + wave * 256) * 4);
+#pragma unroll
+        for (int j = 0; j < LPS; ++j) {
+            const int ks = st * KGS + kgi_[j];
+            const long off = (long)st * (KGS * SPLIT_KSTEP_BYTES) + ((is_a[j] && ks >= s0) ? dseg : 0);
+            glds16s(src[j] + off, lane16, dst + j * 4096);      // fragment q = wave + 4 j of the stage
+        }
+    }
+    // stage st has landed once every wave's requests for it are done: counted wait (stage st + 1 stays in flight), barrier -- which
+    // also frees ring slot (st + 2) % 3, read during stage st - 1 --, request stage st + 2, then this stage's MFMAs
+    template <int SLOT>
+    __device__ __forceinline__ void stage(int st, int nstages, const float* fa0, const float* fb0, floatx16 (&acc)[MTW][NTW]) const
+    {
+        if (st + 1 < nstages) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (st + 2 < nstages) request(st + 2, (SLOT + 2) % 3);
+#pragma unroll
+        for (int kgi = 0; kgi < KGS; ++kgi) {
+            float4 a[MTW][3], b[NTW][3];
+#pragma unroll
+            for (int i = 0; i < MTW; ++i)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) a[i][p] = *reinterpret_cast<const float4*>(fa0 + SLOT * STAGE + (kgi * NF1 + i * 3 + p) * 256);
+#pragma unroll
+            for (int j = 0; j < NTW; ++j)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) b[j][p] = *reinterpret_cast<const float4*>(fb0 + SLOT * STAGE + (kgi * NF1 + j * 3 + p) * 256);
+#pragma unroll
+            for (int i = 0; i < MTW; ++i)
+#pragma unroll
+                for (int j = 0; j < NTW; ++j) {
+                    acc[i][j] = mfma3_lo(b[j], a[i][0], a[i][1], a[i][2], acc[i][j]);      // transposed: (A B)^T
+                    acc[i][j] = mfma3_hi(b[j], a[i][0], a[i][1], acc[i][j]);
+                }
+        }
+    }
+    __device__ __forceinline__ void run_simple(int nstages, const float* fa0, const float* fb0, floatx16 (&acc)[MTW][NTW]) const
+    {
+        for (int st = 0; st < nstages;) {
+            stage<0>(st, nstages, fa0, fb0, acc); if (++st >= nstages) break;
+            stage<1>(st, nstages, fa0, fb0, acc); if (++st >= nstages) break;
+            stage<2>(st, nstages, fa0, fb0, acc); ++st;
+        }
+    }
+
+    // The same ring with the fragments of a stage DOUBLE-BUFFERED IN REGISTERS: while the MFMAs of stage st run out of one register
+    // set, the LDS reads of stage st + 1 fill the other and the LDS-DMA requests of stage st + 3 refill the slot stage st has just
+    // left. With one wave per SIMD (the 128 x 128 tile: one workgroup per CU) the simple loop serialises a stage's 3 (MTW + NTW)
+    // ds_read_b128 with its 6 MTW NTW MFMAs -- 1,500 cycles per k-step for 768 of MFMA in dense(6032, 6032).
+    typedef float4 Frag[KGS][MTW + NTW][3];
+    template <int SLOT>
+    __device__ __forceinline__ void read_stage(const float* fa0, const float* fb0, Frag& f) const
+    {
+#pragma unroll
+        for (int kgi = 0; kgi < KGS; ++kgi) {
+#pragma unroll
+            for (int i = 0; i < MTW; ++i)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) f[kgi][i][p] = *reinterpret_cast<const float4*>(fa0 + SLOT * STAGE + (kgi * NF1 + i * 3 + p) * 256);
+#pragma unroll
+            for (int j = 0; j < NTW; ++j)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) f[kgi][MTW + j][p] = *reinterpret_cast<const float4*>(fb0 + SLOT * STAGE + (kgi * NF1 + j * 3 + p) * 256);
+        }
+    }
+    __device__ __forceinline__ void mfma_stage(const Frag& f, floatx16 (&acc)[MTW][NTW]) const
+    {
+#pragma unroll
+        for (int kgi = 0; kgi < KGS; ++kgi)
+#pragma unroll
+            for (int i = 0; i < MTW; ++i)
+#pragma unroll
+                for (int j = 0; j < NTW; ++j) {
+                    acc[i][j] = mfma3_lo(f[kgi][MTW + j], f[kgi][i][0], f[kgi][i][1], f[kgi][i][2], acc[i][j]);
+                    acc[i][j] = mfma3_hi(f[kgi][MTW + j], f[kgi][i][0], f[kgi][i][1], acc[i][j]);
+                }
+    }
+    // iteration st: registers `cur` hold stage st. Wait until stage st + 1 has landed (counted: stage st + 2 stays in flight), barrier
+    // (everybody's share of st + 1 has landed AND everybody has finished READING stage st's slot), request stage st + 3 into that
+    // slot, start the reads of stage st + 1 into `nxt`, run stage st's MFMAs.
+    template <int SLOT>      // SLOT = ring slot of stage st + 1
+    __device__ __forceinline__ void piped(int st, int nstages, const float* fa0, const float* fb0, const Frag& cur, Frag& nxt, floatx16 (&acc)[MTW][NTW]) const
+    {
+        if (st + 1 < nstages) {
+            if (st + 2 < nstages) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(LPS) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (st + 3 < nstages) request(st + 3, (SLOT + 2) % 3);
+            read_stage<SLOT>(fa0, fb0, nxt);
+        }
+        mfma_stage(cur, acc);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    __device__ __forceinline__ void run(int nstages, const float* fa0, const float* fb0, floatx16 (&acc)[MTW][NTW]) const
+    {
+#if DS_SPLIT_PIPED
+        if (nstages <= 0) return;
+        // (the caller has requested stages 0 and 1)
+        if (nstages > 2) request(2, 2);
+        if (nstages > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPS) : "memory");
+        else if (nstages > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        Frag fa, fb;
+        read_stage<0>(fa0, fb0, fa);
+        for (int st = 0; st < nstages;) {
+            piped<1>(st, nstages, fa0, fb0, fa, fb, acc); if (++st >= nstages) break;
+            piped<2>(st, nstages, fa0, fb0, fb, fa, acc); if (++st >= nstages) break;
+            piped<0>(st, nstages, fa0, fb0, fa, fb, acc); if (++st >= nstages) break;
+            piped<1>(st, nstages, fa0, fb0, fb, fa, acc); if (++st >= nstages) break;
+            piped<2>(st, nstages, fa0, fb0, fa, fb, acc); if (++st >= nstages) break;
+            piped<0>(st, nstages, fa0, fb0, fb, fa, acc); ++st;
+        }
+#else
+        run_simple(nstages, fa0, fb0, acc);
+#endif
+    }
+};
+
+// ---- the BiLSTM cells of one wavefront diagonal (layers.py:45-72), split operands: h and the weights in three bf16 terms, six
+// products per MAC, fp32 accumulate; the layer-0 table row / rank-1 terms, the gates and the cell state are fp32 as in the fp32
+// kernel (lstm_acc_init / lstm_gates are shared with it); h is split once, in the epilogue that produces it.
+template <int MTW, int NTW>
+__global__ __launch_bounds__(256, (SplitRing<MTW, NTW>::LDS_BYTES > 80 * 1024) ? 1 : 2) void lstm_cell_split_kernel(const LstmLaunch L_)
+{
+    const LstmLaunch* const Lp = &L_;
+    typedef SplitRing<MTW, NTW> R;
+    extern __shared__ __attribute__((aligned(16))) float ring[];    // [3 * STAGE]
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int mi = wave & 1, nj = wave >> 1;
+    const int bid = lstm_logical_tile(blockIdx.x, gridDim.x, Lp->cls_tiles[0], Lp->cls_tiles[1]);
+    const int mtiles = Lp->mtiles;
+    const int mblocks = (mtiles + R::FRA - 1) / R::FRA;
+    constexpr int NGROUPS = 32 / R::FRB;
+    const int per_cell = mblocks * NGROUPS;
+    const int ci = bid / per_cell, rem = bid - ci * per_cell;
+    const int ng = rem % NGROUPS, mb = rem / NGROUPS;          // the n-groups of one m-block are neighbours (lstm_cell_bf16_kernel)
+    const LstmCell& C = Lp->cell[ci];
+    const int half = lane >> 5, r31 = lane & 31;
+    const int n = Lp->n, T = Lp->T;
+    const unsigned lane4 = (unsigned)lane * 4;
+    const bool has_x = C.ax != nullptr, has_h = C.ah != nullptr;
+    const int KS = (has_x ? 16 : 0) + (has_h ? 16 : 0);       // k-steps: x rows first, then h rows (TF kernel order)
+    const int nstages = KS / R::KGS;
+    R rg;
+    rg.init(ring, wave, lane, reinterpret_cast<const char*>(has_x ? C.ax : C.ah), reinterpret_cast<const char*>(has_h ? C.ah : C.ax),
+            has_x ? 16 : 0, SPLIT_MT_BYTES, mb * R::FRA, mtiles, reinterpret_cast<const char*>(C.Bp), C.kg_stride, ng * R::FRB);
+    if (nstages > 0) rg.request(0, 0);
+    if (nstages > 1) rg.request(1, 1);
+
+    int mt[MTW];
+    bool valid[MTW];
+#pragma unroll
+    for (int i = 0; i < MTW; ++i) {
+        const int raw = mb * R::FRA + mi * MTW + i;
+        valid[i] = raw < mtiles;
+        mt[i] = valid[i] ? raw : mtiles - 1;
+    }
+    floatx16 acc[MTW][NTW];
+    float4 cp[MTW][NTW];
+#pragma unroll
+    for (int i = 0; i < MTW; ++i) {
+        const int row = mt[i] * 32 + r31;
+        const int rowc = row < n ? row : n - 1;
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) lstm_acc_init(C, (ng * R::FRB + nj * NTW + j) * 8 + 4 * half, rowc, T, acc[i][j]);
+    }
+    const bool c_zero = C.c_zero != 0;
+#pragma unroll
+    for (int i = 0; i < MTW; ++i)
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) {
+            cp[i][j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (!c_zero) cp[i][j] = gload4(C.c + (size_t)mt[i] * LSTM_MT_FLOATS + (unsigned)(ng * R::FRB + nj * NTW + j) * 256 + lane4);
+        }
+    // every compiler-visible load is retired here: the loop's vmcnt waits count the LDS-DMA requests only (lstm_cell_bf16_kernel)
+#pragma unroll
+    for (int i = 0; i < MTW; ++i)
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) {
+            asm volatile("" : "+v"(cp[i][j].x), "+v"(cp[i][j].y), "+v"(cp[i][j].z), "+v"(cp[i][j].w));
+            asm volatile("" : "+v"(acc[i][j]));
+        }
+    rg.run(nstages, ring + (mi * MTW * 3) * 256 + lane4, ring + (3 * R::FRA + nj * NTW * 3) * 256 + lane4, acc);
+
+    // ---- gates (fp32), new state; c fragment-major fp32, h fragment-major in three terms (8 bytes per lane and term), optional
+    // row-major fp32 h for the joint model
+#pragma unroll
+    for (int i = 0; i < MTW; ++i) {
+        if (!valid[i]) continue;
+        const int row = mt[i] * 32 + r31;
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) {
+            const int ntile = ng * R::FRB + nj * NTW + j;
+            float4 cn, hn;
+            lstm_gates(acc[i][j], cp[i][j], cn, hn);
+            const v4f co = {cn.x, cn.y, cn.z, cn.w};
+            *(__attribute__((address_space(1))) v4f*)(C.c + (size_t)mt[i] * LSTM_MT_FLOATS + (unsigned)ntile * 256 + lane4) = co;
+            uint2 t0, t1, t2;
+            split3x4(hn.x, hn.y, hn.z, hn.w, t0, t1, t2);
+            char* const hb = reinterpret_cast<char*>(C.h_out) + (size_t)mt[i] * SPLIT_MT_BYTES + (unsigned)(ntile >> 1) * SPLIT_KSTEP_BYTES +
+                             (unsigned)(((ntile & 1) * 32 + r31) * 16 + half * 8);
+            typedef unsigned int u2v __attribute__((ext_vector_type(2)));
+            *(__attribute__((address_space(1))) u2v*)hb = u2v{t0.x, t0.y};
+            *(__attribute__((address_space(1))) u2v*)(hb + 1024) = u2v{t1.x, t1.y};
+            *(__attribute__((address_space(1))) u2v*)(hb + 2048) = u2v{t2.x, t2.y};
+            if (C.h_row && row < n) {
+                const v4f hr = {hn.x, hn.y, hn.z, hn.w};
+                *(__attribute__((address_space(1))) v4f*)(C.h_row + (size_t)row * 256 + ntile * 8 + 4 * half) = hr;
+            }
+        }
+    }
+}
+
+hipError_t launch_lstm_cells_split(int tile, const LstmLaunch& L, hipStream_t s)
+{
+    const int ncell = L.ncell, mtiles = L.mtiles;
+    if (ncell <= 0 || mtiles <= 0) return hipSuccess;
+    switch (tile) {
+    case 11: hipLaunchKernelGGL((lstm_cell_split_kernel<1, 1>), dim3(ncell * ((mtiles + 1) / 2) * 16), dim3(256), (SplitRing<1, 1>::LDS_BYTES), s, L); break;
+    case 12: hipLaunchKernelGGL((lstm_cell_split_kernel<1, 2>), dim3(ncell * ((mtiles + 1) / 2) * 8), dim3(256), (SplitRing<1, 2>::LDS_BYTES), s, L); break;
+    case 22: hipLaunchKernelGGL((lstm_cell_split_kernel<2, 2>), dim3(ncell * ((mtiles + 3) / 4) * 8), dim3(256), (SplitRing<2, 2>::LDS_BYTES), s, L); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+// ---- dense(J, J) of the joint model (layers.py:257-259: no bias, no activation), split operands. A = the joint rows
+// [h_fw(T-1) | h_bw(0) | signal features] as a fragment-major term image (pack_joint_split_kernel), B = W1's panels.
+__global__ __launch_bounds__(256) void pack_joint_split_kernel(const SplitDense d)
+{
+    // one thread per (row, k-step half): 8 consecutive k of one row -> the 16 bytes of its lane slot in each of the three term fragments
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const int ksteps = d.ksteps;
+    const long total = (long)d.mtiles * 32 * ksteps * 2;
+    if (idx >= total) return;
+    const int half = (int)(idx & 1);
+    const long t = idx >> 1;
+    const int ks = (int)(t % ksteps);
+    const int row = (int)(t / ksteps);
+    const int k0 = ks * 16 + half * 8;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = 0.0f;
+    if (row < d.n) {
+        // the joint row's three segments (lengths are multiples of 8)
+        const float* p = nullptr;
+        int k = k0;
+        if (k < d.len[0]) p = d.seg[0] + (size_t)row * d.len[0] + k;
+        else if ((k -= d.len[0]) < d.len[1]) p = d.seg[1] + (size_t)row * d.len[1] + k;
+        else { k -= d.len[1]; p = d.seg[2] + (size_t)row * d.len[2] + k; }
+        const float4 x = gload4(p), y = gload4(p + 4);
+        v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w; v[4] = y.x; v[5] = y.y; v[6] = y.z; v[7] = y.w;
+    }
+    uint2 a0, a1, a2, b0, b1, b2;
+    split3x4(v[0], v[1], v[2], v[3], a0, a1, a2);
+    split3x4(v[4], v[5], v[6], v[7], b0, b1, b2);
+    char* dst = d.A + ((size_t)(row >> 5) * ksteps + ks) * SPLIT_KSTEP_BYTES + (size_t)(half * 32 + (row & 31)) * 16;
+    *reinterpret_cast<uint4*>(dst) = make_uint4(a0.x, a0.y, b0.x, b0.y);
+    *reinterpret_cast<uint4*>(dst + 1024) = make_uint4(a1.x, a1.y, b1.x, b1.y);
+    *reinterpret_cast<uint4*>(dst + 2048) = make_uint4(a2.x, a2.y, b2.x, b2.y);
+}
+
+// (one workgroup per CU: 192 workgroups of 128 x 128 at 512 sites -- the register budget of one wave per SIMD)
+template <int MTW, int NTW>
+__global__ __launch_bounds__(256, 1) void dense_split_kernel(const SplitDense d)
+{
+    typedef SplitRing<MTW, NTW> R;
+    extern __shared__ __attribute__((aligned(16))) float ring[];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int mi = wave & 1, nj = wave >> 1;
+    const int mblocks = (d.mtiles + R::FRA - 1) / R::FRA;
+    const int nblocks = (d.ntiles + R::FRB - 1) / R::FRB;
+    const int total = mblocks * nblocks;
+    // XCD-aware order (workgroup b runs on XCD b % 8): every XCD takes a contiguous run of logical tiles; the m-blocks of one weight
+    // panel are neighbours, so a panel streams into one L2 once
+    int b = blockIdx.x;
+    if ((total & 7) == 0) b = (b & 7) * (total >> 3) + (b >> 3);
+    const int nb = b / mblocks, mb = b - nb * mblocks;
+    const int half = lane >> 5, r31 = lane & 31;
+    const unsigned lane4 = (unsigned)lane * 4;
+    const int nstages = d.ksteps / R::KGS;          // (ksteps is even wherever KGS = 2 is instantiated: checked by the launcher)
+    R rg;
+    rg.init(ring, wave, lane, d.A, d.A, d.ksteps, (long)d.ksteps * SPLIT_KSTEP_BYTES, mb * R::FRA, d.mtiles, d.Bp, d.kg_stride, min(nb * R::FRB, d.ntiles_alloc - R::FRB));
+    if (nstages > 0) rg.request(0, 0);
+    if (nstages > 1) rg.request(1, 1);
+    floatx16 acc[MTW][NTW];
+#pragma unroll
+    for (int i = 0; i < MTW; ++i)
+#pragma unroll
+        for (int j = 0; j < NTW; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+    rg.run(nstages, ring + (mi * MTW * 3) * 256 + lane4, ring + (3 * R::FRA + nj * NTW * 3) * 256 + lane4, acc);
+    const int nt_base = min(nb * R::FRB, d.ntiles_alloc - R::FRB);
+#pragma unroll
+    for (int i = 0; i < MTW; ++i) {
+        const int mtile = mb * R::FRA + mi * MTW + i;
+        const int row = mtile * 32 + r31;
+        if (mtile >= d.mtiles || row >= d.n) continue;
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) {
+            const int ntile = nt_base + nj * NTW + j;
+            if (ntile < nb * R::FRB) continue;             // (a clamped last block recomputes columns its neighbour owns: not stored twice)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int col = ntile * 32 + 8 * g + 4 * half;
+                if (col < d.N) {
+                    const v4f o = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+                    *(__attribute__((address_space(1))) v4f*)(d.C + (size_t)row * d.N + col) = o;
+                }
+            }
+        }
+    }
+}
+
+hipError_t launch_dense_split(const SplitDense& d, hipStream_t s)
+{
+    if (d.n <= 0) return hipSuccess;
+    if (d.ksteps <= 0 || (d.N & 3) || d.ntiles_alloc < 4) return hipErrorInvalidValue;
+    const long total = (long)d.mtiles * 32 * d.ksteps * 2;
+    hipLaunchKernelGGL(pack_joint_split_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, d);
+    typedef SplitRing<2, 2> R;
+    const int mblocks = (d.mtiles + R::FRA - 1) / R::FRA, nblocks = (d.ntiles + R::FRB - 1) / R::FRB;
+    hipLaunchKernelGGL((dense_split_kernel<2, 2>), dim3(mblocks * nblocks), dim3(256), R::LDS_BYTES, s, d);
+    return hipGetLastError();
+}
+
 static bool split_chain_ok(const FusedChain& c)
 {
     if (c.nmod <= 0 || c.nmod > FUSED_CHAIN_MAX) return false;
@@ -548,8 +948,10 @@ static bool split_chain_ok(const FusedChain& c)
 
 hipError_t configure_split_kernels()
 {
-    const void* fns[3] = {(const void*)inception_fused_split_kernel<1>, (const void*)inception_fused_split_kernel<2>,
-                          (const void*)inception_fused_split_kernel<3>};
+    const void* fns[7] = {(const void*)inception_fused_split_kernel<1>, (const void*)inception_fused_split_kernel<2>,
+                          (const void*)inception_fused_split_kernel<3>, (const void*)lstm_cell_split_kernel<1, 1>,
+                          (const void*)lstm_cell_split_kernel<1, 2>, (const void*)lstm_cell_split_kernel<2, 2>,
+                          (const void*)dense_split_kernel<2, 2>};
     for (const void* f : fns) {
         const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;

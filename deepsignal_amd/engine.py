@@ -135,7 +135,8 @@ class Engine:
                  max_batch: int = 512, is_cnn: bool = True, is_rnn: bool = True, is_base: bool = True,
                  debug: bool = False, slots: int = 0, precision: str = "fp32", serial: bool = False,
                  no_fused: bool = False, debug_stamps: bool = False, fold_fc: bool = True, lstm_tiling: str = "auto",
-                 fuse_max_spt: int = 0, fuse_min_tiles: int = 0, chain_modules: bool = True, shared_event_stream: bool = False):
+                 fuse_max_spt: int = 0, fuse_min_tiles: int = 0, chain_modules: bool = True, shared_event_stream: bool = False,
+                 split_dense_min_n: int = 0):
         self._lib = load_library()
         self._h = ctypes.c_void_p()
         if precision not in PRECISIONS:
@@ -155,6 +156,7 @@ class Engine:
         cfg.reserved[3] = LSTM_TILINGS[lstm_tiling]
         cfg.reserved[4] = fuse_max_spt
         cfg.reserved[5] = fuse_min_tiles
+        cfg.reserved[6] = split_dense_min_n
         rc = self._lib.ds_create(ctypes.byref(cfg), ctypes.byref(self._h))
         if rc != 0:
             msg = self._lib.ds_last_error(None).decode()

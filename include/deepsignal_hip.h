@@ -68,7 +68,8 @@ typedef struct ds_config {
                              reserved[4]: fused inception module, most sites per tile (0 = default 8);
                              reserved[5]: fused inception module, fewest workgroups a grid is shrunk to when the
                                           batch allows more (0 = default 128);
-                             reserved[6]: must be 0.
+                             reserved[6]: DS_PRECISION_BF16X3 only: sites per forward from which dense(J, J) of the three-step joint
+                                          model runs with split operands (0 = default 2048; 1 = always).
                              Every knob is per handle: the library reads no environment variable and keeps no
                              process-global tuning state, so two handles in one process never influence each other. */
 } ds_config;

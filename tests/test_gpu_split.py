@@ -19,7 +19,7 @@ from deepsignal_amd import synth
 
 pytestmark = pytest.mark.gpu
 KEYS = ("kmer", "means", "stds", "sanums", "signals")
-SPLIT_SCOPE = ("modules",)            # what DS_PRECISION_BF16X3 runs split (ds_version() / DESIGN.md section 11)
+SPLIT_SCOPE = ("modules", "lstm", "fc1")      # what DS_PRECISION_BF16X3 runs split (ds_version() / DESIGN.md section 11)
 STATEMENT_RTOL = 6e-6                 # engine vs the CPU statement of the same arithmetic, relative to the tensor's scale
 
 
@@ -36,16 +36,18 @@ def test_split_engine_against_the_cpu_statement_of_the_same_arithmetic(request, 
     w = request.getfixturevalue(which + "_weights")
     n = 96
     feats = synth.synthetic_features(n, seed=4100)
-    eng = _engine(w, max_batch=128, debug=True, precision="bf16x3")
+    eng = _engine(w, max_batch=128, debug=True, precision="bf16x3", split_dense_min_n=1)
     act, pred = eng.run(*(feats[k] for k in KEYS))
     s_act, s_pred, taps = torch_statement.forward_split(w, feats, terms=3, scope=SPLIT_SCOPE, return_taps=True)
     worst = {}
     for name, ref in taps.items():
-        if not (name.startswith("module") or name == "signal_feat"):
+        if not (name.startswith("module") or name.startswith("lstm") or name in ("signal_feat", "fc1")):
             continue
         got = eng.intermediate(name, ref.shape)
         scale = max(1.0, float(np.abs(ref).max()))
-        worst[name] = float(np.abs(got - ref).max()) / scale
+        # (a saturating recurrent net amplifies the last-bit differences of the gate non-linearities -- v_exp_f32 / v_rcp_f32 here, libm
+        # there: the LSTM taps of the stress set get the slack the fp32 engine needs against the fp32 oracle on the same tensors)
+        worst[name] = float(np.abs(got - ref).max()) / scale / (4.0 if which == "stress" and name.startswith("lstm") else 1.0)
     print("\n%s: engine vs forward_split, relative to the tensor's scale: %s" % (which, {k: "%.1e" % v for k, v in worst.items()}))
     bad = {k: v for k, v in worst.items() if not v <= STATEMENT_RTOL}
     assert not bad, bad
@@ -55,14 +57,19 @@ def test_split_engine_against_the_cpu_statement_of_the_same_arithmetic(request, 
 
 def test_the_split_kernels_are_the_ones_that_run(small_weights):
     feats = synth.synthetic_features(96, seed=4101)
-    eng = _engine(small_weights, max_batch=96, precision="bf16x3")
+    # (split_dense_min_n=1: below 2,048 sites per forward the planner keeps the native fp32 GEMM for dense(J, J) -- at 512 sites
+    # the split form is bound by operand delivery and no faster; here it is forced so that all three run)
+    eng = _engine(small_weights, max_batch=96, precision="bf16x3", fold_fc=False, split_dense_min_n=1)
     eng.set_graph(False)
     eng.set_profiling(1)
     eng.run(*(feats[k] for k in KEYS))
     ran = {k["name"]: k["launches"] for k in eng.kernel_stats() if k["launches"]}
     eng.close()
-    assert any(name.startswith("inception_fused_split_kernel") for name in ran), ran
-    assert not any(name.startswith("inception_fused_kernel") or name.startswith("inception_fused_bf16") for name in ran), ran
+    for prefix in ("inception_fused_split_kernel", "lstm_cell_split_kernel", "dense_split_kernel"):
+        assert any(name.startswith(prefix) for name in ran), (prefix, ran)
+    # ... and their native-fp32 / bf16 counterparts did not (the 6032 x 6032 GEMM template, the fp32 / bf16 cells, the fp32 / bf16 chains)
+    assert not any(name.startswith(("inception_fused_kernel", "inception_fused_bf16", "lstm_cell_lds_kernel", "lstm_cell_kernel",
+                                    "lstm_cell_bf16_kernel", "gemm_kernel<1,3,4,1")) for name in ran), ran
 
 
 def test_split_chain_gives_the_bits_of_one_launch_per_module(small_weights):
@@ -77,6 +84,20 @@ def test_split_chain_gives_the_bits_of_one_launch_per_module(small_weights):
     single.close()
     assert np.array_equal(a1, a2) and np.array_equal(p1, p2)
     assert np.array_equal(a1s, a1[:77]) and np.array_equal(p1s, p1[:77])
+
+
+def test_split_lstm_tile_shapes_give_the_same_bits(small_weights):
+    """lstm_cell_split_kernel runs 64 x 64, 64 x 128 or 128 x 128 workgroup tiles: every shape accumulates a unit's K in the same order,
+    so a site's bits do not depend on the tile -- also with an odd number of 32-site m-tiles."""
+    feats = synth.synthetic_features(1100, seed=906)
+    args = [feats[k] for k in KEYS]
+    outs = []
+    for tiling in ("narrow", "lds1", "wide"):
+        eng = _engine(small_weights, max_batch=1100, slots=1, precision="bf16x3", lstm_tiling=tiling)
+        outs.append(eng.run(*args))
+        eng.close()
+    for a, p in outs[1:]:
+        assert np.array_equal(a, outs[0][0]) and np.array_equal(p, outs[0][1])
 
 
 def test_split_mode_refuses_what_it_does_not_implement(small_weights):
