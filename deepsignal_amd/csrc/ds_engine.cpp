@@ -851,7 +851,7 @@ int build_plan(ds_handle* h, int n, Plan* plan)
         x = y; cin = INC_OUT;
         if (m == 2 || m == 7) {   // maxpool_layer2/3                            layers.py:211-213,224-226
             const int wout = m == 2 ? h->wb : h->wc, pad = m == 2 ? h->pl_pool2 : h->pl_pool3;
-            if (!h->no_fused && wout <= 96 && !h->debug_keep_pool && !h->split) {      // (the split-operand kernel reads plain rows)
+            if (!h->no_fused && wout <= 96 && !h->debug_keep_pool) {
                 pend_pool_win = W; pend_pool_pad = pad;      // folded into module m+2's staging: no launch, no buffer
             } else {
                 Op op{};

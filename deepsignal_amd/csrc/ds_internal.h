@@ -138,7 +138,7 @@ hipError_t launch_inception_fused_bf16(int tm, const FusedChain& c, hipStream_t 
 hipError_t launch_inception_fused(int tm, const FusedChain& c, hipStream_t s);
 size_t inception_fused_bf16_lds_bytes(int tm, int W, int spt);
 // split-operand form (ds_split.hip, DS_PRECISION_BF16X3): X / Y are the fp32 engine's fp32 rows, Bp1 / Bp3b / Bp4b / Bp5b / Bp5c point at
-// three-term panels (ds_engine.cpp pack_b_split); no module of the chain may pool its input (pool_win = 0)
+// three-term panels (ds_engine.cpp pack_b_split); as in the fp32 form only the chain's first module may pool its input
 hipError_t launch_inception_fused_split(int tm, const FusedChain& c, hipStream_t s);
 size_t inception_fused_split_lds_bytes(int tm, int W, int spt);
 hipError_t configure_split_kernels();

@@ -222,7 +222,23 @@ __global__ __launch_bounds__(512, 2) void inception_fused_split_kernel(const Fus
     const int sr = tid >> 2, sq = tid & 3;              // waves 0 .. 2 TM - 1 stage: TR32 x 4 slots
     const int rr = sr < TRv ? sr : TRv - 1;
     const int wr = rr % W;
-    const float* pc = a.X + (grow0 + rr) * cin + sq * 4;
+    // plain input: one row per staged row. Pooled input (the module right after maxpool_layer2 / 3, layers.py:211-213,224-226): the
+    // staged row (site s, w) is the max of the input rows 2 w - pad + {0, 1, 2} of site s that exist (padded taps ignored), taken
+    // while loading -- the stride-2 pool costs no launch and no buffer, as in the fp32 kernel
+    const bool pooled_in = a.pool_win > 0;        // wave-uniform per module
+    const float* pc;
+    int oq = 0, orr = 0;                          // float offsets of the second / third tap from the first (0 = the same row again)
+    if (!pooled_in) {
+        pc = a.X + (grow0 + rr) * cin + sq * 4;
+    } else {
+        const int s_ = rr / W;
+        const int i0 = 2 * wr - a.pool_pad;
+        const int ia = i0 < 0 ? i0 + 1 : i0;                               // first existing tap
+        const int ib = i0 + 1 < a.pool_win ? (i0 + 1 < 0 ? ia : i0 + 1) : ia;
+        const int ic = i0 + 2 < a.pool_win ? i0 + 2 : ib;
+        pc = a.X + ((size_t)(site0 + s_) * a.pool_win + ia) * cin + sq * 4;
+        oq = (ib - ia) * cin; orr = (ic - ia) * cin;
+    }
     const int om = wr > 0 ? -S_LDR : 0;           // previous / next row of the same site in the raw LDS copy, or the own row at a site edge
     const int op = wr < W - 1 ? S_LDR : 0;
     // this wave's P1 weights: n-tile `wave`, 16 k-steps x 3 terms of 1 KiB (K padded to 256 in the pack)
@@ -283,7 +299,11 @@ __global__ __launch_bounds__(512, 2) void inception_fused_split_kernel(const Fus
         char* const sdst = Pst + sr * S_LDP + sq * 8;
         char* const rdst = Raw + sr * S_LDR + sq * 16;
         auto load_a = [&](int V) __attribute__((always_inline)) {
-            if (STG && !(DS_SPLIT_BISECT & 2)) { vo[V] = gload4(pc); pc += KC; }
+            if (STG && !(DS_SPLIT_BISECT & 2)) {
+                vo[V] = gload4(pc);
+                if (pooled_in) vo[V] = f4max(f4max(vo[V], gload4(pc + oq)), gload4(pc + orr));      // wave-uniform branch
+                pc += KC;
+            }
         };
         auto raw_a = [&](int X, int V) __attribute__((always_inline)) {
             if (STG && !(DS_SPLIT_BISECT & 1)) *reinterpret_cast<float4*>(rdst + X * TR32 * S_LDR) = vo[V];
@@ -938,7 +958,7 @@ static bool split_chain_ok(const FusedChain& c)
 {
     if (c.nmod <= 0 || c.nmod > FUSED_CHAIN_MAX) return false;
     for (int i = 0; i < c.nmod; ++i) {
-        if (c.m[i].pool_win != 0) return false;                              // the stride-2 pools run as their own launches in this mode
+        if (i > 0 && c.m[i].pool_win != 0) return false;                     // only a chain's first module may pool its input
         if (c.m[i].cin != 240 && c.m[i].cin != 256) return false;            // P1 is unrolled over 15 or 16 chunks (every module of the model)
         if (i > 0 && (c.m[i].W != c.m[0].W || c.m[i].spt != c.m[0].spt || c.m[i].n_sites != c.m[0].n_sites || c.m[i].X != c.m[i - 1].Y))
             return false;
