@@ -325,7 +325,9 @@ def test_cli_on_a_hand_assembled_tf_checkpoint(small_weights, tmp_path):
 def test_tf_written_checkpoint_on_the_gpu():
     """The HIP engine fed the checkpoint TensorFlow wrote (through deepsignal_amd.tf_checkpoint; from the seed when only
     the npz is present) against TensorFlow's own activation_logits / prediction on the same feed: normalised
-    probabilities within the north star's 1e-4, labels equal wherever the margin exceeds 1e-3 -- both joint-model forms."""
+    probabilities within the north star's 1e-4, labels equal wherever the margin exceeds 1e-3 -- both joint-model forms, and
+    both fp32-class precisions: DS_PRECISION_BF16X3 consumes the same inputs and the same fp32 weights (its terms are formed
+    inside the engine), so the day the fixture exists it pins that mode to TensorFlow with the same bars."""
     import tf_golden_fixture as fx
     from deepsignal_amd import tf_checkpoint
     from deepsignal_amd.engine import Engine
@@ -335,10 +337,11 @@ def test_tf_written_checkpoint_on_the_gpu():
     w = tf_checkpoint.checkpoint_to_weights(prefix) if tf_checkpoint.is_checkpoint(prefix) else fx.weights_of(g)
     tf_act, tf_pred = g["act"], g["pred"]
     decided = np.abs(tf_act[:, 1] - tf_act[:, 0]) > 1e-3
-    for fold in (True, False):
-        eng = Engine(max_batch=16, fold_fc=fold)
-        eng.load_weights(w)
-        act, pred = eng.run(*(feats[k] for k in KEYS))
-        eng.close()
-        assert np.abs(act - tf_act).max() <= 2e-5 and np.abs(_norm(act) - _norm(tf_act)).max() <= 1e-4
-        assert (pred[decided] == tf_pred[decided]).all()
+    for precision in ("fp32", "bf16x3"):
+        for fold in (True, False):
+            eng = Engine(max_batch=16, fold_fc=fold, precision=precision)
+            eng.load_weights(w)
+            act, pred = eng.run(*(feats[k] for k in KEYS))
+            eng.close()
+            assert np.abs(act - tf_act).max() <= 2e-5 and np.abs(_norm(act) - _norm(tf_act)).max() <= 1e-4, (precision, fold)
+            assert (pred[decided] == tf_pred[decided]).all(), (precision, fold)
