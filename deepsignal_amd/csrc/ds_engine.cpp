@@ -72,7 +72,7 @@ struct Op {
 
 // per-kernel accumulators (one entry per __global__ function / template instantiation)
 enum KernelClass { K_GEMM_CONV = 0, K_GEMM_FC, K_GEMM_LSTM, K_GEMM_CONV_WIDE, K_GEMM_CONV_POOL, K_GEMM_FC_DENSE, K_GEMM_LSTM_DENSE, K_FUSED1, K_FUSED2, K_FUSED3, K_STEM1, K_MAXPOOL, K_AVGPOOL, K_HEAD,
-                   K_GEMM_BCONV, K_GEMM_BCONV_POOL, K_GEMM_BFC, K_GEMM_BFC_DENSE, K_PACKEV, K_GEMM_BLSTM, K_GEMM_BLSTM_DENSE, K_FUSEDB1, K_FUSEDB2, K_FUSEDB3, K_GEMM_LSTM_T, K_GEMM_LSTM_T_DENSE, K_GEMM_BLSTM_T, K_GEMM_BLSTM_T_DENSE, K_LSTM_CELL1, K_LSTM_CELL2, K_LSTM_CELL4, K_LSTM_LDS1, K_LSTM_LDS2, K_STEM23, K_HEADF, K_LSTM_B11, K_LSTM_B12, K_LSTM_B22, K_STEM23B, K_FUSEDS1, K_FUSEDS2, K_FUSEDS3, K_LSTM_S11, K_LSTM_S12, K_LSTM_S22, K_DENSE_SPLIT, K_COUNT };
+                   K_GEMM_BCONV, K_GEMM_BCONV_POOL, K_GEMM_BFC, K_GEMM_BFC_DENSE, K_PACKEV, K_GEMM_BLSTM, K_GEMM_BLSTM_DENSE, K_FUSEDB1, K_FUSEDB2, K_FUSEDB3, K_GEMM_LSTM_T, K_GEMM_LSTM_T_DENSE, K_GEMM_BLSTM_T, K_GEMM_BLSTM_T_DENSE, K_LSTM_CELL1, K_LSTM_CELL2, K_LSTM_CELL4, K_LSTM_LDS1, K_LSTM_LDS2, K_STEM23, K_HEADF, K_LSTM_B11, K_LSTM_B12, K_LSTM_B22, K_STEM23B, K_FUSEDS1, K_FUSEDS2, K_FUSEDS3, K_LSTM_S11, K_LSTM_S12, K_LSTM_S22, K_DENSE_SPLIT, K_STEM23S, K_COUNT };
 const char* const kKernelNames[K_COUNT] = {"gemm_kernel<1,2,4,1,0,0,1,1>", "gemm_kernel<1,3,4,1,0,0,2,1>", "gemm_kernel<1,4,4,1,1,0,1,1>",
                                            "gemm_kernel<2,2,2,2,0,0,1,1>", "gemm_kernel<1,2,4,1,0,1,1,1>", "gemm_kernel<1,3,4,1,0,2,2,1>",
                                            "gemm_kernel<1,4,4,1,1,2,1,1>", "inception_fused_kernel<1>",
@@ -90,7 +90,7 @@ const char* const kKernelNames[K_COUNT] = {"gemm_kernel<1,2,4,1,0,0,1,1>", "gemm
                                            "lstm_cell_bf16_kernel<1,1>", "lstm_cell_bf16_kernel<1,2>", "lstm_cell_bf16_kernel<2,2>", "stem23_bf16_kernel",
                                            "inception_fused_split_kernel<1>", "inception_fused_split_kernel<2>", "inception_fused_split_kernel<3>",
                                            "lstm_cell_split_kernel<1,1>", "lstm_cell_split_kernel<1,2>", "lstm_cell_split_kernel<2,2>",
-                                           "dense_split_kernel<2,2> (+ pack_joint_split_kernel)"};
+                                           "dense_split_kernel<2,2> (+ pack_joint_split_kernel)", "stem23_split_kernel"};
 struct KernelStat {
     int64_t launches = 0;
     double total_ms = 0;
@@ -421,8 +421,8 @@ int finalize_weights(ds_handle* h)
     if ((rc = fold_conv(h, "modelsignalmconv_layer3", "conv", "bn", 3, 128, 256, &c3))) return rc;
     if ((rc = upload(h, &h->stem1_w, c1.w))) return rc;
     if ((rc = upload(h, &h->stem1_b, c1.b))) return rc;
-    if ((rc = upload_concat(h, {&c2}, &h->conv2))) return rc;
-    if ((rc = upload_concat(h, {&c3}, &h->conv3))) return rc;
+    if ((rc = upload_concat(h, {&c2}, &h->conv2, h->split))) return rc;
+    if ((rc = upload_concat(h, {&c3}, &h->conv3, h->split))) return rc;
     // ---- inception modules (layers.py:87-139) ----
     for (int m = 0; m < NMOD; ++m) {
         const int cin = m == 0 ? 256 : INC_OUT;
@@ -726,6 +726,10 @@ int build_plan(ds_handle* h, int n, Plan* plan)
             // kernel may ask for at two workgroups per CU (configure_fused_kernels)
             while (spt > 1 && (bf ? stem23_bf16_lds_bytes(h->wa, spt) : stem23_lds_bytes(h->wa, spt)) > STEM23_MAX_LDS) --spt;
             o2.sa.spt = spt;
+            if (h->split && stem23_split_lds_bytes(h->wa, spt) <= 160 * 1024) {      // DS_PRECISION_BF16X3: split operands (ds_split.hip)
+                o2.a = 2;
+                o2.sa.Bp2 = h->conv2.Bps; o2.sa.Bp3 = h->conv3.Bps;
+            }
             o2.flops = 2.0 * M * (64.0 * 128 + 384.0 * 256);
             add_ew_op(cnn, o2);
             if (first_plan) h->stages[st].flops_per_site += 2.0 * h->wa * (64.0 * 128 + 384.0 * 256);
@@ -887,7 +891,8 @@ int build_plan(ds_handle* h, int n, Plan* plan)
         // bf16-operand cells (DS_PRECISION_BF16_ALL): lstm_cell_bf16_kernel, workgroup tile 64 x 64 .. 128 x 128 by batch.
         const int mtiles = (n + 31) / 32;
         const int nt = lbf ? (h->lstm_variant == DS_LSTM_TILING_NARROW ? 211 : h->lstm_variant == DS_LSTM_TILING_LDS1 ? 212
-                              : h->lstm_variant == DS_LSTM_TILING_WIDE ? 222 : n >= 2048 ? 222 : n > 768 ? 212 : 211)
+                              : h->lstm_variant == DS_LSTM_TILING_WIDE ? 222
+                              : n >= 2048 ? 222 : n > 768 ? 212 : 211)
                        : h->lstm_variant == DS_LSTM_TILING_NARROW ? 1 : h->lstm_variant == DS_LSTM_TILING_WIDE ? 4
                        : h->lstm_variant == DS_LSTM_TILING_LDS1 ? 101 : h->lstm_variant == DS_LSTM_TILING_LDS2 ? 102
                        : (n <= 1024 ? 101 : 102);
@@ -1069,7 +1074,8 @@ int issue_op(ds_handle* h, Plan& plan, const Op& op, hipStream_t s)
         HIPCHK(h, launch_dense_split(op.sd, s));
         break;
     case OP_STEM23:
-        if (op.a) HIPCHK(h, launch_stem23_bf16(op.sa, s));
+        if (op.a == 2) HIPCHK(h, launch_stem23_split(op.sa, s));
+        else if (op.a) HIPCHK(h, launch_stem23_bf16(op.sa, s));
         else HIPCHK(h, launch_stem23(op.sa, s));
         break;
     case OP_HEADF:
@@ -1163,7 +1169,7 @@ int kernel_class(const Op& op)
         if (op.d == 3) return op.tm == 1 ? K_FUSEDS1 : op.tm == 2 ? K_FUSEDS2 : K_FUSEDS3;          // split operands (three terms)
         return op.tm == 1 ? K_FUSED1 : op.tm == 2 ? K_FUSED2 : K_FUSED3;
     case OP_STEM1: return K_STEM1;
-    case OP_STEM23: return op.a ? K_STEM23B : K_STEM23;
+    case OP_STEM23: return op.a == 2 ? K_STEM23S : op.a ? K_STEM23B : K_STEM23;
     case OP_HEADF: return K_HEADF;
     case OP_MAXPOOL: return K_MAXPOOL;
     case OP_AVGPOOL: return K_AVGPOOL;
@@ -1332,7 +1338,8 @@ extern "C" {
 const char* ds_version(void)
 {
     return "deepsignal_amd 0.4 (gfx950; fp32 MFMA, bf16 conv + FC and bf16_all operand modes; bf16x3 = fp32 operands as three bf16 "
-           "terms, six products per MAC, in: the eleven inception modules, the BiLSTM cells' recurrent and lower-layer products, dense(J, J) of the three-step joint model)";
+           "terms, six products per MAC, in: conv_layer2 / 3, the eleven inception modules, the BiLSTM cells' recurrent and lower-layer products, dense(J, J) of the three-step "
+           "joint model from 2,048 sites per forward)";
 }
 
 const char* ds_last_error(const ds_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }

@@ -168,6 +168,9 @@ struct Stem23Args {
     int n_sites, W, spt;   // spt = whole sites per workgroup tile, spt * W <= 96
 };
 hipError_t launch_stem23(const Stem23Args& a, hipStream_t s);
+// conv_layer2 + conv_layer3 with split operands (ds_split.hip): X / Y / C2 as the fp32 kernel, Bp2 / Bp3 = pack_b_split panels
+hipError_t launch_stem23_split(const Stem23Args& a, hipStream_t s);
+size_t stem23_split_lds_bytes(int W, int spt);
 size_t stem23_lds_bytes(int W, int spt);
 // bf16 form (DS_PRECISION_BF16*): X / Y / C2 are bf16 rows (64 / 256 / 128 channels), Bp2 / Bp3 packed by pack_b_bf16
 hipError_t launch_stem23_bf16(const Stem23Args& a, hipStream_t s);

@@ -963,6 +963,8 @@ hipError_t launch_lstm_cells(int nt, const LstmLaunch& L, hipStream_t s)
     case 211: hipLaunchKernelGGL((lstm_cell_bf16_kernel<1, 1>), dim3(ncell * ((mtiles + 1) / 2) * 16), dim3(256), 3 * 2 * 4 * 1024, s, L); break;
     case 212: hipLaunchKernelGGL((lstm_cell_bf16_kernel<1, 2>), dim3(ncell * ((mtiles + 1) / 2) * 8), dim3(256), 3 * 2 * 6 * 1024, s, L); break;
     case 222: hipLaunchKernelGGL((lstm_cell_bf16_kernel<2, 2>), dim3(ncell * ((mtiles + 3) / 4) * 8), dim3(256), 3 * 2 * 8 * 1024, s, L); break;
+    // (a 128 x 256 tile -- a wave owning 64 sites x 128 columns, 0.09 KiB of operand fragments per MFMA against 0.125 -- was measured in
+    // round 5: 756 against 673 us per 4096-site step; 768 workgroups of 72 KB rings fill the GPU in 1.5 rounds)
     case 1: hipLaunchKernelGGL(lstm_cell_kernel<1>, dim3(ncell * mblocks * 32), dim3(256), 0, s, L); break;
     case 2: hipLaunchKernelGGL(lstm_cell_kernel<2>, dim3(ncell * mblocks * 16), dim3(256), 0, s, L); break;
     case 4: hipLaunchKernelGGL(lstm_cell_kernel<4>, dim3(ncell * mblocks * 8), dim3(256), 0, s, L); break;

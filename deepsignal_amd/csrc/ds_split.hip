@@ -219,7 +219,11 @@ __global__ __launch_bounds__(512, 2) void inception_fused_split_kernel(const Fus
     }
 
     // ---- P1 staging cursor: thread -> (row, 16-byte slot of the chunk's 64 B); rows past the tile end re-read row TRv-1
-    const int sr = tid >> 2, sq = tid & 3;              // waves 0 .. 2 TM - 1 stage: TR32 x 4 slots
+    // waves 0 .. 2 TM - 1 stage TR32 x 4 sixteen-byte slots, four lanes a row (a row's 64 B of a chunk are one contiguous request).
+    // (Sixteen consecutive lanes on sixteen rows at one slot makes the 8-byte term writes and the raw copy's accesses tile the LDS
+    // banks exactly -- SQ_LDS_BANK_CONFLICT is 36 % of the kernel's LDS-active cycles with this mapping -- but scatters every
+    // row load over sixteen lines per sixteen lanes: measured 373 against 345 us per step. The conflicts are the cheaper evil.)
+    const int sr = tid >> 2, sq = tid & 3;
     const int rr = sr < TRv ? sr : TRv - 1;
     const int wr = rr % W;
     // plain input: one row per staged row. Pooled input (the module right after maxpool_layer2 / 3, layers.py:211-213,224-226): the
@@ -552,6 +556,170 @@ __global__ __launch_bounds__(512, 2) void inception_fused_split_kernel(const Fus
     // re-uses every LDS region
     if (mi + 1 < c.nmod) __syncthreads();
     }   // modules of the chain
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// conv_layer2 (1x1, 64 -> 128) + conv_layer3 (1x3, 128 -> 256), BN folded, ReLU (layers.py:192-203), split operands: the
+// structure of stem23_kernel (ds_kernels.hip) -- a tile of whole sites (<= 96 rows), 8 waves, conv2's rows never leave LDS (zero halo
+// row on either side of every site = conv3's SAME padding), conv3 with wave w = output channels [32 w, 32 w + 32) of all three
+// m-tiles and its weights streamed global -> VGPR -- with the input rows split into terms while they are staged and conv2's rows
+// split in its epilogue. LDS: input terms 96 x 400 B + conv2 terms (spt (W + 2) + 3) x 784 B = 117 KB, one workgroup per CU.
+// Per tile conv3 streams 576 KB of weight fragments (24 k-steps x 3 terms x 8 n-tiles) for 27.6 k cycles of MFMA per SIMD: bound by
+// operand delivery.
+constexpr int S23_SX = 400;      // input term row: 3 x 64 channels x 2 B + 16
+constexpr int S23_ST = 784;      // conv2 term row: 3 x 128 channels x 2 B + 16 (49 x 16 B)
+size_t stem23_split_lds_bytes(int W, int spt) { return (size_t)96 * S23_SX + (size_t)(spt * (W + 2) + 3) * S23_ST + 96 * 4; }
+
+__global__ __launch_bounds__(512, 2) void stem23_split_kernel(const Stem23Args a)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    char* const Xs = reinterpret_cast<char*>(smem);                  // [96][S23_SX]
+    char* const T = Xs + 96 * S23_SX;                               // [spt * (W + 2) + 3][S23_ST]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int W = a.W, spt = a.spt;
+    const int trows = spt * (W + 2) + 3;                            // last three rows: halo | dump row (padding rows of the tile) | halo
+    int* const rowmap = reinterpret_cast<int*>(T + trows * S23_ST);
+    const int site0 = blockIdx.x * spt;
+    const int nhere = min(spt, a.n_sites - site0);
+    const int TRv = nhere * W;
+    const size_t grow0 = (size_t)site0 * W;
+    const int h4 = 4 * (lane >> 5), rlane = lane & 31, hb = (lane >> 5) * 16;
+    auto lds_barrier = []() __attribute__((always_inline)) { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+
+    // ---- stage: zero T (halo rows must be zero; the rest is overwritten), row map, input rows as terms
+    for (int i = tid; i < trows * (S23_ST / 16); i += 512) reinterpret_cast<float4*>(T)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (tid < 96) rowmap[tid] = tid < TRv ? (tid / W) * (W + 2) + 1 + tid % W : spt * (W + 2) + 1;
+    {
+        float4 v[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {                          // 96 rows x 16 float4
+            const int idx = tid + 512 * i, row = idx >> 4, q = idx & 15;
+            const int rr = row < TRv ? row : TRv - 1;
+            v[i] = gload4(a.X + (grow0 + rr) * 64 + q * 4);
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int idx = tid + 512 * i, row = idx >> 4, q = idx & 15;
+            uint2 t0, t1, t2;
+            split3x4(v[i].x, v[i].y, v[i].z, v[i].w, t0, t1, t2);
+            char* d = Xs + row * S23_SX + q * 8;
+            *reinterpret_cast<uint2*>(d) = t0; *reinterpret_cast<uint2*>(d + 128) = t1; *reinterpret_cast<uint2*>(d + 256) = t2;
+        }
+    }
+    // conv3 weights of the first two k-steps and both bias vectors are requested before the barrier
+    const float* const b3 = a.Bp3 + ((size_t)wave * 24 * 3 * 64 + lane) * 4;       // n-tile `wave`: 24 k-steps x 3 terms of 1 KiB
+    float4 bq[2][3];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) bq[i][p] = gload4(b3 + (i * 3 + p) * 256);
+    float4 bias3[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) bias3[g] = gload4(a.bias3 + wave * 32 + 8 * g + h4);
+    // conv2: unit u = (m, n); waves 0..3 take (0, w) and (2, w), waves 4..7 take (1, w - 4): three units per SIMD
+    const int n2 = wave & 3;
+    float4 w2[12];
+#pragma unroll
+    for (int g = 0; g < 12; ++g) w2[g] = gload4(a.Bp2 + ((size_t)(n2 * 12 + g) * 64 + lane) * 4);      // 4 k-steps x 3 terms
+    float4 bias2[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) bias2[g] = gload4(a.bias2 + n2 * 32 + 8 * g + h4);
+    lds_barrier();
+    {
+        const int nunits = wave < 4 ? 2 : 1;
+        for (int ui = 0; ui < nunits; ++ui) {
+            const int m = wave < 4 ? 2 * ui : 1;
+            floatx16 u;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) { u[4 * g] = bias2[g].x; u[4 * g + 1] = bias2[g].y; u[4 * g + 2] = bias2[g].z; u[4 * g + 3] = bias2[g].w; }
+            const char* xr = Xs + (m * 32 + rlane) * S23_SX + hb;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 x0 = *reinterpret_cast<const float4*>(xr + g * 32);
+                const float4 x1 = *reinterpret_cast<const float4*>(xr + 128 + g * 32);
+                const float4 x2 = *reinterpret_cast<const float4*>(xr + 256 + g * 32);
+                const float4 w[3] = {w2[3 * g], w2[3 * g + 1], w2[3 * g + 2]};
+                u = mfma3_lo(w, x0, x1, x2, u);
+                u = mfma3_hi(w, x0, x1, u);
+            }
+            const int row = m * 32 + rlane;
+            char* const td = T + rowmap[row] * S23_ST + (n2 * 32 + h4) * 2;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 o = make_float4(relu_f(u[4 * g]), relu_f(u[4 * g + 1]), relu_f(u[4 * g + 2]), relu_f(u[4 * g + 3]));
+                uint2 t0, t1, t2;
+                split3x4(o.x, o.y, o.z, o.w, t0, t1, t2);
+                *reinterpret_cast<uint2*>(td + 16 * g) = t0;
+                *reinterpret_cast<uint2*>(td + 16 * g + 256) = t1;
+                *reinterpret_cast<uint2*>(td + 16 * g + 512) = t2;
+                if (a.C2 && row < TRv) {                       // diagnostic tap (debug mode): conv_layer2's output rows
+                    const v4f ov = {o.x, o.y, o.z, o.w};
+                    *(__attribute__((address_space(1))) v4f*)(a.C2 + (grow0 + row) * 128 + n2 * 32 + 8 * g + h4) = ov;
+                }
+            }
+        }
+    }
+    lds_barrier();
+
+    // ---- conv3: 24 k-steps (3 taps x 8) without a barrier: the whole activation tile is resident; weights through a register ring
+    // two k-steps deep, activation fragments one k-step ahead
+    floatx16 acc[3];
+#pragma unroll
+    for (int m = 0; m < 3; ++m)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) { acc[m][4 * g] = bias3[g].x; acc[m][4 * g + 1] = bias3[g].y; acc[m][4 * g + 2] = bias3[g].z; acc[m][4 * g + 3] = bias3[g].w; }
+    const char* tb[3];
+#pragma unroll
+    for (int m = 0; m < 3; ++m) tb[m] = T + (rowmap[m * 32 + rlane] - 1) * S23_ST + hb;     // tap t reads row + t - 1
+    float4 af[2][3][3];
+#pragma unroll
+    for (int m = 0; m < 3; ++m)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) af[0][m][p] = *reinterpret_cast<const float4*>(tb[m] + p * 256);
+#pragma unroll
+    for (int ks = 0; ks < 24; ++ks) {
+        const int cur = ks & 1;
+        if (ks + 1 < 24) {
+            const int t1 = (ks + 1) >> 3, g1 = (ks + 1) & 7;
+#pragma unroll
+            for (int m = 0; m < 3; ++m)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) af[cur ^ 1][m][p] = *reinterpret_cast<const float4*>(tb[m] + t1 * S23_ST + g1 * 32 + p * 256);
+        }
+#pragma unroll
+        for (int m = 0; m < 3; ++m) {
+            acc[m] = mfma3_lo(bq[cur], af[cur][m][0], af[cur][m][1], af[cur][m][2], acc[m]);
+            acc[m] = mfma3_hi(bq[cur], af[cur][m][0], af[cur][m][1], acc[m]);
+        }
+        if (ks + 2 < 24) {
+#pragma unroll
+            for (int p = 0; p < 3; ++p) bq[cur][p] = gload4(b3 + ((ks + 2) * 3 + p) * 256);
+        }
+        __builtin_amdgcn_sched_barrier(0);       // pins the ring: requests stay two k-steps ahead of their MFMAs
+    }
+
+    // ---- ReLU, rows out (each lane: 4 x 16 B of one row)
+#pragma unroll
+    for (int m = 0; m < 3; ++m) {
+        const int row = m * 32 + rlane;
+        if (row < TRv) {
+            float* const yd = a.Y + (grow0 + row) * 256 + wave * 32 + h4;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const v4f o = {relu_f(acc[m][4 * g]), relu_f(acc[m][4 * g + 1]), relu_f(acc[m][4 * g + 2]), relu_f(acc[m][4 * g + 3])};
+                *(__attribute__((address_space(1))) v4f*)(yd + 8 * g) = o;
+            }
+        }
+    }
+}
+
+hipError_t launch_stem23_split(const Stem23Args& a, hipStream_t s)
+{
+    if (a.n_sites <= 0) return hipSuccess;
+    if (a.spt * a.W > 96 || stem23_split_lds_bytes(a.W, a.spt) > 160 * 1024) return hipErrorInvalidValue;
+    const int grid = (a.n_sites + a.spt - 1) / a.spt;
+    hipLaunchKernelGGL(stem23_split_kernel, dim3(grid), dim3(512), stem23_split_lds_bytes(a.W, a.spt), s, a);
+    return hipGetLastError();
 }
 
 // =====================================================================================================================
@@ -968,7 +1136,7 @@ static bool split_chain_ok(const FusedChain& c)
 
 hipError_t configure_split_kernels()
 {
-    const void* fns[7] = {(const void*)inception_fused_split_kernel<1>, (const void*)inception_fused_split_kernel<2>,
+    const void* fns[8] = {(const void*)stem23_split_kernel, (const void*)inception_fused_split_kernel<1>, (const void*)inception_fused_split_kernel<2>,
                           (const void*)inception_fused_split_kernel<3>, (const void*)lstm_cell_split_kernel<1, 1>,
                           (const void*)lstm_cell_split_kernel<1, 2>, (const void*)lstm_cell_split_kernel<2, 2>,
                           (const void*)dense_split_kernel<2, 2>};

@@ -19,7 +19,7 @@ from deepsignal_amd import synth
 
 pytestmark = pytest.mark.gpu
 KEYS = ("kmer", "means", "stds", "sanums", "signals")
-SPLIT_SCOPE = ("modules", "lstm", "fc1")      # what DS_PRECISION_BF16X3 runs split (ds_version() / DESIGN.md section 11)
+SPLIT_SCOPE = ("modules", "stem23", "lstm", "fc1")      # what DS_PRECISION_BF16X3 runs split (ds_version() / DESIGN.md section 11)
 STATEMENT_RTOL = 6e-6                 # engine vs the CPU statement of the same arithmetic, relative to the tensor's scale
 
 
@@ -41,7 +41,7 @@ def test_split_engine_against_the_cpu_statement_of_the_same_arithmetic(request, 
     s_act, s_pred, taps = torch_statement.forward_split(w, feats, terms=3, scope=SPLIT_SCOPE, return_taps=True)
     worst = {}
     for name, ref in taps.items():
-        if not (name.startswith("module") or name.startswith("lstm") or name in ("signal_feat", "fc1")):
+        if not (name.startswith("module") or name.startswith("lstm") or name in ("stem_conv2", "stem_conv3", "signal_feat", "fc1")):
             continue
         got = eng.intermediate(name, ref.shape)
         scale = max(1.0, float(np.abs(ref).max()))
@@ -65,10 +65,10 @@ def test_the_split_kernels_are_the_ones_that_run(small_weights):
     eng.run(*(feats[k] for k in KEYS))
     ran = {k["name"]: k["launches"] for k in eng.kernel_stats() if k["launches"]}
     eng.close()
-    for prefix in ("inception_fused_split_kernel", "lstm_cell_split_kernel", "dense_split_kernel"):
+    for prefix in ("stem23_split_kernel", "inception_fused_split_kernel", "lstm_cell_split_kernel", "dense_split_kernel"):
         assert any(name.startswith(prefix) for name in ran), (prefix, ran)
     # ... and their native-fp32 / bf16 counterparts did not (the 6032 x 6032 GEMM template, the fp32 / bf16 cells, the fp32 / bf16 chains)
-    assert not any(name.startswith(("inception_fused_kernel", "inception_fused_bf16", "lstm_cell_lds_kernel", "lstm_cell_kernel",
+    assert not any(name.startswith(("stem23_kernel", "inception_fused_kernel", "inception_fused_bf16", "lstm_cell_lds_kernel", "lstm_cell_kernel",
                                     "lstm_cell_bf16_kernel", "gemm_kernel<1,3,4,1")) for name in ran), ran
 
 
