@@ -752,11 +752,12 @@ template <int MTW, int NTW>
 struct SplitRing {
     static constexpr int FRA = 2 * MTW, FRB = 2 * NTW;
     static constexpr int NF1 = 3 * (FRA + FRB);              // 1 KiB fragments per k-step
-    // k-steps per ring stage (the fragments of a stage are dealt to four waves, so NF must be a multiple of 4): one barrier per KGS
-    // k-steps. DS_SPLIT_KGS11 / DS_SPLIT_KGS22: measured choices for the 64 x 64 and the 128 x 128 tile
-    static constexpr int KGS = (MTW == 1 && NTW == 1) ? DS_SPLIT_KGS11 : (MTW == 2 && NTW == 2) ? DS_SPLIT_KGS22 : (NF1 % 4 == 0 ? 1 : 2);
+    // k-steps per ring stage: one barrier per KGS k-steps. DS_SPLIT_KGS11 / DS_SPLIT_KGS22: measured choices for the 64 x 64 and the
+    // 128 x 128 tile. The fragments of a stage are dealt to the four waves round robin; where NF is not a multiple of 4 (the 64 x 128
+    // tile: 18) waves 0 .. NF % 4 - 1 request one more than the others and wait with a count of their own.
+    static constexpr int KGS = (MTW == 1 && NTW == 1) ? DS_SPLIT_KGS11 : (MTW == 2 && NTW == 2) ? DS_SPLIT_KGS22 : 1;
     static constexpr int NF = KGS * NF1;
-    static constexpr int LPS = NF / 4;                       // LDS-DMA requests per wave and stage
+    static constexpr int LPS = (NF + 3) / 4;                 // LDS-DMA requests per wave and stage (waves >= NF % 4: one fewer if NF % 4)
     static constexpr int STAGE = NF * 256;                   // floats
     static constexpr size_t LDS_BYTES = (size_t)3 * STAGE * 4;
     const char* src[LPS];
@@ -779,7 +780,7 @@ struct SplitRing {
         dseg = (a1 - a0) - (long)s0_ * SPLIT_KSTEP_BYTES;
 #pragma unroll
         for (int j = 0; j < LPS; ++j) {
-            const int q = wave_ + 4 * j, kgi = q / NF1, f = q - kgi * NF1;
+            const int q = min(wave_ + 4 * j, NF - 1), kgi = q / NF1, f = q - kgi * NF1;       // (q >= NF: never requested)
             kgi_[j] = kgi;
             is_a[j] = f < 3 * FRA;
             if (f < 3 * FRA) {
@@ -796,6 +797,7 @@ struct SplitRing {
         const unsigned dst = __builtin_amdgcn_readfirstlane(ring_lds + (slot * STAGE + wave * 256) * 4);
 #pragma unroll
         for (int j = 0; j < LPS; ++j) {
+            if (NF % 4 != 0 && j == LPS - 1 && wave >= NF % 4) break;      // wave-uniform: this wave has no fragment 4 j + wave
             const int ks = st * KGS + kgi_[j];
             const long off = (long)st * (KGS * SPLIT_KSTEP_BYTES) + ((is_a[j] && ks >= s0) ? dseg : 0);
             glds16s(src[j] + off, lane16, dst + j * 4096);      // fragment q = wave + 4 j of the stage
@@ -806,8 +808,9 @@ struct SplitRing {
     template <int SLOT>
     __device__ __forceinline__ void stage(int st, int nstages, const float* fa0, const float* fb0, floatx16 (&acc)[MTW][NTW]) const
     {
-        if (st + 1 < nstages) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (st + 1 >= nstages) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (NF % 4 == 0 || wave < NF % 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS - 1) : "memory");
         __builtin_amdgcn_s_barrier();
         if (st + 2 < nstages) request(st + 2, (SLOT + 2) % 3);
 #pragma unroll
