@@ -167,10 +167,10 @@ def pmc_traffic(kernel_name, pattern="r[0-9][0-9]_pmc_traffic.json"):
     return {"traffic": None}
 
 
-def pmc_mfma_busy(kernel_name):
+def pmc_mfma_busy(kernel_name, pattern="r[0-9][0-9]_pmc_mfma_util.json"):
     """MFMA-pipe busy share of `kernel_name` (SQ_VALU_MFMA_BUSY_CYCLES / duration at the in-kernel clock) from the committed
     PMC pass -- a committed constant like pmc_traffic."""
-    path = _latest_profile("r[0-9][0-9]_pmc_mfma_util.json")
+    path = _latest_profile(pattern)
     try:
         rec = json.load(open(path))
         for name, v in rec["kernels"].items():
@@ -417,6 +417,8 @@ def bf16x3_leg(Engine, w, torch, make_step, timed_windows, local_rank, slots, ls
                                    "frac_of_fp32_mfma_peak": round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
                                    "bf16_mfma_frac": round(ach * SPLIT_PRODUCTS_PER_MAC / PEAK_BF16_MFMA_TFLOPS, 4),
                                    "measured": "stand-alone: every launch of the step on ONE stream, HIP events on that stream, eager replay of %d steps" % KP}
+                out["roofline"].update(pmc_traffic(k["name"], "r[0-9][0-9]_bf16x3_pmc_traffic.json"))
+                out["roofline"].update(pmc_mfma_busy(k["name"], "r[0-9][0-9]_bf16x3_pmc_mfma_util.json"))
         e.close()
     g = np.load(os.path.join(ROOT, "tests", "golden", "stress_golden.npz"))
     ws = W.stress_weights(int(g["stress_seed"]), head=g["stress_head"])

@@ -111,19 +111,20 @@ __device__ __forceinline__ void fuseds_conv_unit(const char* T1, int rm, int cby
     }
 }
 
-// the same conv on NM m-tiles at once: one set of weights, NM accumulators. ONE fragment buffer: the three reads of the next
-// (tap, k-step, m-tile) are issued right behind the six MFMAs of the current one -- which have taken their operands by then -- and
-// land while those run (192 cycles of MFMA per group against ~100 of LDS latency); without this order hipcc issues a group's reads
-// directly in front of its MFMAs and every group waits for the LDS (6.8 k cycles for 108 MFMAs with one wave per SIMD active).
+// the same conv on NM m-tiles at once: one set of weights, NM accumulators, TWO fragment buffers: the three reads of the next
+// (tap, k-step, m-tile) group are issued in front of the six MFMAs of the current one and land while those run (192 cycles of MFMA
+// per group against ~100 of LDS latency); left to itself hipcc issues a group's reads directly in front of its MFMAs and every group
+// waits for the LDS (6.8 k cycles for 108 MFMAs with one wave per SIMD active).
 template <int NTAPS, int NM>
 __device__ __forceinline__ void fuseds_conv_units(const char* T1, const int (&rm)[NM], int cbyte, int lane, const float4 (&ub)[30], floatx16 (&acc)[NM])
 {
     const char* base[NM];
 #pragma unroll
     for (int m = 0; m < NM; ++m) base[m] = T1 + (rm[m] - NTAPS / 2) * S_LD1 + cbyte + (lane >> 5) * 16;
-    float4 a0 = *reinterpret_cast<const float4*>(base[0]);
-    float4 a1 = *reinterpret_cast<const float4*>(base[0] + S_T1P);
-    float4 a2 = *reinterpret_cast<const float4*>(base[0] + 2 * S_T1P);
+    float4 fr[2][3];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) fr[0][p] = *reinterpret_cast<const float4*>(base[0] + p * S_T1P);
+    int cur = 0;
 #pragma unroll
     for (int t = 0; t < NTAPS; ++t)
 #pragma unroll
@@ -132,18 +133,18 @@ __device__ __forceinline__ void fuseds_conv_units(const char* T1, const int (&rm
             const float4 w[3] = {ub[q], ub[q + 1], ub[q + 2]};
 #pragma unroll
             for (int m = 0; m < NM; ++m) {
-                acc[m] = mfma3_lo(w, a0, a1, a2, acc[m]);
-                acc[m] = mfma3_hi(w, a0, a1, acc[m]);
                 // next group: (t, j, m + 1), or m-tile 0 of the next k-step / tap
                 const int mn = m + 1 < NM ? m + 1 : 0;
                 const int jn = m + 1 < NM ? j : (j + 1) & 1;
                 const int tn = (m + 1 < NM || j == 0) ? t : t + 1;
                 if (tn < NTAPS) {
                     const char* arow = base[mn] + tn * S_LD1 + jn * 32;
-                    a0 = *reinterpret_cast<const float4*>(arow);
-                    a1 = *reinterpret_cast<const float4*>(arow + S_T1P);
-                    a2 = *reinterpret_cast<const float4*>(arow + 2 * S_T1P);
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) fr[cur ^ 1][p] = *reinterpret_cast<const float4*>(arow + p * S_T1P);
                 }
+                acc[m] = mfma3_lo(w, fr[cur][0], fr[cur][1], fr[cur][2], acc[m]);
+                acc[m] = mfma3_hi(w, fr[cur][0], fr[cur][1], acc[m]);
+                cur ^= 1;
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -479,57 +480,32 @@ __global__ __launch_bounds__(512, 2) void inception_fused_split_kernel(const Fus
         }
     };
 
-    // ---- P2a
-    if (wave < 2) {
-        run_job(SplitRole<1>{}, SplitRole<TM>{}, 0, wave);
-        // the tail's twelve weight fragments travel in the unit registers (behind the job's MFMAs; its results are LDS writes)
-#pragma unroll
-        for (int g = 0; g < 12; ++g) pf[g] = gload4(a.Bp5c + ((size_t)(wave * 12 + g) * 64 + lane) * 4);
-    } else if (wave < 4) {
-        run_job(SplitRole<2>{}, SplitRole<TM>{}, 0, wave - 2);
-    } else {
-        // the b1|b2 tile leaves as whole 384-byte row segments, by the four waves whose second-stage job waits for P2b; every
-        // thread issues the same number of stores (slots past the tile's last one repeat it)
-        constexpr int NFL = (TR32 * 24 + 255) / 256;
-        const int last = TRv * 24 - 1, t4 = tid - 256;
-#pragma unroll
-        for (int i = 0; i < NFL; ++i) {
-            const int idx = min(t4 + i * 256, last);
-            const int row = idx / 24, q = idx - row * 24;
-            const float4 v = *reinterpret_cast<const float4*>(Ys + row * S_LDY + q * 16);
-            v4f o = {v.x, v.y, v.z, v.w};
-            *(__attribute__((address_space(1))) v4f*)(Yg + (unsigned)(row * 240 + q * 4)) = o;
-        }
-    }
-    DS_STAMP(5);
-    lds_barrier();   // T2 complete
-    DS_STAMP(6);
-
-    // ---- P2b
-    if (wave < 2) {
+    // ---- P2a | barrier (T2 complete) | P2b, one code path per wave role with the barrier INSIDE the paths (every path passes exactly
+    // one): the stem accumulators are then live in the path of waves 0, 1 only and each role's registers are its own (round 5: 250 ->
+    // fewer VGPRs, which pays for the second fragment buffer of fuseds_conv_units)
+    auto tail_and_store = [&]() __attribute__((always_inline)) {
         // branch 5 tail: 1x1 64 -> 48 (BN, no ReLU) accumulated on top of the stem conv held in acc,
         // then relu(stem + tail)                                                         layers.py:132-138
-        {
-            const char* const tb = T2 + rlane * S_LD2 + (lane >> 5) * 16;
-            float4 a0 = *reinterpret_cast<const float4*>(tb);
-            float4 a1 = *reinterpret_cast<const float4*>(tb + S_T2P);
-            float4 a2 = *reinterpret_cast<const float4*>(tb + 2 * S_T2P);
+        const char* const tb = T2 + rlane * S_LD2 + (lane >> 5) * 16;
+        float4 fr[2][3];
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const float4 w[3] = {pf[3 * g], pf[3 * g + 1], pf[3 * g + 2]};
+        for (int p = 0; p < 3; ++p) fr[0][p] = *reinterpret_cast<const float4*>(tb + p * S_T2P);
+        int cur = 0;
 #pragma unroll
-                for (int mt = 0; mt < TM; ++mt) {
-                    acc[mt] = mfma3_lo(w, a0, a1, a2, acc[mt]);
-                    acc[mt] = mfma3_hi(w, a0, a1, acc[mt]);
-                    const int mn = mt + 1 < TM ? mt + 1 : 0, gn = mt + 1 < TM ? g : g + 1;
-                    if (gn < 4) {      // the next group's fragments, behind this group's MFMAs (see fuseds_conv_units)
-                        const char* q = tb + mn * 32 * S_LD2 + gn * 32;
-                        a0 = *reinterpret_cast<const float4*>(q);
-                        a1 = *reinterpret_cast<const float4*>(q + S_T2P);
-                        a2 = *reinterpret_cast<const float4*>(q + 2 * S_T2P);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
+        for (int g = 0; g < 4; ++g) {
+            const float4 w[3] = {pf[3 * g], pf[3 * g + 1], pf[3 * g + 2]};
+#pragma unroll
+            for (int mt = 0; mt < TM; ++mt) {
+                const int mn = mt + 1 < TM ? mt + 1 : 0, gn = mt + 1 < TM ? g : g + 1;
+                if (gn < 4) {      // the next group's fragments, in front of this group's MFMAs
+                    const char* q = tb + mn * 32 * S_LD2 + gn * 32;
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) fr[cur ^ 1][p] = *reinterpret_cast<const float4*>(q + p * S_T2P);
                 }
+                acc[mt] = mfma3_lo(w, fr[cur][0], fr[cur][1], fr[cur][2], acc[mt]);
+                acc[mt] = mfma3_hi(w, fr[cur][0], fr[cur][1], acc[mt]);
+                cur ^= 1;
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
 #pragma unroll
@@ -545,10 +521,37 @@ __global__ __launch_bounds__(512, 2) void inception_fused_split_kernel(const Fus
                     }
             }
         }
-    } else if (wave >= 6) {
-        run_job(SplitRole<3>{}, SplitRole<TM - 1>{}, 1, wave - 6);
-    } else if (wave >= 4) {
-        run_job(SplitRole<3>{}, SplitRole<1>{}, 0, wave - 4);
+    };
+    if (wave < 2) {
+        run_job(SplitRole<1>{}, SplitRole<TM>{}, 0, wave);
+        // the tail's twelve weight fragments travel in the unit registers (behind the job's MFMAs; its results are LDS writes)
+#pragma unroll
+        for (int g = 0; g < 12; ++g) pf[g] = gload4(a.Bp5c + ((size_t)(wave * 12 + g) * 64 + lane) * 4);
+        DS_STAMP(5);
+        lds_barrier();   // T2 complete
+        DS_STAMP(6);
+        tail_and_store();
+    } else if (wave < 4) {
+        run_job(SplitRole<2>{}, SplitRole<TM>{}, 0, wave - 2);
+        lds_barrier();
+    } else {
+        // the b1|b2 tile leaves as whole 384-byte row segments, by the four waves whose second-stage job waits for P2b; every
+        // thread issues the same number of stores (slots past the tile's last one repeat it)
+        constexpr int NFL = (TR32 * 24 + 255) / 256;
+        const int last = TRv * 24 - 1, t4 = tid - 256;
+#pragma unroll
+        for (int i = 0; i < NFL; ++i) {
+            const int idx = min(t4 + i * 256, last);
+            const int row = idx / 24, q = idx - row * 24;
+            const float4 v = *reinterpret_cast<const float4*>(Ys + row * S_LDY + q * 16);
+            v4f o = {v.x, v.y, v.z, v.w};
+            *(__attribute__((address_space(1))) v4f*)(Yg + (unsigned)(row * 240 + q * 4)) = o;
+        }
+        DS_STAMP(5);
+        lds_barrier();
+        DS_STAMP(6);
+        if (wave >= 6) run_job(SplitRole<3>{}, SplitRole<TM - 1>{}, 1, wave - 6);
+        else run_job(SplitRole<3>{}, SplitRole<1>{}, 0, wave - 4);
     }
     DS_STAMP(7);
 #undef DS_STAMP
