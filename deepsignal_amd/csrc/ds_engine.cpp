@@ -90,7 +90,7 @@ const char* const kKernelNames[K_COUNT] = {"gemm_kernel<1,2,4,1,0,0,1,1>", "gemm
                                            "lstm_cell_bf16_kernel<1,1>", "lstm_cell_bf16_kernel<1,2>", "lstm_cell_bf16_kernel<2,2>", "stem23_bf16_kernel",
                                            "inception_fused_split_kernel<1>", "inception_fused_split_kernel<2>", "inception_fused_split_kernel<3>",
                                            "lstm_cell_split_kernel<1,1>", "lstm_cell_split_kernel<1,2>", "lstm_cell_split_kernel<2,2>",
-                                           "dense_split_kernel<2,2> (+ pack_joint_split_kernel)", "stem23_split_kernel"};
+                                           "dense_split_kernel (+ pack_joint_split_kernel)", "stem23_split_kernel"};
 struct KernelStat {
     int64_t launches = 0;
     double total_ms = 0;
@@ -151,11 +151,11 @@ struct Slot {
     int last_n = 0;
 };
 
-// dense(J, J) with split operands moves 1.5x the operand bytes of the fp32 GEMM for 0.375x its matrix time; at 512 sites per forward
-// (188 tiles of 128 x 128) it is bound by operand delivery and no faster than the native fp32 GEMM (300 against 290 us), so the
-// planner keeps the fp32 GEMM below this many sites (ds_config.reserved[6] overrides; measured)
+// dense(J, J) with split operands moves 1.5x the operand bytes of the fp32 GEMM for 0.375x its matrix time and is bound by operand
+// delivery; measured on one box (us per forward at 512 / 2,048 sites): split 245 / 725, native fp32 GEMM 292 / 1,148. The planner uses
+// it from DS_SPLIT_DENSE_MIN_N sites per forward (ds_config.reserved[6] overrides).
 #ifndef DS_SPLIT_DENSE_MIN_N
-#define DS_SPLIT_DENSE_MIN_N 2048
+#define DS_SPLIT_DENSE_MIN_N 1
 #endif
 struct ds_handle {
     ds_config cfg{};
@@ -1339,7 +1339,7 @@ const char* ds_version(void)
 {
     return "deepsignal_amd 0.4 (gfx950; fp32 MFMA, bf16 conv + FC and bf16_all operand modes; bf16x3 = fp32 operands as three bf16 "
            "terms, six products per MAC, in: conv_layer2 / 3, the eleven inception modules, the BiLSTM cells' recurrent and lower-layer products, dense(J, J) of the three-step "
-           "joint model from 2,048 sites per forward)";
+           "joint model)";
 }
 
 const char* ds_last_error(const ds_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }

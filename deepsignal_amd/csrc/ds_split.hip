@@ -751,9 +751,10 @@ constexpr int SPLIT_MT_BYTES = 16 * SPLIT_KSTEP_BYTES;    // one m-tile of a spl
 #ifndef DS_SPLIT_KGS22
 #define DS_SPLIT_KGS22 1
 #endif
-template <int MTW, int NTW>
+template <int MTW, int NTW, int WM = 2, int WN = 2>      // WM x WN waves (= 4), each MTW x NTW tiles of 32 x 32
 struct SplitRing {
-    static constexpr int FRA = 2 * MTW, FRB = 2 * NTW;
+    static_assert(WM * WN == 4, "four waves per workgroup");
+    static constexpr int FRA = WM * MTW, FRB = WN * NTW;
     static constexpr int NF1 = 3 * (FRA + FRB);              // 1 KiB fragments per k-step
     // k-steps per ring stage: one barrier per KGS k-steps. DS_SPLIT_KGS11 / DS_SPLIT_KGS22: measured choices for the 64 x 64 and the
     // 128 x 128 tile. The fragments of a stage are dealt to the four waves round robin; where NF is not a multiple of 4 (the 64 x 128
@@ -1063,14 +1064,14 @@ __global__ __launch_bounds__(256) void pack_joint_split_kernel(const SplitDense 
     *reinterpret_cast<uint4*>(dst + 2048) = make_uint4(a2.x, a2.y, b2.x, b2.y);
 }
 
-// (one workgroup per CU: 192 workgroups of 128 x 128 at 512 sites -- the register budget of one wave per SIMD)
-template <int MTW, int NTW>
-__global__ __launch_bounds__(256, 1) void dense_split_kernel(const SplitDense d)
+// Workgroup tile = (32 WM MTW) rows x (32 WN NTW) columns; the launcher picks it by forward size.
+template <int MTW, int NTW, int WM, int WN>
+__global__ __launch_bounds__(256, (SplitRing<MTW, NTW, WM, WN>::LDS_BYTES > 80 * 1024) ? 1 : 2) void dense_split_kernel(const SplitDense d)
 {
-    typedef SplitRing<MTW, NTW> R;
+    typedef SplitRing<MTW, NTW, WM, WN> R;
     extern __shared__ __attribute__((aligned(16))) float ring[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int mi = wave & 1, nj = wave >> 1;
+    const int mi = wave % WM, nj = wave / WM;
     const int mblocks = (d.mtiles + R::FRA - 1) / R::FRA;
     const int nblocks = (d.ntiles + R::FRB - 1) / R::FRB;
     const int total = mblocks * nblocks;
@@ -1122,9 +1123,17 @@ hipError_t launch_dense_split(const SplitDense& d, hipStream_t s)
     if (d.ksteps <= 0 || (d.N & 3) || d.ntiles_alloc < 4) return hipErrorInvalidValue;
     const long total = (long)d.mtiles * 32 * d.ksteps * 2;
     hipLaunchKernelGGL(pack_joint_split_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, d);
-    typedef SplitRing<2, 2> R;
-    const int mblocks = (d.mtiles + R::FRA - 1) / R::FRA, nblocks = (d.ntiles + R::FRB - 1) / R::FRB;
-    hipLaunchKernelGGL((dense_split_kernel<2, 2>), dim3(mblocks * nblocks), dim3(256), R::LDS_BYTES, s, d);
+    // tile by forward size (measured on one box, us per forward at 512 / 2,048 sites; the native fp32 GEMM: 292 / 1,148):
+    // 128 x 96 (waves 4 x 1): 245 / 769 -- 252 workgroups at 512 sites fill the 256 CUs; 128 x 128 (waves 2 x 2): 253 / 725
+    if (d.n < 1024) {
+        typedef SplitRing<1, 3, 4, 1> R;
+        const int mblocks = (d.mtiles + R::FRA - 1) / R::FRA, nblocks = (d.ntiles + R::FRB - 1) / R::FRB;
+        hipLaunchKernelGGL((dense_split_kernel<1, 3, 4, 1>), dim3(mblocks * nblocks), dim3(256), R::LDS_BYTES, s, d);
+    } else {
+        typedef SplitRing<2, 2, 2, 2> R;
+        const int mblocks = (d.mtiles + R::FRA - 1) / R::FRA, nblocks = (d.ntiles + R::FRB - 1) / R::FRB;
+        hipLaunchKernelGGL((dense_split_kernel<2, 2, 2, 2>), dim3(mblocks * nblocks), dim3(256), R::LDS_BYTES, s, d);
+    }
     return hipGetLastError();
 }
 
@@ -1142,10 +1151,10 @@ static bool split_chain_ok(const FusedChain& c)
 
 hipError_t configure_split_kernels()
 {
-    const void* fns[8] = {(const void*)stem23_split_kernel, (const void*)inception_fused_split_kernel<1>, (const void*)inception_fused_split_kernel<2>,
+    const void* fns[9] = {(const void*)stem23_split_kernel, (const void*)inception_fused_split_kernel<1>, (const void*)inception_fused_split_kernel<2>,
                           (const void*)inception_fused_split_kernel<3>, (const void*)lstm_cell_split_kernel<1, 1>,
                           (const void*)lstm_cell_split_kernel<1, 2>, (const void*)lstm_cell_split_kernel<2, 2>,
-                          (const void*)dense_split_kernel<2, 2>};
+                          (const void*)dense_split_kernel<2, 2, 2, 2>, (const void*)dense_split_kernel<1, 3, 4, 1>};
     for (const void* f : fns) {
         const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;

@@ -69,7 +69,7 @@ typedef struct ds_config {
                              reserved[5]: fused inception module, fewest workgroups a grid is shrunk to when the
                                           batch allows more (0 = default 128);
                              reserved[6]: DS_PRECISION_BF16X3 only: sites per forward from which dense(J, J) of the three-step joint
-                                          model runs with split operands (0 = default 2048; 1 = always).
+                                          model runs with split operands instead of the native fp32 GEMM (0 = default: always).
                              Every knob is per handle: the library reads no environment variable and keeps no
                              process-global tuning state, so two handles in one process never influence each other. */
 } ds_config;

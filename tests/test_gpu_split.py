@@ -57,8 +57,7 @@ def test_split_engine_against_the_cpu_statement_of_the_same_arithmetic(request, 
 
 def test_the_split_kernels_are_the_ones_that_run(small_weights):
     feats = synth.synthetic_features(96, seed=4101)
-    # (split_dense_min_n=1: below 2,048 sites per forward the planner keeps the native fp32 GEMM for dense(J, J) -- at 512 sites
-    # the split form is bound by operand delivery and no faster; here it is forced so that all three run)
+    # (split_dense_min_n=1 = the default since the 128 x 96 tile: every matrix product of the three-step path runs split)
     eng = _engine(small_weights, max_batch=96, precision="bf16x3", fold_fc=False, split_dense_min_n=1)
     eng.set_graph(False)
     eng.set_profiling(1)
