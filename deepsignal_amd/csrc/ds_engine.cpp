@@ -609,10 +609,13 @@ int alloc_workspace(ds_handle* h)
     return rc;
 }
 
-// workgroup tile of the split-operand BiLSTM cells by sites per forward (measured on MI355X): the cells are
-// bound by operand delivery, so the widest tile that still fills the GPU wins
+// workgroup tile of the split-operand BiLSTM cells by sites per forward (measured on MI355X). The cells are
+// bound by operand delivery. Stand-alone the 64 x 64 tile is the fastest below 2,048 sites (333 against 474 us per 512-site step:
+// 768 small workgroups hide latency), but in the PIPELINED step -- where the cells share the CUs' operand path with the other
+// forwards' kernels -- the 128 x 128 tile's halved bytes per MFMA win: 629 k against 610 k sites/s (three-step), 831 k against 809 k
+// (folded) at 512 sites, 8 slots. Tiny forwards keep the small tile (too few 128 x 128 workgroups to fill anything).
 #ifndef DS_SPLIT_LSTM_TILE
-#define DS_SPLIT_LSTM_TILE(n) ((n) >= 2048 ? 322 : 311)
+#define DS_SPLIT_LSTM_TILE(n) ((n) >= 256 ? 322 : 311)
 #endif
 
 int module_width(const ds_handle* h, int m) { return m < 3 ? h->wa : (m < 8 ? h->wb : h->wc); }
