@@ -373,7 +373,7 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0     # MI355X_MICROARCH.md, "Peak BF16/FP16 MFMA" 
 SPLIT_PRODUCTS_PER_MAC = 6         # DS_PRECISION_BF16X3: three bf16 terms per operand, six term products per fp32-class MAC
 
 
-def bf16x3_leg(Engine, w, torch, make_step, timed_windows, local_rank, slots, lstm_tiling, steps):
+def bf16x3_leg(Engine, w, torch, make_step, timed_windows, local_rank, slots, lstm_tiling, steps, host_feats=None):
     """DS_PRECISION_BF16X3 beside the headline: the same 512-site steps, the same timed-window rules, on an
     engine that carries fp32 operands as three bf16 terms through the bf16 matrix pipe (six products per MAC, fp32 accumulate) in
     the layers ds_version() lists, everything else as the fp32 engine. Its own key with its own roofline: algorithmic FLOPs of the
@@ -437,6 +437,13 @@ def bf16x3_leg(Engine, w, torch, make_step, timed_windows, local_rank, slots, ls
                      "label_flip_rate_vs_f64": round(float((p_ != p64).mean()), 5)}
     acc["label1_share_f64"] = round(float(p64.mean()), 4)
     out["accuracy_stress_set"] = acc
+    if host_feats is not None:
+        # feature TSV -> result TSV as `deepsignal call_mods --precision bf16x3` runs it (engine created for ENGINE_BATCH sites per forward)
+        from deepsignal_amd import call_modifications as _cm
+        e = Engine(device=local_rank, max_batch=_cm.ENGINE_BATCH["bf16x3"], precision="bf16x3")
+        e.load_weights(w)
+        out["e2e_tsv"] = e2e_tsv(e, host_feats, 163840, BATCH)
+        e.close()
     return out
 
 
@@ -889,7 +896,8 @@ def main():
         if rank == 0:
             result["e2e_tsv_sharded"] = shard
     if solo and not args.no_split:
-        result["fp32_class_bf16x3"] = bf16x3_leg(Engine, w, torch, make_step, timed_windows, local_rank, args.slots, args.lstm_tiling, K)
+        result["fp32_class_bf16x3"] = bf16x3_leg(Engine, w, torch, make_step, timed_windows, local_rank, args.slots, args.lstm_tiling, K,
+                                                 host_feats=None if args.no_host_path else feats)
     if solo and not args.no_configs2:
         result["configs2_bf16_batch4096"] = configs2_leg(Engine, w, torch, dev, local_rank, host_path=not args.no_host_path)
         if "e2e_tsv" in result["configs2_bf16_batch4096"].get("bf16_all", {}):

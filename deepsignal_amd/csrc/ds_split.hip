@@ -50,22 +50,23 @@ __device__ __forceinline__ floatx16 mfma3_hi(const float4 (&w)[3], float4 a0, fl
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// Fused inception modules, split operands. Phases, wave roles and the static wave -> unit table are those of
-// inception_fused_kernel (ds_kernels.hip): one workgroup (8 waves) owns a tile of whole sites (<= 96 rows) and takes it through
-// the modules of one width class;
+// Fused inception modules, split operands. Tile, chaining and phases are those of inception_fused_kernel (ds_kernels.hip): one
+// workgroup (8 waves) owns a tile of whole sites (<= 96 rows) and takes it through the modules of one width class; only a chain's
+// first module may take the stride-2 max pool of its input while staging;
 //   P1  [rows x cin] x [cin x 256]: wave w owns n-tile w for all m-tiles, K in chunks of 16 channels = ONE bf16 k-step.
-//       The stagers (waves 0..5) load the chunk's fp32 rows AND their two neighbour rows from global memory, take the 3-tap
-//       max (branch 1's maxpool(3, 1, SAME), padded taps ignored = the own row), split both the plain and the pooled values
-//       into terms and write ONE staged row [plain t0 | t1 | t2 | pooled t0 | t1 | t2] x 32 B: every wave's fragment reads
-//       are three ds_read_b128 at immediate offsets from one address (waves 6, 7: the pooled half), no wave pools or splits
-//       inside its MFMA stream. Per chunk and wave: 3 weight fragments (one per term, global -> VGPR), 3 x TM activation
-//       fragments, 6 x TM MFMAs.
-//   P2a / P2b: the 1x3 / 1x5 convs from the 32-channel intermediates, which the P1 epilogue wrote to LDS as terms (T1, zero
-//       halo rows = SAME padding); branch 5's 64-channel intermediate likewise (T2); its last 1x1 accumulates on top of the
-//       stem accumulators.
-// LDS (bytes): staged chunks 2 x rows x 208 (later the fp32 b1|b2 output tile) | T2 rows x 400 | T1 (spt (W + 4) + 5) x 592:
-// 143 - 147 KB for 96-row tiles, one workgroup per CU. Every row stride is an odd number of 16-byte slots.
-// Roofline: the bf16 matrix pipe at six products per MAC.
+//       The staging waves (0 .. 2 TM - 1) load the chunk's fp32 rows ONCE, park a raw copy in LDS (T2's region, idle during P1), and
+//       one step later read the row and its two neighbours back from it, take the 3-tap max (branch 1's maxpool(3, 1, SAME), padded
+//       taps ignored = the own row), split both the plain and the pooled values into terms and write ONE staged row
+//       [plain t0 | t1 | t2 | pooled t0 | t1 | t2] x 32 B: every wave's fragment reads are three ds_read_b128 at immediate
+//       offsets from one address (waves 6, 7: the pooled half), no wave pools or splits inside its MFMA stream. Per chunk and wave:
+//       3 weight fragments (one per term, global -> VGPR), 3 x TM activation fragments, 6 x TM MFMAs; one barrier per chunk.
+//   P2  the 1x3 / 1x5 convs from the 32-channel intermediates, which the P1 epilogue wrote to LDS as terms (T1, zero halo rows =
+//       SAME padding), dealt by (conv, n-tile): a wave takes its weight fragments through all the m-tiles it owns. Branch 5's
+//       64-channel intermediate goes to LDS as terms as well (T2); its last 1x1 accumulates on top of the stem accumulators.
+// LDS (bytes): staged chunks 2 x rows x 208 (later the fp32 b1|b2 output tile) | T2 rows x 400 (raw chunks during P1) | T1
+// (spt (W + 4) + 5) x 592: 143 - 147 KB for 96-row tiles, one workgroup per CU. Every row stride is an odd number of 16-byte slots.
+// What bounds it: operand delivery in P1 (24 KB of weight fragments + 6 KB of rows per 16-channel step and CU, ~16 B/clk), the
+// dependent phases of one workgroup per CU in P2.
 constexpr int S_LDP = 208;      // staged chunk row: 6 x 32 B + 16
 constexpr int S_LD1 = 592;      // T1 row: 3 terms x 96 channels x 2 B + 16
 constexpr int S_LD2 = 400;      // T2 row: 3 terms x 64 channels x 2 B + 16
@@ -1077,8 +1078,10 @@ __global__ __launch_bounds__(256, (SplitRing<MTW, NTW, WM, WN>::LDS_BYTES > 80 *
     const int total = mblocks * nblocks;
     // XCD-aware order (workgroup b runs on XCD b % 8): every XCD takes a contiguous run of logical tiles; the m-blocks of one weight
     // panel are neighbours, so a panel streams into one L2 once
-    int b = blockIdx.x;
-    if ((total & 7) == 0) b = (b & 7) * (total >> 3) + (b >> 3);
+    // (workgroup b runs on XCD b % 8; XCD x takes total / 8 tiles, the first total % 8 XCDs one more; PMC: with the m-blocks of a panel on
+    // different XCDs the 128 x 96 launch fetched 913 MB from the memory side for 218 MB of weights)
+    const int bx = blockIdx.x & 7, bq = blockIdx.x >> 3, per = total >> 3, rem8 = total & 7;
+    const int b = bx * per + min(bx, rem8) + bq;
     const int nb = b / mblocks, mb = b - nb * mblocks;
     const int half = lane >> 5, r31 = lane & 31;
     const unsigned lane4 = (unsigned)lane * 4;
