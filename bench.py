@@ -417,6 +417,8 @@ def bf16x3_leg(Engine, w, torch, make_step, timed_windows, local_rank, slots, ls
                                    "frac_of_fp32_mfma_peak": round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
                                    "bf16_mfma_frac": round(ach * SPLIT_PRODUCTS_PER_MAC / PEAK_BF16_MFMA_TFLOPS, 4),
                                    "measured": "stand-alone: every launch of the step on ONE stream, HIP events on that stream, eager replay of %d steps" % KP}
+                out["roofline"]["standalone_fracs"] = {
+                    k_["name"]: round(k_["flops"] / (k_["total_ms"] * 1e-3) / 1e12 / peak, 4) for k_ in sp if k_["total_ms"] and k_["flops"]}
                 out["roofline"].update(pmc_traffic(k["name"], "r[0-9][0-9]_bf16x3_pmc_traffic.json"))
                 out["roofline"].update(pmc_mfma_busy(k["name"], "r[0-9][0-9]_bf16x3_pmc_mfma_util.json"))
         e.close()
