@@ -188,3 +188,36 @@ def test_stress_golden_vectors_and_balanced_heads():
         head = W.centred_head(taps["fc1"], wset["dense_1/kernel"][:, 0], std, seed + 3)
         ref = g[tag + "_head"]
         assert head.shape == ref.shape and np.allclose(head, ref, rtol=1e-6, atol=1e-6 * float(np.abs(ref).max())), tag
+
+
+def test_split_operand_statement_is_exact_in_its_terms_and_fp32_class():
+    """oracle/torch_statement.py::forward_split is the CPU statement of DS_PRECISION_BF16X3 (tests/test_gpu_split.py holds the HIP
+    engine to it). Pinned here without a GPU: three bf16 terms reproduce an fp32 value exactly, the six-product sum of a matrix
+    product is as close to float64 as a native fp32 product, and the whole forward with every matrix product split lands within
+    the fp32 oracle's own distance of the float64 oracle (two terms / three products do not: 16 significant bits)."""
+    import torch
+    from deepsignal_amd import synth, weights as W
+    from oracle import oracle, torch_statement as ts
+    rng = np.random.default_rng(5)
+    x = torch.from_numpy((rng.normal(size=4096) * np.exp(rng.uniform(-20, 20, size=4096))).astype(np.float32))
+    t = ts.split_terms(x, 3)
+    assert all(torch.equal(v, v.to(torch.bfloat16).to(torch.float32)) for v in t)            # every term is a bf16 value
+    assert torch.equal(t[0] + t[1] + t[2], x)                                                 # ... and they sum to x exactly
+    assert ts.split_pairs(3) == [(0, 0), (0, 1), (1, 0), (0, 2), (1, 1), (2, 0)] and ts.split_pairs(2) == [(0, 0), (0, 1), (1, 0)]
+    a = torch.from_numpy(rng.normal(size=(64, 512)).astype(np.float32))
+    b = torch.from_numpy(rng.normal(size=(512, 96)).astype(np.float32))
+    ref = a.double() @ b.double()
+    e3 = float((ts._split_matmul(a, b, 3, torch.float32).double() - ref).abs().max())
+    e32 = float(((a @ b).double() - ref).abs().max())
+    e2 = float((ts._split_matmul(a, b, 2, torch.float32).double() - ref).abs().max())
+    assert e3 <= 2.0 * e32 + 1e-6 and e2 > 10.0 * e3, (e3, e32, e2)
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "stress_golden.npz"))
+    w = W.stress_weights(int(g["stress_seed"]), head=g["stress_head"])
+    feats = synth.synthetic_features(24, seed=77)
+    a64, p64 = oracle.forward(w, feats, "f64")
+    a32, _ = oracle.forward(w, feats, "f32")
+    a3, p3 = ts.forward_split(w, feats, terms=3, scope=("modules", "stem23", "lstm", "fc1"))
+    d3, d32 = float(np.abs(a3 - a64).max()), float(np.abs(a32 - a64).max())
+    assert d3 <= max(2.0 * d32, 4e-5) and d3 <= 1e-4, (d3, d32)
+    decided = np.abs(a64[:, 1] - a64[:, 0]) > 1e-3
+    assert (p3[decided] == p64[decided]).all()
