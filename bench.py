@@ -892,9 +892,15 @@ def main():
         result["fast_mode_folded"] = fm
         engf.close()
     eng.close()
-    if dist is not None and world > 1 and not args.no_host_path:
-        # every rank takes part (collectives inside); rank 0 reports
-        shard = e2e_tsv_sharded(Engine, w, feats, dist, rank, world, gpu_index, cdev, args.sharded_rows_per_rank, BATCH)
+    if dist is not None and not args.no_host_path:
+        # the product's multi-GPU route: every rank takes part (collectives inside), rank 0 reports. Also with ONE rank under the
+        # launcher, so that the leg's RCCL calls have run on a GPU box before a multi-GPU node ever sees them (tests/test_gpu_rccl.py).
+        # A failure here must not take the headline down with it: it is caught on the rank it happens on and reported as text (a
+        # rank that fails inside a collective still ends the job through the process group's timeout)
+        try:
+            shard = e2e_tsv_sharded(Engine, w, feats, dist, rank, world, gpu_index, cdev, args.sharded_rows_per_rank, BATCH)
+        except Exception as exc:
+            shard = {"error": repr(exc)}
         if rank == 0:
             result["e2e_tsv_sharded"] = shard
     if solo and not args.no_split:

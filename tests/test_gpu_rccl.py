@@ -193,7 +193,7 @@ def test_bench_under_the_launcher_with_one_rank(tmp_path):
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5",
-           "--windows", "3", "--no-profile-pass"]
+           "--windows", "3", "--no-profile-pass", "--sharded-rows-per-rank", "4000"]
     out = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
     assert out.returncode == 0, out.stderr.decode()[-3000:]
     lines = [l for l in out.stdout.decode().splitlines() if l.startswith("{")]
@@ -201,5 +201,9 @@ def test_bench_under_the_launcher_with_one_rank(tmp_path):
     r = json.loads(lines[0])
     assert r["n_gpus"] == 1 and r["steps"] == 20 and r["value"] > 1e5
     assert r["gather"]["backend"] == "nccl" and r["gather"]["bytes_per_window"] == 20 * 512 * 12
+    # the product's sharded TSV -> TSV route inside the same run, its collectives on RCCL (one rank: the calls eight ranks make)
+    sh = r["e2e_tsv_sharded"]
+    assert "error" not in sh, sh
+    assert sh["complete"] and sh["rows"] == 4000 and sh["value"] > 0 and "nccl" in sh["path"]
     with open(os.path.join(str(tmp_path), "bench_launcher_1rank.json"), "w") as f:
         f.write(lines[0])
