@@ -92,27 +92,7 @@ __device__ __forceinline__ void fuseds_unit_prefetch(const float* __restrict__ B
         if (g < ntaps * 6) ub[g] = gload4(bsrc + g * 256);
 }
 
-template <int NTAPS>
-__device__ __forceinline__ void fuseds_conv_unit(const char* T1, int rm, int cbyte, int lane, const float4 (&ub)[30], floatx16& acc)
-{
-    const char* base = T1 + rm * S_LD1 + cbyte + (lane >> 5) * 16;
-#pragma unroll
-    for (int t = 0; t < NTAPS; ++t) {
-        const char* arow = base + (t - NTAPS / 2) * S_LD1;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const float4 a0 = *reinterpret_cast<const float4*>(arow + j * 32);
-            const float4 a1 = *reinterpret_cast<const float4*>(arow + S_T1P + j * 32);
-            const float4 a2 = *reinterpret_cast<const float4*>(arow + 2 * S_T1P + j * 32);
-            const int q = (t * 2 + j) * 3;
-            const float4 w[3] = {ub[q], ub[q + 1], ub[q + 2]};
-            acc = mfma3_lo(w, a0, a1, a2, acc);
-            acc = mfma3_hi(w, a0, a1, acc);
-        }
-    }
-}
-
-// the same conv on NM m-tiles at once: one set of weights, NM accumulators, TWO fragment buffers: the three reads of the next
+// one second-stage conv on NM m-tiles at once: one set of weights, NM accumulators, TWO fragment buffers: the three reads of the next
 // (tap, k-step, m-tile) group are issued in front of the six MFMAs of the current one and land while those run (192 cycles of MFMA
 // per group against ~100 of LDS latency); left to itself hipcc issues a group's reads directly in front of its MFMAs and every group
 // waits for the LDS (6.8 k cycles for 108 MFMAs with one wave per SIMD active).
