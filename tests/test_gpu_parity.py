@@ -166,13 +166,14 @@ def test_errors_are_loud(small_weights):
                                      dict(is_cnn=True, is_rnn=False, is_base=True),     # CNN-only
                                      dict(is_cnn=True, is_rnn=True, is_base=False),     # no k-mer embedding
                                      dict(is_cnn=False, is_rnn=True, is_base=False)])
-def test_model_variants(variant):
+@pytest.mark.parametrize("precision", FP32_CLASS)
+def test_model_variants(variant, precision):
     """Model(is_cnn, is_rnn, is_base) switches of model.py:28-29,59-75,89-95."""
     from deepsignal_amd import weights as W
     from oracle import oracle
     w = W.random_weights(seed=21, lstm_bias_std=0.1, **variant)
     feats = synth.synthetic_features(40, seed=77)
-    eng = _engine(w, max_batch=64, debug=True, **variant)
+    eng = _engine(w, max_batch=64, debug=True, precision=precision, **variant)
     act, pred = eng.run(feats["kmer"], feats["means"], feats["stds"], feats["sanums"], feats["signals"])
     o_act, o_pred, taps = oracle.forward(w, feats, "f32", taps=True, **variant)
     for name, ref in taps.items():
@@ -183,12 +184,13 @@ def test_model_variants(variant):
     eng.close()
 
 
-def test_pipelined_device_forwards_match_blocking(small_weights):
+@pytest.mark.parametrize("precision", FP32_CLASS)
+def test_pipelined_device_forwards_match_blocking(small_weights, precision):
     """ds_forward_device rotates over independent slots (several forwards in flight): every slot must give
     bit-identical results to the blocking host path, in any interleaving."""
     import torch
     feats = synth.synthetic_features(4 * 512, seed=31)
-    eng = _engine(small_weights, max_batch=512, slots=5)
+    eng = _engine(small_weights, max_batch=512, slots=5, precision=precision)
     dev = torch.device("cuda", 0)
     d = {k: torch.from_numpy(feats[k]).to(dev) for k in ("kmer", "means", "stds", "sanums", "signals")}
     nstep = 13
