@@ -724,17 +724,31 @@ constexpr int SPLIT_KSTEP_BYTES = 3 * 1024;               // the three term frag
 constexpr int SPLIT_MT_BYTES = 16 * SPLIT_KSTEP_BYTES;    // one m-tile of a split h buffer (256 units = 16 k-steps)
 
 #ifndef DS_SPLIT_PIPED
-#define DS_SPLIT_PIPED 0        // 1: fragments double-buffered in registers (SplitRing::run; measured SLOWER: 342 against 310 us for dense(6032, 6032) at
-#endif                          // 512 sites -- the loop is bound by operand delivery, not by LDS latency), 0: one stage at a time
+#define DS_SPLIT_PIPED 3        // SplitRing::run: 0 = one stage at a time (run_simple), 1 / 2 = fragments double-buffered in registers with the
+#endif                          // stage's requests in one burst before / after its MFMAs, 3 = requests spread between the MFMAs (shipped)
 #ifndef DS_SPLIT_KGS11
 #define DS_SPLIT_KGS11 1
 #endif
 #ifndef DS_SPLIT_KGS22
 #define DS_SPLIT_KGS22 1
 #endif
-template <int MTW, int NTW, int WM = 2, int WN = 2>      // WM x WN waves (= 4), each MTW x NTW tiles of 32 x 32
+#ifndef DS_RING_SCHED
+#define DS_RING_SCHED 1
+#endif
+#ifndef DS_RING_BISECT
+#define DS_RING_BISECT 0      // timing experiments only: 1 = no MFMAs, 2 = no LDS-DMA requests, 3 = no barrier, 4 = no K loop at all; (piped loop) no MFMAs and 5 = A requests only, 6 = B requests only, 7 = no LDS reads either
+#endif
+#ifndef DS_SPLIT_LSTM_SLOTS
+#define DS_SPLIT_LSTM_SLOTS 3
+#endif
+#ifndef DS_SPLIT_DENSE_SLOTS
+#define DS_SPLIT_DENSE_SLOTS 4
+#endif
+// WM x WN waves (= 4), each MTW x NTW tiles of 32 x 32; NSLOT ring slots: stage st + NSLOT - 1 is requested while stage st is consumed
+template <int MTW, int NTW, int WM = 2, int WN = 2, int NSLOT = 3>
 struct SplitRing {
     static_assert(WM * WN == 4, "four waves per workgroup");
+    static_assert(NSLOT >= 3 && (NSLOT - 2) * ((3 * (WM * MTW + WN * NTW) + 3) / 4) <= 63, "vmcnt holds six bits");
     static constexpr int FRA = WM * MTW, FRB = WN * NTW;
     static constexpr int NF1 = 3 * (FRA + FRB);              // 1 KiB fragments per k-step
     // k-steps per ring stage: one barrier per KGS k-steps. DS_SPLIT_KGS11 / DS_SPLIT_KGS22: measured choices for the 64 x 64 and the
@@ -744,8 +758,21 @@ struct SplitRing {
     static constexpr int NF = KGS * NF1;
     static constexpr int LPS = (NF + 3) / 4;                 // LDS-DMA requests per wave and stage (waves >= NF % 4: one fewer if NF % 4)
     static constexpr int STAGE = NF * 256;                   // floats
-    static constexpr size_t LDS_BYTES = (size_t)3 * STAGE * 4;
+    // (piped loop: waves with one fragment fewer send a filler request into a pad, so that every wave counts the same vmcnt)
+    static constexpr int PAD_BYTES = (DS_SPLIT_PIPED == 3 && NF % 4 != 0) ? 4096 : 0;
+    static constexpr size_t LDS_BYTES = (size_t)NSLOT * STAGE * 4 + PAD_BYTES;
+#ifndef DS_RING_STAGGER
+#define DS_RING_STAGGER 0
+#endif
+#ifndef DS_RING_CLOCK
+#define DS_RING_CLOCK 0       // 1: s_memtime around the piped loop's wait / barrier / requests / rest, printed by two workgroups of the dense kernel
+#endif
+#if DS_RING_CLOCK
+    mutable unsigned long long clk[5] = {0, 0, 0, 0, 0};
+#endif
     const char* src[LPS];
+    mutable const char* rs[LPS];          // piped loop: request sources of stage 0, moved to the second A segment when the stages reach it
+    mutable bool in_seg1 = false;
     int kgi_[LPS];
     bool is_a[LPS];
     long dseg;
@@ -775,6 +802,7 @@ struct SplitRing {
                 const int g = f - 3 * FRA;
                 src[j] = B + ((size_t)(nt0 + g / 3) * kg_stride + kgi) * SPLIT_KSTEP_BYTES + (g % 3) * 1024;
             }
+            rs[j] = src[j];
         }
     }
     __device__ __forceinline__ void request(int st, int slot) const
@@ -783,21 +811,83 @@ struct SplitRing {
 #pragma unroll
         for (int j = 0; j < LPS; ++j) {
             if (NF % 4 != 0 && j == LPS - 1 && wave >= NF % 4) break;      // wave-uniform: this wave has no fragment 4 j + wave
+            if ((DS_RING_BISECT == 5 && !is_a[j]) || (DS_RING_BISECT == 6 && is_a[j])) continue;
             const int ks = st * KGS + kgi_[j];
             const long off = (long)st * (KGS * SPLIT_KSTEP_BYTES) + ((is_a[j] && ks >= s0) ? dseg : 0);
             glds16s(src[j] + off, lane16, dst + j * 4096);      // fragment q = wave + 4 j of the stage
         }
     }
-    // stage st has landed once every wave's requests for it are done: counted wait (stage st + 1 stays in flight), barrier -- which
-    // also frees ring slot (st + 2) % 3, read during stage st - 1 --, request stage st + 2, then this stage's MFMAs
+    // request j of this wave for stage st (the piped loop spreads a stage's requests between its MFMAs)
+    template <int J>
+    __device__ __forceinline__ void request_one(int st, unsigned dst) const
+    {
+        if (NF % 4 != 0 && J == LPS - 1 && wave >= NF % 4) return;
+        const int ks = st * KGS + kgi_[J];
+        const long off = (long)st * (KGS * SPLIT_KSTEP_BYTES) + ((is_a[J] && ks >= s0) ? dseg : 0);
+        glds16s(src[J] + off, lane16, dst + J * 4096);
+    }
+    // ---- piped loop, requests: the source of request J is (wave-uniform base rs[J]) + (lane offset + stage offset, ONE vector add per
+    // stage): no scalar address arithmetic per request; no branch either -- past the last stage the requests repeat it into the slot
+    // that has just been freed, and a wave without a fragment 4 J + wave refetches its last one into a pad
+    __device__ __forceinline__ unsigned stage_voff(int sreq) const
+    {
+        if (!in_seg1 && sreq >= s0) {
+#pragma unroll
+            for (int j = 0; j < LPS; ++j)
+                if (is_a[j]) rs[j] += dseg;
+            in_seg1 = true;
+        }
+        return lane16 + (unsigned)sreq * SPLIT_KSTEP_BYTES;
+    }
+    template <int J>
+    __device__ __forceinline__ void request3(unsigned voff, unsigned rdst) const
+    {
+        unsigned dst = rdst + J * 4096;
+        if (NF % 4 != 0 && J == LPS - 1 && wave >= NF % 4) dst = ring_lds + NSLOT * STAGE * 4 + wave * 1024;
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(rs[J]), "s"(dst) : "memory");      // (m0: saved and restored around the run of requests by the caller)
+    }
+    template <int J>
+    __device__ __forceinline__ void request3_all(unsigned voff, unsigned rdst) const
+    {
+        if constexpr (J < LPS) { request3<J>(voff, rdst); request3_all<J + 1>(voff, rdst); }
+    }
+    __device__ __forceinline__ void prologue(int nstages) const
+    {
+#if DS_SPLIT_PIPED == 3
+        static_assert(KGS == 1 && (NSLOT - 1) * LPS <= 63, "one k-step per stage; vmcnt holds six bits");
+        if (nstages <= 0) return;
+        unsigned keep_m0;
+        asm volatile("s_mov_b32 %0, m0" : "=s"(keep_m0));
+#pragma unroll
+        for (int s = 0; s < NSLOT; ++s) {
+            const unsigned voff = stage_voff(min(s, nstages - 1));
+            request3_all<0>(voff, __builtin_amdgcn_readfirstlane(ring_lds + (s * STAGE + wave * 256) * 4));
+        }
+        asm volatile("s_mov_b32 m0, %0" ::"s"(keep_m0));
+        return;
+#endif
+#pragma unroll
+        for (int s = 0; s < NSLOT - (DS_SPLIT_PIPED ? 0 : 1); ++s)
+            if (DS_RING_BISECT != 2 && DS_RING_BISECT != 4 && s < nstages) request(s, s);
+    }
+    // wait until all but the last K stages requested have landed (this wave's share; waves >= NF % 4 request one fragment fewer)
+    template <int K>
+    __device__ __forceinline__ void wait_but(int later) const
+    {
+        if (later >= K) {
+            if (NF % 4 == 0 || wave < NF % 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(K * LPS) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(K * (LPS - 1)) : "memory");
+        } else if constexpr (K > 0) wait_but<K - 1>(later);
+    }
+    // stage st has landed once every wave's requests for it are done: counted wait (stages st + 1 .. st + NSLOT - 2 stay in flight),
+    // barrier -- which also frees ring slot (st - 1) % NSLOT, read during stage st - 1 --, request stage st + NSLOT - 1 into it, then
+    // this stage's MFMAs
     template <int SLOT>
     __device__ __forceinline__ void stage(int st, int nstages, const float* fa0, const float* fb0, floatx16 (&acc)[MTW][NTW]) const
     {
-        if (st + 1 >= nstages) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else if (NF % 4 == 0 || wave < NF % 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
-        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS - 1) : "memory");
-        __builtin_amdgcn_s_barrier();
-        if (st + 2 < nstages) request(st + 2, (SLOT + 2) % 3);
+        wait_but<NSLOT - 2>(nstages - 1 - st);
+        if (DS_RING_BISECT != 3) __builtin_amdgcn_s_barrier();
+        if (DS_RING_BISECT != 2 && st + NSLOT - 1 < nstages) request(st + NSLOT - 1, (SLOT + NSLOT - 1) % NSLOT);
 #pragma unroll
         for (int kgi = 0; kgi < KGS; ++kgi) {
             float4 a[MTW][3], b[NTW][3];
@@ -813,88 +903,195 @@ struct SplitRing {
             for (int i = 0; i < MTW; ++i)
 #pragma unroll
                 for (int j = 0; j < NTW; ++j) {
+                    if (DS_RING_BISECT == 1) { acc[i][j][0] += b[j][0].x + b[j][1].y + b[j][2].z + a[i][0].x + a[i][1].y + a[i][2].z; continue; }
                     acc[i][j] = mfma3_lo(b[j], a[i][0], a[i][1], a[i][2], acc[i][j]);      // transposed: (A B)^T
                     acc[i][j] = mfma3_hi(b[j], a[i][0], a[i][1], acc[i][j]);
                 }
+#if DS_RING_SCHED == 1
+            // hipcc's own schedule reads a fragment, waits for it and issues its MFMA, one after the other, in 20 registers: every LDS
+            // latency is exposed (one wave per SIMD). All of a k-step's reads first, then its MFMAs behind counted waits.
+            __builtin_amdgcn_sched_group_barrier(0x100, 3 * (MTW + NTW), 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 6 * MTW * NTW, 0);
+#endif
         }
+    }
+    template <int SLOT>
+    __device__ __forceinline__ void run_from(int& st, int nstages, const float* fa0, const float* fb0, floatx16 (&acc)[MTW][NTW]) const
+    {
+        stage<SLOT>(st, nstages, fa0, fb0, acc);
+        if (++st >= nstages) return;
+        if constexpr (SLOT + 1 < NSLOT) run_from<SLOT + 1>(st, nstages, fa0, fb0, acc);
     }
     __device__ __forceinline__ void run_simple(int nstages, const float* fa0, const float* fb0, floatx16 (&acc)[MTW][NTW]) const
     {
-        for (int st = 0; st < nstages;) {
-            stage<0>(st, nstages, fa0, fb0, acc); if (++st >= nstages) break;
-            stage<1>(st, nstages, fa0, fb0, acc); if (++st >= nstages) break;
-            stage<2>(st, nstages, fa0, fb0, acc); ++st;
-        }
+        if (DS_RING_BISECT == 4) return;
+        for (int st = 0; st < nstages;) run_from<0>(st, nstages, fa0, fb0, acc);
     }
 
-    // The same ring with the fragments of a stage DOUBLE-BUFFERED IN REGISTERS: while the MFMAs of stage st run out of one register
-    // set, the LDS reads of stage st + 1 fill the other and the LDS-DMA requests of stage st + 3 refill the slot stage st has just
-    // left. With one wave per SIMD (the 128 x 128 tile: one workgroup per CU) the simple loop serialises a stage's 3 (MTW + NTW)
-    // ds_read_b128 with its 6 MTW NTW MFMAs -- 1,500 cycles per k-step for 768 of MFMA in dense(6032, 6032).
-    typedef float4 Frag[KGS][MTW + NTW][3];
-    template <int SLOT>
-    __device__ __forceinline__ void read_stage(const float* fa0, const float* fb0, Frag& f) const
+    // The same ring with a stage's fragments DOUBLE-BUFFERED IN REGISTERS. With one wave per SIMD (one workgroup per CU: the 128 x 96 dense
+    // tile, the 128 x 128 cell tile) nothing else issues while a wave waits, so run_simple pays per k-step, one after the other: the
+    // barrier, the requests, the LDS latency of the first fragments, then the MFMAs (dense(6032, 6032), 512 sites: 1,080 cycles per
+    // k-step WITHOUT any operand traffic, for 576 of MFMA). Here iteration st holds stage st in registers; it waits until stage st + 1
+    // has landed, passes the barrier (everybody's share of st + 1 has landed, everybody has READ stage st: its slot is free), requests
+    // stage st + NSLOT into that slot and then issues the LDS reads of stage st + 1 BETWEEN the MFMAs of stage st -- the interleave is
+    // pinned with sched_group_barrier, hipcc's own schedule serialises read -> wait -> MFMA. NSLOT stages are requested ahead.
+    // The MFMAs of one accumulator keep their order: bit-identical to run_simple.
+    static_assert(!DS_SPLIT_PIPED || KGS == 1, "the piped loop takes one k-step per stage");
+    typedef float4 Frag[MTW + NTW][3];
+    __device__ __forceinline__ void read_frags(const float* fa0, const float* fb0, int slot, Frag& f) const
+    {
+        if (DS_RING_BISECT == 7) return;
+        const float* fa = fa0 + slot * STAGE;
+        const float* fb = fb0 + slot * STAGE;
+#pragma unroll
+        for (int i = 0; i < MTW; ++i)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) f[i][p] = *reinterpret_cast<const float4*>(fa + (i * 3 + p) * 256);
+#pragma unroll
+        for (int j = 0; j < NTW; ++j)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) f[MTW + j][p] = *reinterpret_cast<const float4*>(fb + (j * 3 + p) * 256);
+    }
+    __device__ __forceinline__ void mfma_frags(const Frag& f, floatx16 (&acc)[MTW][NTW]) const
     {
 #pragma unroll
-        for (int kgi = 0; kgi < KGS; ++kgi) {
+        for (int i = 0; i < MTW; ++i)
 #pragma unroll
-            for (int i = 0; i < MTW; ++i)
-#pragma unroll
-                for (int p = 0; p < 3; ++p) f[kgi][i][p] = *reinterpret_cast<const float4*>(fa0 + SLOT * STAGE + (kgi * NF1 + i * 3 + p) * 256);
-#pragma unroll
-            for (int j = 0; j < NTW; ++j)
-#pragma unroll
-                for (int p = 0; p < 3; ++p) f[kgi][MTW + j][p] = *reinterpret_cast<const float4*>(fb0 + SLOT * STAGE + (kgi * NF1 + j * 3 + p) * 256);
+            for (int j = 0; j < NTW; ++j) {
+                if (DS_RING_BISECT == 7) continue;
+                if (DS_RING_BISECT == 1 || DS_RING_BISECT == 5 || DS_RING_BISECT == 6) { acc[i][j][0] += f[MTW + j][0].x + f[MTW + j][1].y + f[MTW + j][2].z + f[i][0].x + f[i][1].y + f[i][2].z; continue; }
+                acc[i][j] = mfma3_lo(f[MTW + j], f[i][0], f[i][1], f[i][2], acc[i][j]);
+                acc[i][j] = mfma3_hi(f[MTW + j], f[i][0], f[i][1], acc[i][j]);
+            }
+    }
+    static constexpr int req_pos(int j, bool odd)
+    {
+        const int nm = 6 * MTW * NTW, sp = nm / LPS, half = (DS_RING_STAGGER && sp >= 2) ? sp / 2 : 0;
+        const int p = (j * nm + LPS - 1) / LPS + 1 + (odd ? half : 0);
+        return p < nm ? p : nm - 1;
+    }
+    template <int M, int J>
+    __device__ __forceinline__ void piped_req(int st, bool more, unsigned rdst) const
+    {
+        if constexpr (J < LPS) {
+            if constexpr (req_pos(J, false) == M) request3<J>((unsigned)st, rdst);      // (st carries the stage's vector offset)
+            piped_req<M, J + 1>(st, more, rdst);
         }
     }
-    __device__ __forceinline__ void mfma_stage(const Frag& f, floatx16 (&acc)[MTW][NTW]) const
+    // element M of the pinned sequence (PIPED == 3)
+    template <int M>
+    __device__ __forceinline__ void piped_seq(int st, bool more, unsigned rdst, const float* fa, const float* fb, const Frag& cur, Frag& nxt,
+                                              floatx16 (&acc)[MTW][NTW]) const
     {
-#pragma unroll
-        for (int kgi = 0; kgi < KGS; ++kgi)
-#pragma unroll
-            for (int i = 0; i < MTW; ++i)
-#pragma unroll
-                for (int j = 0; j < NTW; ++j) {
-                    acc[i][j] = mfma3_lo(f[kgi][MTW + j], f[kgi][i][0], f[kgi][i][1], f[kgi][i][2], acc[i][j]);
-                    acc[i][j] = mfma3_hi(f[kgi][MTW + j], f[kgi][i][0], f[kgi][i][1], acc[i][j]);
-                }
-    }
-    // iteration st: registers `cur` hold stage st. Wait until stage st + 1 has landed (counted: stage st + 2 stays in flight), barrier
-    // (everybody's share of st + 1 has landed AND everybody has finished READING stage st's slot), request stage st + 3 into that
-    // slot, start the reads of stage st + 1 into `nxt`, run stage st's MFMAs.
-    template <int SLOT>      // SLOT = ring slot of stage st + 1
-    __device__ __forceinline__ void piped(int st, int nstages, const float* fa0, const float* fb0, const Frag& cur, Frag& nxt, floatx16 (&acc)[MTW][NTW]) const
-    {
-        if (st + 1 < nstages) {
-            if (st + 2 < nstages) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(LPS) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            if (st + 3 < nstages) request(st + 3, (SLOT + 2) % 3);
-            read_stage<SLOT>(fa0, fb0, nxt);
+        constexpr int NT_ = MTW * NTW, NR = 3 * (MTW + NTW), NM = 6 * NT_;
+        if constexpr (M < NM) {
+            constexpr int P = M / NT_, T = M % NT_, I = T / NTW, J = T % NTW;
+            // products in mfma3_lo / mfma3_hi order: (w2, a0) (w0, a2) (w1, a1) | (w1, a0) (w0, a1) (w0, a0)
+            constexpr int WI = P == 0 ? 2 : P == 1 ? 0 : P == 2 ? 1 : P == 3 ? 1 : 0;
+            constexpr int AI = P == 0 ? 0 : P == 1 ? 2 : P == 2 ? 1 : P == 3 ? 0 : P == 4 ? 1 : 0;
+            acc[I][J] = mfma_bf(cur[MTW + J][WI], cur[I][AI], acc[I][J]);
+            if constexpr (M < NR) {
+                constexpr int F = M / 3, TERM = M % 3;
+                nxt[F][TERM] = *reinterpret_cast<const float4*>((F < MTW ? fa + (F * 3 + TERM) * 256 : fb + ((F - MTW) * 3 + TERM) * 256));
+            }
+            // request j goes behind MFMA (j NM) / LPS + 1 in waves 0 and 2, half a spacing later in waves 1 and 3: the four waves run in
+            // step, and four requests at once hold each wave for the address unit's 4 x 16 cycles instead of 16
+            piped_req<M, 0>(st, more, rdst);
+            __builtin_amdgcn_sched_barrier(0);
+            piped_seq<M + 1>(st, more, rdst, fa, fb, cur, nxt, acc);
         }
-        mfma_stage(cur, acc);
+    }
+    // one iteration with a successor stage: slot = ring slot of stage st
+    __device__ __forceinline__ void piped(int st, int slot, int nstages, const float* fa0, const float* fb0, const Frag& cur, Frag& nxt, floatx16 (&acc)[MTW][NTW]) const
+    {
+#if DS_RING_CLOCK
+        const unsigned long long c0 = __builtin_amdgcn_s_memtime();
+        if (clk[4]) clk[3] += c0 - clk[4];
+#endif
+#if DS_SPLIT_PIPED == 3
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((NSLOT - 2) * LPS) : "memory");
+#else
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        wait_but<NSLOT - 2>(nstages - 2 - st);
+#endif
+#if DS_RING_CLOCK
+        const unsigned long long c1 = __builtin_amdgcn_s_memtime();
+#endif
+        __builtin_amdgcn_s_barrier();
+#if DS_RING_CLOCK
+        const unsigned long long c2 = __builtin_amdgcn_s_memtime();
+#endif
+#if DS_SPLIT_PIPED == 1
+        if (DS_RING_BISECT != 2 && st + NSLOT < nstages) request(st + NSLOT, slot);
+#endif
+#if DS_RING_CLOCK
+        const unsigned long long c3 = __builtin_amdgcn_s_memtime();
+        clk[0] += c1 - c0; clk[1] += c2 - c1; clk[2] += c3 - c2; clk[4] = c3;
+#endif
+#if DS_SPLIT_PIPED == 3
+        // the order is pinned instruction by instruction: MFMA m (round robin over the accumulators, the six products of one accumulator
+        // in mfma3_lo / mfma3_hi order), behind it LDS read m of the next stage, and every NM / LPS MFMAs one LDS-DMA request. In one
+        // burst behind the barrier the four waves' 21 requests held every wave for 350 cycles per k-step in front of its MFMAs
+        // (s_memtime: wait 150, barrier 20 - 50, requests 350, reads + MFMAs 600 of 1,150)
+        const unsigned voff = stage_voff(min(st + NSLOT, nstages - 1));
+        const unsigned rdst = __builtin_amdgcn_readfirstlane(ring_lds + (slot * STAGE + wave * 256) * 4);
+        const int nslot = slot + 1 == NSLOT ? 0 : slot + 1;
+        const float* fa = fa0 + nslot * STAGE;
+        const float* fb = fb0 + nslot * STAGE;
+        unsigned keep_m0;
+        asm volatile("s_mov_b32 %0, m0" : "=s"(keep_m0));
         __builtin_amdgcn_sched_barrier(0);
+        piped_seq<0>((int)voff, true, rdst, fa, fb, cur, nxt, acc);
+        asm volatile("s_mov_b32 m0, %0" ::"s"(keep_m0));
+#else
+        read_frags(fa0, fb0, slot + 1 == NSLOT ? 0 : slot + 1, nxt);
+        mfma_frags(cur, acc);
+        constexpr int NR = 3 * (MTW + NTW), NM = 6 * MTW * NTW;
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, NM - NR - 1, 0);
+#endif
+#if DS_SPLIT_PIPED == 2
+        if (st + NSLOT < nstages) request(st + NSLOT, slot);
+#endif
+        __builtin_amdgcn_sched_barrier(0);      // (the next iteration's lgkmcnt(0) stays behind this iteration's last MFMAs)
+    }
+    __device__ __forceinline__ void run_piped(int nstages, const float* fa0, const float* fb0, floatx16 (&acc)[MTW][NTW]) const
+    {
+        if (nstages <= 0) return;
+        // (prologue() has requested stages 0 .. NSLOT - 1)
+#if DS_SPLIT_PIPED == 3
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSLOT - 1) * LPS) : "memory");
+#else
+        wait_but<NSLOT - 1>(nstages - 1);
+#endif
+        __builtin_amdgcn_s_barrier();
+        Frag f0, f1;
+        read_frags(fa0, fb0, 0, f0);
+        int slot = 0, st = 0;
+        const int n1 = nstages - 1;                 // iterations with a successor stage, two per trip (the register sets swap roles)
+        for (int p = 0; p < (n1 >> 1); ++p) {
+            piped(st, slot, nstages, fa0, fb0, f0, f1, acc);
+            ++st; slot = slot + 1 == NSLOT ? 0 : slot + 1;
+            piped(st, slot, nstages, fa0, fb0, f1, f0, acc);
+            ++st; slot = slot + 1 == NSLOT ? 0 : slot + 1;
+        }
+        if (n1 & 1) {
+            piped(st, slot, nstages, fa0, fb0, f0, f1, acc);
+            mfma_frags(f1, acc);
+        } else mfma_frags(f0, acc);
+#if DS_SPLIT_PIPED == 3
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the filler requests of the last iterations)
+#endif
     }
     __device__ __forceinline__ void run(int nstages, const float* fa0, const float* fb0, floatx16 (&acc)[MTW][NTW]) const
     {
 #if DS_SPLIT_PIPED
-        if (nstages <= 0) return;
-        // (the caller has requested stages 0 and 1)
-        if (nstages > 2) request(2, 2);
-        if (nstages > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPS) : "memory");
-        else if (nstages > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        Frag fa, fb;
-        read_stage<0>(fa0, fb0, fa);
-        for (int st = 0; st < nstages;) {
-            piped<1>(st, nstages, fa0, fb0, fa, fb, acc); if (++st >= nstages) break;
-            piped<2>(st, nstages, fa0, fb0, fb, fa, acc); if (++st >= nstages) break;
-            piped<0>(st, nstages, fa0, fb0, fa, fb, acc); if (++st >= nstages) break;
-            piped<1>(st, nstages, fa0, fb0, fb, fa, acc); if (++st >= nstages) break;
-            piped<2>(st, nstages, fa0, fb0, fa, fb, acc); if (++st >= nstages) break;
-            piped<0>(st, nstages, fa0, fb0, fb, fa, acc); ++st;
-        }
+        run_piped(nstages, fa0, fb0, acc);
 #else
         run_simple(nstages, fa0, fb0, acc);
 #endif
@@ -905,11 +1102,11 @@ struct SplitRing {
 // products per MAC, fp32 accumulate; the layer-0 table row / rank-1 terms, the gates and the cell state are fp32 as in the fp32
 // kernel (lstm_acc_init / lstm_gates are shared with it); h is split once, in the epilogue that produces it.
 template <int MTW, int NTW>
-__global__ __launch_bounds__(256, (SplitRing<MTW, NTW>::LDS_BYTES > 80 * 1024) ? 1 : 2) void lstm_cell_split_kernel(const LstmLaunch L_)
+__global__ __launch_bounds__(256, (SplitRing<MTW, NTW, 2, 2, DS_SPLIT_LSTM_SLOTS>::LDS_BYTES > 80 * 1024) ? 1 : 2) void lstm_cell_split_kernel(const LstmLaunch L_)
 {
     const LstmLaunch* const Lp = &L_;
-    typedef SplitRing<MTW, NTW> R;
-    extern __shared__ __attribute__((aligned(16))) float ring[];    // [3 * STAGE]
+    typedef SplitRing<MTW, NTW, 2, 2, DS_SPLIT_LSTM_SLOTS> R;
+    extern __shared__ __attribute__((aligned(16))) float ring[];    // [NSLOT * STAGE]
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int mi = wave & 1, nj = wave >> 1;
     const int bid = lstm_logical_tile(blockIdx.x, gridDim.x, Lp->cls_tiles[0], Lp->cls_tiles[1]);
@@ -929,8 +1126,7 @@ __global__ __launch_bounds__(256, (SplitRing<MTW, NTW>::LDS_BYTES > 80 * 1024) ?
     R rg;
     rg.init(ring, wave, lane, reinterpret_cast<const char*>(has_x ? C.ax : C.ah), reinterpret_cast<const char*>(has_h ? C.ah : C.ax),
             has_x ? 16 : 0, SPLIT_MT_BYTES, mb * R::FRA, mtiles, reinterpret_cast<const char*>(C.Bp), C.kg_stride, ng * R::FRB);
-    if (nstages > 0) rg.request(0, 0);
-    if (nstages > 1) rg.request(1, 1);
+    rg.prologue(nstages);
 
     int mt[MTW];
     bool valid[MTW];
@@ -1001,9 +1197,9 @@ hipError_t launch_lstm_cells_split(int tile, const LstmLaunch& L, hipStream_t s)
     const int ncell = L.ncell, mtiles = L.mtiles;
     if (ncell <= 0 || mtiles <= 0) return hipSuccess;
     switch (tile) {
-    case 11: hipLaunchKernelGGL((lstm_cell_split_kernel<1, 1>), dim3(ncell * ((mtiles + 1) / 2) * 16), dim3(256), (SplitRing<1, 1>::LDS_BYTES), s, L); break;
-    case 12: hipLaunchKernelGGL((lstm_cell_split_kernel<1, 2>), dim3(ncell * ((mtiles + 1) / 2) * 8), dim3(256), (SplitRing<1, 2>::LDS_BYTES), s, L); break;
-    case 22: hipLaunchKernelGGL((lstm_cell_split_kernel<2, 2>), dim3(ncell * ((mtiles + 3) / 4) * 8), dim3(256), (SplitRing<2, 2>::LDS_BYTES), s, L); break;
+    case 11: hipLaunchKernelGGL((lstm_cell_split_kernel<1, 1>), dim3(ncell * ((mtiles + 1) / 2) * 16), dim3(256), (SplitRing<1, 1, 2, 2, DS_SPLIT_LSTM_SLOTS>::LDS_BYTES), s, L); break;
+    case 12: hipLaunchKernelGGL((lstm_cell_split_kernel<1, 2>), dim3(ncell * ((mtiles + 1) / 2) * 8), dim3(256), (SplitRing<1, 2, 2, 2, DS_SPLIT_LSTM_SLOTS>::LDS_BYTES), s, L); break;
+    case 22: hipLaunchKernelGGL((lstm_cell_split_kernel<2, 2>), dim3(ncell * ((mtiles + 3) / 4) * 8), dim3(256), (SplitRing<2, 2, 2, 2, DS_SPLIT_LSTM_SLOTS>::LDS_BYTES), s, L); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
@@ -1047,9 +1243,9 @@ __global__ __launch_bounds__(256) void pack_joint_split_kernel(const SplitDense 
 
 // Workgroup tile = (32 WM MTW) rows x (32 WN NTW) columns; the launcher picks it by forward size.
 template <int MTW, int NTW, int WM, int WN>
-__global__ __launch_bounds__(256, (SplitRing<MTW, NTW, WM, WN>::LDS_BYTES > 80 * 1024) ? 1 : 2) void dense_split_kernel(const SplitDense d)
+__global__ __launch_bounds__(256, (SplitRing<MTW, NTW, WM, WN, DS_SPLIT_DENSE_SLOTS>::LDS_BYTES > 80 * 1024) ? 1 : 2) void dense_split_kernel(const SplitDense d)
 {
-    typedef SplitRing<MTW, NTW, WM, WN> R;
+    typedef SplitRing<MTW, NTW, WM, WN, DS_SPLIT_DENSE_SLOTS> R;
     extern __shared__ __attribute__((aligned(16))) float ring[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int mi = wave % WM, nj = wave / WM;
@@ -1068,8 +1264,7 @@ __global__ __launch_bounds__(256, (SplitRing<MTW, NTW, WM, WN>::LDS_BYTES > 80 *
     const int nstages = d.ksteps / R::KGS;          // (ksteps is even wherever KGS = 2 is instantiated: checked by the launcher)
     R rg;
     rg.init(ring, wave, lane, d.A, d.A, d.ksteps, (long)d.ksteps * SPLIT_KSTEP_BYTES, mb * R::FRA, d.mtiles, d.Bp, d.kg_stride, min(nb * R::FRB, d.ntiles_alloc - R::FRB));
-    if (nstages > 0) rg.request(0, 0);
-    if (nstages > 1) rg.request(1, 1);
+    rg.prologue(nstages);
     floatx16 acc[MTW][NTW];
 #pragma unroll
     for (int i = 0; i < MTW; ++i)
@@ -1078,6 +1273,11 @@ __global__ __launch_bounds__(256, (SplitRing<MTW, NTW, WM, WN>::LDS_BYTES > 80 *
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
     rg.run(nstages, ring + (mi * MTW * 3) * 256 + lane4, ring + (3 * R::FRA + nj * NTW * 3) * 256 + lane4, acc);
+#if DS_RING_CLOCK
+    if ((blockIdx.x == 0 || blockIdx.x == 101) && lane == 0 && (wave == 0 || wave == 3))
+        printf("RING block %d wave %d: per k-step (100 MHz ticks x 1000) wait %d barrier %d request %d rest %d\n", (int)blockIdx.x, wave,
+               (int)(rg.clk[0] * 1000 / nstages), (int)(rg.clk[1] * 1000 / nstages), (int)(rg.clk[2] * 1000 / nstages), (int)(rg.clk[3] * 1000 / nstages));
+#endif
     const int nt_base = min(nb * R::FRB, d.ntiles_alloc - R::FRB);
 #pragma unroll
     for (int i = 0; i < MTW; ++i) {
@@ -1109,11 +1309,11 @@ hipError_t launch_dense_split(const SplitDense& d, hipStream_t s)
     // tile by forward size (measured on one box, us per forward at 512 / 2,048 sites; the native fp32 GEMM: 292 / 1,148):
     // 128 x 96 (waves 4 x 1): 245 / 769 -- 252 workgroups at 512 sites fill the 256 CUs; 128 x 128 (waves 2 x 2): 253 / 725
     if (d.n < 1024) {
-        typedef SplitRing<1, 3, 4, 1> R;
+        typedef SplitRing<1, 3, 4, 1, DS_SPLIT_DENSE_SLOTS> R;
         const int mblocks = (d.mtiles + R::FRA - 1) / R::FRA, nblocks = (d.ntiles + R::FRB - 1) / R::FRB;
         hipLaunchKernelGGL((dense_split_kernel<1, 3, 4, 1>), dim3(mblocks * nblocks), dim3(256), R::LDS_BYTES, s, d);
     } else {
-        typedef SplitRing<2, 2, 2, 2> R;
+        typedef SplitRing<2, 2, 2, 2, DS_SPLIT_DENSE_SLOTS> R;
         const int mblocks = (d.mtiles + R::FRA - 1) / R::FRA, nblocks = (d.ntiles + R::FRB - 1) / R::FRB;
         hipLaunchKernelGGL((dense_split_kernel<2, 2, 2, 2>), dim3(mblocks * nblocks), dim3(256), R::LDS_BYTES, s, d);
     }
