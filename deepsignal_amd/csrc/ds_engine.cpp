@@ -106,12 +106,15 @@ struct Stage {
     int64_t calls = 0;
 };
 
+#define DS_SPLIT_DENSE_PARTS 4       // K ranges of the split dense at small forwards (fc1o holds that many partial products)
+
 struct Plan {
     int n = 0;
     std::vector<GemmLaunch> launches;     // host copy
     GemmLaunch* d_launches = nullptr;
     std::vector<LstmLaunch> lstm_launches;   // fp32 BiLSTM diagonals (lstm_cell_*kernel): passed by value at launch
     std::vector<Op> ops;                  // merged issue order
+    int fc1_parts = 1;                    // partial products the split dense leaves in fc1o (launch_head adds them up)
     hipGraphExec_t graph = nullptr;
     int64_t uses = 0, last_use = 0;       // ragged tails produce many one-off sizes: graphs are captured for sizes that
                                           // recur, and the per-slot plan cache is bounded (get_plan)
@@ -583,7 +586,7 @@ int alloc_workspace(ds_handle* h)
         }
     if (h->is_rnn)
         for (int d = 0; d < 2; ++d) A(&h->cur->hlast[d], B * HID);
-    A(&h->cur->fc1o, B * h->J); A(&h->cur->logits, B * h->C);
+    A(&h->cur->fc1o, B * h->J * (h->split && !h->fold_fc ? DS_SPLIT_DENSE_PARTS : 1)); A(&h->cur->logits, B * h->C);
     A(&h->cur->act, B * h->C + B);            // [act | pred]: one block, one D2H copy
     if (!rc) h->cur->pred = reinterpret_cast<int*>(h->cur->act + B * h->C);
     if (h->bf16) A(&h->cur->joint, B * (size_t)h->JP / 2);
@@ -1002,6 +1005,11 @@ int build_plan(ds_handle* h, int n, Plan* plan)
         d.A = h->cur->jsplit; d.Bp = reinterpret_cast<const char*>(h->fc1.Bps); d.C = h->cur->fc1o;
         d.n = n; d.N = h->J; d.mtiles = (n + 31) / 32; d.ntiles = (h->J + 31) / 32; d.ntiles_alloc = d.ntiles;
         d.ksteps = h->J / 16; d.kg_stride = (h->J + 63) / 64 * 64 / 16;
+        // forwards below 1,024 sites: the 256 x 192 tile with K in ranges (at 512 sites 64 tiles x 4 ranges fill the 256 CUs)
+        static const bool wide = !getenv("DS_SPLIT_DENSE_WIDE") || atoi(getenv("DS_SPLIT_DENSE_WIDE")) != 0;
+        d.splits = (wide && n < 1024 && d.ntiles >= 6) ? DS_SPLIT_DENSE_PARTS : 1;
+        d.part_stride = (size_t)h->B * h->J;
+        plan->fc1_parts = d.splits;
         op.flops = 2.0 * n * (double)h->J * h->J;
         add_ew_op(tail, op);
         if (first_plan) h->stages[st].flops_per_site += 2.0 * (double)h->J * h->J;
@@ -1090,7 +1098,7 @@ int issue_op(ds_handle* h, Plan& plan, const Op& op, hipStream_t s)
         else HIPCHK(h, launch_inception_fused(op.tm, op.fc, s));
         break;
     case OP_HEAD:
-        HIPCHK(h, launch_head(h->cur->fc1o, h->fc2, h->cur->logits, h->cur->act, h->cur->pred, n, h->J, h->C, s));
+        HIPCHK(h, launch_head(h->cur->fc1o, h->fc2, h->cur->logits, h->cur->act, h->cur->pred, n, h->J, h->C, s, plan.fc1_parts, (size_t)h->B * h->J));
         break;
     }
     return DS_OK;
@@ -1768,7 +1776,19 @@ int64_t ds_get_intermediate(ds_handle* h, const char* name, float* out, int64_t 
     if (s == "stem_conv2") return copy(h->cur->conv2o, (int64_t)n * h->wa * 128);
     if (s == "stem_conv3") return copy(h->cur->conv3o, (int64_t)n * h->wa * 256);
     if (s == "signal_feat") return copy(h->cur->sigfeat, (int64_t)n * h->SF);
-    if (s == "fc1") return copy(h->cur->fc1o, (int64_t)n * h->J);
+    if (s == "fc1") {
+        const auto it = h->cur->plans.find((int)n);
+        const int parts = it != h->cur->plans.end() ? it->second.fc1_parts : 1;
+        const int64_t got = copy(h->cur->fc1o, (int64_t)n * h->J);
+        if (got < 0 || parts == 1) return got;
+        std::vector<float> part((size_t)n * h->J);            // the split dense's partial products, added in launch_head's order
+        for (int p = 1; p < parts; ++p) {
+            if (hipMemcpy(part.data(), h->cur->fc1o + (size_t)p * h->B * h->J, part.size() * 4, hipMemcpyDeviceToHost) != hipSuccess)
+                return fail(h, DS_ERR_HIP, "hipMemcpy D2H");
+            for (size_t i = 0; i < part.size(); ++i) out[i] += part[i];
+        }
+        return got;
+    }
     if (s == "logits") return copy(h->cur->logits, (int64_t)n * h->C);
     if (s.rfind("module", 0) == 0) {
         const int m = atoi(s.c_str() + 6) - 1;

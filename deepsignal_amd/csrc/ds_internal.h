@@ -153,8 +153,10 @@ struct SplitDense {
     int len[3];
     char* A;               // [mtiles][ksteps][3][1 KiB] workspace
     const char* Bp;        // [ntiles_alloc][kg_stride][3][1 KiB]
-    float* C;              // [n][N] fp32
+    float* C;              // [splits][n][N] fp32: partial sums over `splits` ranges of K (1: the product itself)
     int n, N, mtiles, ntiles, ntiles_alloc, ksteps, kg_stride;
+    int splits;            // > 1: the 256 x 192 tile, K in `splits` ranges; the reader sums the partial products in order (launch_head)
+    size_t part_stride;    // floats between two partial products
 };
 hipError_t launch_dense_split(const SplitDense& d, hipStream_t s);
 
@@ -191,7 +193,7 @@ hipError_t launch_maxpool_s2(const float* in, float* out, int n, int win, int wo
 hipError_t launch_avgpool7(const float* in, float* out, int n, int w, int ch, hipStream_t s);
 // fc2 (J x class_num, no bias) + sigmoid + argmax                               layers.py:261-263, model.py:100,108
 hipError_t launch_head(const float* fc1, const float* w2, float* logits, float* act, int* pred,
-                       int n, int J, int class_num, hipStream_t s);
+                       int n, int J, int class_num, hipStream_t s, int nparts = 1, size_t part_stride = 0);      // fc1 = sum of nparts partial products
 // Folded joint model (DS_TUNE_NO_FOLD_FC off): logits = x W12', x = up to three row segments per site (h_fw(T-1), h_bw(0),
 // module-11 rows), W12' [J][class_num] k-major; then sigmoid + argmax as launch_head        layers.py:233-238,247-264
 struct HeadFoldedArgs {

@@ -2333,7 +2333,7 @@ hipError_t launch_avgpool7(const float* in, float* out, int n, int w, int ch, hi
 // fc2 + sigmoid + argmax: one 256-thread block per site, float4 sweeps of the fc1 row, block reduce.
 __global__ __launch_bounds__(256) void head_kernel(const float* __restrict__ fc1, const float* __restrict__ w2,
                                                     float* __restrict__ logits, float* __restrict__ act,
-                                                    int* __restrict__ pred, int n, int J, int C)
+                                                    int* __restrict__ pred, int n, int J, int C, int nparts, size_t part_stride)
 {
     __shared__ float part[4][16];
     const int site = blockIdx.x;
@@ -2344,7 +2344,11 @@ __global__ __launch_bounds__(256) void head_kernel(const float* __restrict__ fc1
     for (int c = 0; c < 16; ++c) accv[c] = 0.0f;
     const int J4 = J >> 2;
     for (int k4 = tid; k4 < J4; k4 += 256) {
-        const float4 x = x4[k4];
+        float4 x = x4[k4];
+        for (int p = 1; p < nparts; ++p) {            // fc1 in partial products over ranges of K (the split dense at small forwards): summed in order
+            const float4 y = *reinterpret_cast<const float4*>(fc1 + p * part_stride + (size_t)site * J + 4 * (size_t)k4);
+            x.x += y.x; x.y += y.y; x.z += y.z; x.w += y.w;
+        }
         const float* w = w2 + (size_t)k4 * 4 * C;
         if (C == 2) {
             const float4 wa = *reinterpret_cast<const float4*>(w);
@@ -2357,8 +2361,11 @@ __global__ __launch_bounds__(256) void head_kernel(const float* __restrict__ fc1
                 if (c < C) accv[c] += x.x * w[c] + x.y * w[C + c] + x.z * w[2 * C + c] + x.w * w[3 * C + c];
         }
     }
-    for (int k = (J4 << 2) + tid; k < J; k += 256)      // J not a multiple of 4
-        for (int c = 0; c < C; ++c) accv[c] += fc1[(size_t)site * J + k] * w2[(size_t)k * C + c];
+    for (int k = (J4 << 2) + tid; k < J; k += 256) {    // J not a multiple of 4
+        float xk = fc1[(size_t)site * J + k];
+        for (int p = 1; p < nparts; ++p) xk += fc1[p * part_stride + (size_t)site * J + k];
+        for (int c = 0; c < C; ++c) accv[c] += xk * w2[(size_t)k * C + c];
+    }
 #pragma unroll
     for (int c = 0; c < 16; ++c) {
         if (c >= C) break;
@@ -2383,10 +2390,10 @@ __global__ __launch_bounds__(256) void head_kernel(const float* __restrict__ fc1
 }
 
 hipError_t launch_head(const float* fc1, const float* w2, float* logits, float* act, int* pred, int n, int J,
-                       int class_num, hipStream_t s)
+                       int class_num, hipStream_t s, int nparts, size_t part_stride)
 {
     if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(head_kernel, dim3(n), dim3(256), 0, s, fc1, w2, logits, act, pred, n, J, class_num);
+    hipLaunchKernelGGL(head_kernel, dim3(n), dim3(256), 0, s, fc1, w2, logits, act, pred, n, J, class_num, nparts, part_stride);
     return hipGetLastError();
 }
 

@@ -855,7 +855,7 @@ struct SplitRing {
     {
 #if DS_SPLIT_PIPED == 3
         static_assert(KGS == 1 && (NSLOT - 1) * LPS <= 63, "one k-step per stage; vmcnt holds six bits");
-        if (nstages <= 0) return;
+        if (nstages <= 0 || DS_RING_BISECT == 4) return;
         unsigned keep_m0;
         asm volatile("s_mov_b32 %0, m0" : "=s"(keep_m0));
 #pragma unroll
@@ -978,20 +978,39 @@ struct SplitRing {
             piped_req<M, J + 1>(st, more, rdst);
         }
     }
+    static constexpr bool ROLL = MTW >= 3;
+    static constexpr int read_frag(int m)
+    {
+        if (!ROLL) return m < 3 * (MTW + NTW) ? m : -1;
+        // the weight fragments and the LAST m-tile's activations first (that m-tile's MFMAs close the sequence), then m-tile i's
+        // activations behind its last MFMA
+        if (m < 3 * NTW) return (MTW + m / 3) * 3 + m % 3;
+        if (m < 3 * NTW + 3) return (MTW - 1) * 3 + (m - 3 * NTW);
+        for (int i = 0; i + 1 < MTW; ++i) {
+            const int base = (i + 1) * 6 * NTW;
+            if (m >= base && m < base + 3) return i * 3 + (m - base);
+        }
+        return -1;
+    }
+    static_assert(!ROLL || 3 * NTW + 3 <= 6 * NTW, "the early reads end before the first m-tile's MFMAs do");
     // element M of the pinned sequence (PIPED == 3)
     template <int M>
     __device__ __forceinline__ void piped_seq(int st, bool more, unsigned rdst, const float* fa, const float* fb, const Frag& cur, Frag& nxt,
                                               floatx16 (&acc)[MTW][NTW]) const
     {
-        constexpr int NT_ = MTW * NTW, NR = 3 * (MTW + NTW), NM = 6 * NT_;
+        constexpr int NT_ = MTW * NTW, NM = 6 * NT_;
         if constexpr (M < NM) {
-            constexpr int P = M / NT_, T = M % NT_, I = T / NTW, J = T % NTW;
+            // small tiles: product-major (every MFMA of a round goes to another accumulator). Tiles of three and more m-tiles per wave:
+            // m-tile-major, so that an activation fragment is dead after its 6 NTW MFMAs and the next stage's copy can take its
+            // registers (both stages' fragments live at once are 168 registers beside 192 of accumulators: hipcc spilled inside the loop)
+            constexpr int P = ROLL ? (M % (6 * NTW)) / NTW : M / NT_, I = ROLL ? M / (6 * NTW) : (M % NT_) / NTW, J = M % NTW;
             // products in mfma3_lo / mfma3_hi order: (w2, a0) (w0, a2) (w1, a1) | (w1, a0) (w0, a1) (w0, a0)
             constexpr int WI = P == 0 ? 2 : P == 1 ? 0 : P == 2 ? 1 : P == 3 ? 1 : 0;
             constexpr int AI = P == 0 ? 0 : P == 1 ? 2 : P == 2 ? 1 : P == 3 ? 0 : P == 4 ? 1 : 0;
             acc[I][J] = mfma_bf(cur[MTW + J][WI], cur[I][AI], acc[I][J]);
-            if constexpr (M < NR) {
-                constexpr int F = M / 3, TERM = M % 3;
+            constexpr int RF = read_frag(M);          // 3 fragment + term of the next stage's LDS read behind this MFMA, or -1
+            if constexpr (RF >= 0) {
+                constexpr int F = RF / 3, TERM = RF % 3;
                 nxt[F][TERM] = *reinterpret_cast<const float4*>((F < MTW ? fa + (F * 3 + TERM) * 256 : fb + ((F - MTW) * 3 + TERM) * 256));
             }
             // request j goes behind MFMA (j NM) / LPS + 1 in waves 0 and 2, half a spacing later in waves 1 and 3: the four waves run in
@@ -1073,24 +1092,33 @@ struct SplitRing {
         Frag f0, f1;
         read_frags(fa0, fb0, 0, f0);
         int slot = 0, st = 0;
+#if DS_SPLIT_PIPED == 3
+        // every stage through the same pinned sequence -- the last one reads a "next stage" nobody uses: a separate tail of plain MFMAs
+        // made hipcc keep the 256 x 192 tile's accumulators in two places and spill inside the loop
+        const int n1 = nstages;
+#else
         const int n1 = nstages - 1;                 // iterations with a successor stage, two per trip (the register sets swap roles)
+#endif
         for (int p = 0; p < (n1 >> 1); ++p) {
             piped(st, slot, nstages, fa0, fb0, f0, f1, acc);
             ++st; slot = slot + 1 == NSLOT ? 0 : slot + 1;
             piped(st, slot, nstages, fa0, fb0, f1, f0, acc);
             ++st; slot = slot + 1 == NSLOT ? 0 : slot + 1;
         }
+#if DS_SPLIT_PIPED == 3
+        if (n1 & 1) piped(st, slot, nstages, fa0, fb0, f0, f1, acc);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // (the filler requests and reads of the last iterations)
+#else
         if (n1 & 1) {
             piped(st, slot, nstages, fa0, fb0, f0, f1, acc);
             mfma_frags(f1, acc);
         } else mfma_frags(f0, acc);
-#if DS_SPLIT_PIPED == 3
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the filler requests of the last iterations)
 #endif
     }
     __device__ __forceinline__ void run(int nstages, const float* fa0, const float* fb0, floatx16 (&acc)[MTW][NTW]) const
     {
 #if DS_SPLIT_PIPED
+        if (DS_RING_BISECT == 4) return;
         run_piped(nstages, fa0, fb0, acc);
 #else
         run_simple(nstages, fa0, fb0, acc);
@@ -1123,6 +1151,9 @@ __global__ __launch_bounds__(256, (SplitRing<MTW, NTW, 2, 2, DS_SPLIT_LSTM_SLOTS
     const bool has_x = C.ax != nullptr, has_h = C.ah != nullptr;
     const int KS = (has_x ? 16 : 0) + (has_h ? 16 : 0);       // k-steps: x rows first, then h rows (TF kernel order)
     const int nstages = KS / R::KGS;
+#if DS_RING_CLOCK
+    const unsigned long long k0 = __builtin_amdgcn_s_memtime();
+#endif
     R rg;
     rg.init(ring, wave, lane, reinterpret_cast<const char*>(has_x ? C.ax : C.ah), reinterpret_cast<const char*>(has_h ? C.ah : C.ax),
             has_x ? 16 : 0, SPLIT_MT_BYTES, mb * R::FRA, mtiles, reinterpret_cast<const char*>(C.Bp), C.kg_stride, ng * R::FRB);
@@ -1161,7 +1192,13 @@ __global__ __launch_bounds__(256, (SplitRing<MTW, NTW, 2, 2, DS_SPLIT_LSTM_SLOTS
             asm volatile("" : "+v"(cp[i][j].x), "+v"(cp[i][j].y), "+v"(cp[i][j].z), "+v"(cp[i][j].w));
             asm volatile("" : "+v"(acc[i][j]));
         }
+#if DS_RING_CLOCK
+    const unsigned long long k1 = __builtin_amdgcn_s_memtime();
+#endif
     rg.run(nstages, ring + (mi * MTW * 3) * 256 + lane4, ring + (3 * R::FRA + nj * NTW * 3) * 256 + lane4, acc);
+#if DS_RING_CLOCK
+    const unsigned long long k2 = __builtin_amdgcn_s_memtime();
+#endif
 
     // ---- gates (fp32), new state; c fragment-major fp32, h fragment-major in three terms (8 bytes per lane and term), optional
     // row-major fp32 h for the joint model
@@ -1190,6 +1227,14 @@ __global__ __launch_bounds__(256, (SplitRing<MTW, NTW, 2, 2, DS_SPLIT_LSTM_SLOTS
             }
         }
     }
+#if DS_RING_CLOCK
+    const unsigned long long k3 = __builtin_amdgcn_s_memtime();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned long long k4 = __builtin_amdgcn_s_memtime();
+    if ((blockIdx.x == 0 || blockIdx.x == gridDim.x - 1 || blockIdx.x == 77) && threadIdx.x == 0 && C.t == 8)
+        printf("CELL block %d of %d cell %d ksteps %d: cycles init %d loop %d gates+stores issued %d stores done %d\n", (int)blockIdx.x, (int)gridDim.x, ci, KS,
+               (int)(k1 - k0), (int)(k2 - k1), (int)(k3 - k2), (int)(k4 - k3));
+#endif
 }
 
 hipError_t launch_lstm_cells_split(int tile, const LstmLaunch& L, hipStream_t s)
@@ -1243,27 +1288,35 @@ __global__ __launch_bounds__(256) void pack_joint_split_kernel(const SplitDense 
 
 // Workgroup tile = (32 WM MTW) rows x (32 WN NTW) columns; the launcher picks it by forward size.
 template <int MTW, int NTW, int WM, int WN>
-__global__ __launch_bounds__(256, (SplitRing<MTW, NTW, WM, WN, DS_SPLIT_DENSE_SLOTS>::LDS_BYTES > 80 * 1024) ? 1 : 2) void dense_split_kernel(const SplitDense d)
+struct DenseRing {           // (the 256 x 192 tile's stage is 42 KiB: three slots)
+    typedef SplitRing<MTW, NTW, WM, WN, (MTW * NTW > 4 ? 3 : DS_SPLIT_DENSE_SLOTS)> R;
+};
+template <int MTW, int NTW, int WM, int WN>
+__global__ __launch_bounds__(256, (DenseRing<MTW, NTW, WM, WN>::R::LDS_BYTES > 80 * 1024) ? 1 : 2) void dense_split_kernel(const SplitDense d)
 {
-    typedef SplitRing<MTW, NTW, WM, WN, DS_SPLIT_DENSE_SLOTS> R;
+    typedef typename DenseRing<MTW, NTW, WM, WN>::R R;
     extern __shared__ __attribute__((aligned(16))) float ring[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int mi = wave % WM, nj = wave / WM;
     const int mblocks = (d.mtiles + R::FRA - 1) / R::FRA;
     const int nblocks = (d.ntiles + R::FRB - 1) / R::FRB;
-    const int total = mblocks * nblocks;
+    const int tiles = mblocks * nblocks, total = tiles * d.splits;      // logical workgroup = (K range, n-block, m-block), m fastest
     // XCD-aware order (workgroup b runs on XCD b % 8): every XCD takes a contiguous run of logical tiles; the m-blocks of one weight
     // panel are neighbours, so a panel streams into one L2 once
     // (workgroup b runs on XCD b % 8; XCD x takes total / 8 tiles, the first total % 8 XCDs one more; PMC: with the m-blocks of a panel on
     // different XCDs the 128 x 96 launch fetched 913 MB from the memory side for 218 MB of weights)
     const int bx = blockIdx.x & 7, bq = blockIdx.x >> 3, per = total >> 3, rem8 = total & 7;
     const int b = bx * per + min(bx, rem8) + bq;
-    const int nb = b / mblocks, mb = b - nb * mblocks;
+    const int ks = b / tiles, bt = b - ks * tiles;
+    const int nb = bt / mblocks, mb = bt - nb * mblocks;
+    const int k0 = (int)((long)ks * d.ksteps / d.splits), k1 = (int)((long)(ks + 1) * d.ksteps / d.splits);
     const int half = lane >> 5, r31 = lane & 31;
     const unsigned lane4 = (unsigned)lane * 4;
-    const int nstages = d.ksteps / R::KGS;          // (ksteps is even wherever KGS = 2 is instantiated: checked by the launcher)
+    const int nstages = (k1 - k0) / R::KGS;         // (ksteps is even wherever KGS = 2 is instantiated: checked by the launcher)
     R rg;
-    rg.init(ring, wave, lane, d.A, d.A, d.ksteps, (long)d.ksteps * SPLIT_KSTEP_BYTES, mb * R::FRA, d.mtiles, d.Bp, d.kg_stride, min(nb * R::FRB, d.ntiles_alloc - R::FRB));
+    rg.init(ring, wave, lane, d.A + (size_t)k0 * SPLIT_KSTEP_BYTES, d.A + (size_t)k0 * SPLIT_KSTEP_BYTES, nstages, (long)d.ksteps * SPLIT_KSTEP_BYTES, mb * R::FRA,
+            d.mtiles, d.Bp + (size_t)k0 * SPLIT_KSTEP_BYTES, d.kg_stride, min(nb * R::FRB, d.ntiles_alloc - R::FRB));
+    float* const Cp = d.C + (size_t)ks * d.part_stride;
     rg.prologue(nstages);
     floatx16 acc[MTW][NTW];
 #pragma unroll
@@ -1293,7 +1346,7 @@ __global__ __launch_bounds__(256, (SplitRing<MTW, NTW, WM, WN, DS_SPLIT_DENSE_SL
                 const int col = ntile * 32 + 8 * g + 4 * half;
                 if (col < d.N) {
                     const v4f o = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
-                    *(__attribute__((address_space(1))) v4f*)(d.C + (size_t)row * d.N + col) = o;
+                    *(__attribute__((address_space(1))) v4f*)(Cp + (size_t)row * d.N + col) = o;
                 }
             }
         }
@@ -1308,12 +1361,20 @@ hipError_t launch_dense_split(const SplitDense& d, hipStream_t s)
     hipLaunchKernelGGL(pack_joint_split_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, d);
     // tile by forward size (measured on one box, us per forward at 512 / 2,048 sites; the native fp32 GEMM: 292 / 1,148):
     // 128 x 96 (waves 4 x 1): 245 / 769 -- 252 workgroups at 512 sites fill the 256 CUs; 128 x 128 (waves 2 x 2): 253 / 725
-    if (d.n < 1024) {
-        typedef SplitRing<1, 3, 4, 1, DS_SPLIT_DENSE_SLOTS> R;
+    if (d.splits < 1 || d.splits > d.ksteps) return hipErrorInvalidValue;
+    if (d.splits > 1) {
+        // 256 x 192 (waves 2 x 2, each 128 x 96), K in d.splits ranges: half the operand bytes per MFMA of the 128 x 96 tile; the partial
+        // products go to d.C + range * d.part_stride and their reader adds them up (launch_head)
+        typedef DenseRing<4, 3, 2, 2>::R R;
+        if (d.ntiles_alloc < R::FRB) return hipErrorInvalidValue;
+        const int mblocks = (d.mtiles + R::FRA - 1) / R::FRA, nblocks = (d.ntiles + R::FRB - 1) / R::FRB;
+        hipLaunchKernelGGL((dense_split_kernel<4, 3, 2, 2>), dim3(mblocks * nblocks * d.splits), dim3(256), R::LDS_BYTES, s, d);
+    } else if (d.n < 1024) {
+        typedef DenseRing<1, 3, 4, 1>::R R;
         const int mblocks = (d.mtiles + R::FRA - 1) / R::FRA, nblocks = (d.ntiles + R::FRB - 1) / R::FRB;
         hipLaunchKernelGGL((dense_split_kernel<1, 3, 4, 1>), dim3(mblocks * nblocks), dim3(256), R::LDS_BYTES, s, d);
     } else {
-        typedef SplitRing<2, 2, 2, 2, DS_SPLIT_DENSE_SLOTS> R;
+        typedef DenseRing<2, 2, 2, 2>::R R;
         const int mblocks = (d.mtiles + R::FRA - 1) / R::FRA, nblocks = (d.ntiles + R::FRB - 1) / R::FRB;
         hipLaunchKernelGGL((dense_split_kernel<2, 2, 2, 2>), dim3(mblocks * nblocks), dim3(256), R::LDS_BYTES, s, d);
     }
@@ -1334,7 +1395,7 @@ static bool split_chain_ok(const FusedChain& c)
 
 hipError_t configure_split_kernels()
 {
-    const void* fns[9] = {(const void*)stem23_split_kernel, (const void*)inception_fused_split_kernel<1>, (const void*)inception_fused_split_kernel<2>,
+    const void* fns[10] = {(const void*)dense_split_kernel<4, 3, 2, 2>, (const void*)stem23_split_kernel, (const void*)inception_fused_split_kernel<1>, (const void*)inception_fused_split_kernel<2>,
                           (const void*)inception_fused_split_kernel<3>, (const void*)lstm_cell_split_kernel<1, 1>,
                           (const void*)lstm_cell_split_kernel<1, 2>, (const void*)lstm_cell_split_kernel<2, 2>,
                           (const void*)dense_split_kernel<2, 2, 2, 2>, (const void*)dense_split_kernel<1, 3, 4, 1>};
