@@ -612,11 +612,11 @@ int alloc_workspace(ds_handle* h)
     return rc;
 }
 
-// workgroup tile of the split-operand BiLSTM cells by sites per forward (measured on MI355X). The cells are
-// bound by operand delivery. Stand-alone the 64 x 64 tile is the fastest below 2,048 sites (333 against 474 us per 512-site step:
-// 768 small workgroups hide latency), but in the PIPELINED step -- where the cells share the CUs' operand path with the other
-// forwards' kernels -- the 128 x 128 tile's halved bytes per MFMA win: 629 k against 610 k sites/s (three-step), 831 k against 809 k
-// (folded) at 512 sites, 8 slots. Tiny forwards keep the small tile (too few 128 x 128 workgroups to fill anything).
+// workgroup tile of the split-operand BiLSTM cells by sites per forward (measured on MI355X). Stand-alone the
+// 64 x 64 tile is the fastest below 2,048 sites (333 against 420 us per 512-site step: 768 small workgroups hide latency), but in the
+// PIPELINED step -- where the cells share the CUs and the power budget with the other forwards' kernels -- the 128 x 128 tile's halved
+// bytes per MFMA win: 647 k against 623 k sites/s (three-step), 849 k against 802 k (folded) at 512 sites, 8 slots. Tiny forwards keep
+// the small tile (too few 128 x 128 workgroups to fill anything).
 #ifndef DS_SPLIT_LSTM_TILE
 #define DS_SPLIT_LSTM_TILE(n) ((n) >= 256 ? 322 : 311)
 #endif
@@ -1005,9 +1005,13 @@ int build_plan(ds_handle* h, int n, Plan* plan)
         d.A = h->cur->jsplit; d.Bp = reinterpret_cast<const char*>(h->fc1.Bps); d.C = h->cur->fc1o;
         d.n = n; d.N = h->J; d.mtiles = (n + 31) / 32; d.ntiles = (h->J + 31) / 32; d.ntiles_alloc = d.ntiles;
         d.ksteps = h->J / 16; d.kg_stride = (h->J + 63) / 64 * 64 / 16;
-        // forwards below 1,024 sites: the 256 x 192 tile with K in ranges (at 512 sites 64 tiles x 4 ranges fill the 256 CUs)
+        // the 256 x 192 tile, K in as many ranges (<= DS_SPLIT_DENSE_PARTS) as it takes to put ~256 workgroups on the 256 CUs: 4 at 512
+        // sites, 2 at 1,024, 1 from 2,048 (us per forward against the 128 x 96 / 128 x 128 tiles of mid-round with the same piped loop:
+        // 168 / 177 at 512 sites, 326 / 405 at 1,024, 633 / 683 at 2,048, 1,262 / 1,376 at 4,096). DS_SPLIT_DENSE_WIDE=0: the 128 x 96 tile
         static const bool wide = !getenv("DS_SPLIT_DENSE_WIDE") || atoi(getenv("DS_SPLIT_DENSE_WIDE")) != 0;
-        d.splits = (wide && n < 1024 && d.ntiles >= 6) ? DS_SPLIT_DENSE_PARTS : 1;
+        d.wide = wide && d.ntiles >= 6;
+        d.splits = 1;
+        if (d.wide) d.splits = std::max(1, std::min(DS_SPLIT_DENSE_PARTS, 256 / (((d.mtiles + 7) / 8) * ((d.ntiles + 5) / 6))));
         d.part_stride = (size_t)h->B * h->J;
         plan->fc1_parts = d.splits;
         op.flops = 2.0 * n * (double)h->J * h->J;

@@ -155,8 +155,9 @@ struct SplitDense {
     const char* Bp;        // [ntiles_alloc][kg_stride][3][1 KiB]
     float* C;              // [splits][n][N] fp32: partial sums over `splits` ranges of K (1: the product itself)
     int n, N, mtiles, ntiles, ntiles_alloc, ksteps, kg_stride;
-    int splits;            // > 1: the 256 x 192 tile, K in `splits` ranges; the reader sums the partial products in order (launch_head)
+    int splits;            // K in `splits` ranges (256 x 192 tile only); the reader sums the partial products in order (launch_head)
     size_t part_stride;    // floats between two partial products
+    bool wide;             // the 256 x 192 tile (K in `splits` ranges); false: 128 x 96, one range
 };
 hipError_t launch_dense_split(const SplitDense& d, hipStream_t s);
 

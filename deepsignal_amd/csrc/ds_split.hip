@@ -65,8 +65,8 @@ __device__ __forceinline__ floatx16 mfma3_hi(const float4 (&w)[3], float4 a0, fl
 //       64-channel intermediate goes to LDS as terms as well (T2); its last 1x1 accumulates on top of the stem accumulators.
 // LDS (bytes): staged chunks 2 x rows x 208 (later the fp32 b1|b2 output tile) | T2 rows x 400 (raw chunks during P1) | T1
 // (spt (W + 4) + 5) x 592: 143 - 147 KB for 96-row tiles, one workgroup per CU. Every row stride is an odd number of 16-byte slots.
-// What bounds it: operand delivery in P1 (24 KB of weight fragments + 6 KB of rows per 16-channel step and CU, ~16 B/clk), the
-// dependent phases of one workgroup per CU in P2.
+// What bounds it: P1's staging work on the CU itself (26 k of its 31.5 k cycles per module remain with every global load removed;
+// 18.4 k are MFMA), the dependent phases of one workgroup per CU in P2.
 constexpr int S_LDP = 208;      // staged chunk row: 6 x 32 B + 16
 constexpr int S_LD1 = 592;      // T1 row: 3 terms x 96 channels x 2 B + 16
 constexpr int S_LD2 = 400;      // T2 row: 3 terms x 64 channels x 2 B + 16
@@ -548,8 +548,8 @@ __global__ __launch_bounds__(512, 2) void inception_fused_split_kernel(const Fus
 // row on either side of every site = conv3's SAME padding), conv3 with wave w = output channels [32 w, 32 w + 32) of all three
 // m-tiles and its weights streamed global -> VGPR -- with the input rows split into terms while they are staged and conv2's rows
 // split in its epilogue. LDS: input terms 96 x 400 B + conv2 terms (spt (W + 2) + 3) x 784 B = 117 KB, one workgroup per CU.
-// Per tile conv3 streams 576 KB of weight fragments (24 k-steps x 3 terms x 8 n-tiles) for 27.6 k cycles of MFMA per SIMD: bound by
-// operand delivery.
+// Per tile conv3 streams 576 KB of weight fragments (24 k-steps x 3 terms x 8 n-tiles) for 27.6 k cycles of MFMA per SIMD (matrix
+// pipe 0.51 busy).
 constexpr int S23_SX = 400;      // input term row: 3 x 64 channels x 2 B + 16
 constexpr int S23_ST = 784;      // conv2 term row: 3 x 128 channels x 2 B + 16 (49 x 16 B)
 size_t stem23_split_lds_bytes(int W, int spt) { return (size_t)96 * S23_SX + (size_t)(spt * (W + 2) + 3) * S23_ST + 96 * 4; }
@@ -717,9 +717,10 @@ hipError_t launch_stem23_split(const Stem23Args& a, hipStream_t s)
 //     [m-tile of 32 rows][k-step of 16][term][64 lanes][8 bf16]      (lane (r, half) holds k = 16 s + 8 half .. + 7 of row 32 m + r),
 // which is what a cell's epilogue writes for h (split once, where it is produced) and what pack_joint_split_kernel writes for the
 // joint row; the weights are pack_b_split's panels [n-tile][k-step][term][64][8].
-// What bounds them is operand delivery (a CU's vector-memory path, ~32 B/clk): the fp32 cell kernel already sits on
-// that limit (197 MB per full diagonal in 22.7 us), so the split cells use the 128 x 128 tile -- 0.25 KiB per MFMA, where the
-// fp32 64 x 64 tile needs 0.25 KiB per fp32 MFMA of 1/12 the work.
+// One workgroup per CU means one wave per SIMD: what bounded these kernels was the wave's own instruction stream (hipcc's
+// read -> wait -> MFMA schedule, the requests' issue time in front of the MFMAs), not what a CU can take in -- SplitRing::run_piped
+// and DESIGN.md section 11. The split cells use the 128 x 128 tile (0.25 KiB per MFMA): slower alone than 64 x 64, faster in the
+// pipelined step, which rewards bytes.
 constexpr int SPLIT_KSTEP_BYTES = 3 * 1024;               // the three term fragments of one k-step
 constexpr int SPLIT_MT_BYTES = 16 * SPLIT_KSTEP_BYTES;    // one m-tile of a split h buffer (256 units = 16 k-steps)
 
@@ -1359,24 +1360,19 @@ hipError_t launch_dense_split(const SplitDense& d, hipStream_t s)
     if (d.ksteps <= 0 || (d.N & 3) || d.ntiles_alloc < 4) return hipErrorInvalidValue;
     const long total = (long)d.mtiles * 32 * d.ksteps * 2;
     hipLaunchKernelGGL(pack_joint_split_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, d);
-    // tile by forward size (measured on one box, us per forward at 512 / 2,048 sites; the native fp32 GEMM: 292 / 1,148):
-    // 128 x 96 (waves 4 x 1): 245 / 769 -- 252 workgroups at 512 sites fill the 256 CUs; 128 x 128 (waves 2 x 2): 253 / 725
-    if (d.splits < 1 || d.splits > d.ksteps) return hipErrorInvalidValue;
-    if (d.splits > 1) {
+    if (d.splits < 1 || d.splits > d.ksteps || (!d.wide && d.splits != 1)) return hipErrorInvalidValue;
+    if (d.wide) {
         // 256 x 192 (waves 2 x 2, each 128 x 96), K in d.splits ranges: half the operand bytes per MFMA of the 128 x 96 tile; the partial
         // products go to d.C + range * d.part_stride and their reader adds them up (launch_head)
         typedef DenseRing<4, 3, 2, 2>::R R;
         if (d.ntiles_alloc < R::FRB) return hipErrorInvalidValue;
         const int mblocks = (d.mtiles + R::FRA - 1) / R::FRA, nblocks = (d.ntiles + R::FRB - 1) / R::FRB;
         hipLaunchKernelGGL((dense_split_kernel<4, 3, 2, 2>), dim3(mblocks * nblocks * d.splits), dim3(256), R::LDS_BYTES, s, d);
-    } else if (d.n < 1024) {
+    } else {
+        // 128 x 96 (waves 4 x 1): 252 workgroups at 512 sites (mid-round's tile; narrow output widths)
         typedef DenseRing<1, 3, 4, 1>::R R;
         const int mblocks = (d.mtiles + R::FRA - 1) / R::FRA, nblocks = (d.ntiles + R::FRB - 1) / R::FRB;
         hipLaunchKernelGGL((dense_split_kernel<1, 3, 4, 1>), dim3(mblocks * nblocks), dim3(256), R::LDS_BYTES, s, d);
-    } else {
-        typedef DenseRing<2, 2, 2, 2>::R R;
-        const int mblocks = (d.mtiles + R::FRA - 1) / R::FRA, nblocks = (d.ntiles + R::FRB - 1) / R::FRB;
-        hipLaunchKernelGGL((dense_split_kernel<2, 2, 2, 2>), dim3(mblocks * nblocks), dim3(256), R::LDS_BYTES, s, d);
     }
     return hipGetLastError();
 }
@@ -1395,10 +1391,10 @@ static bool split_chain_ok(const FusedChain& c)
 
 hipError_t configure_split_kernels()
 {
-    const void* fns[10] = {(const void*)dense_split_kernel<4, 3, 2, 2>, (const void*)stem23_split_kernel, (const void*)inception_fused_split_kernel<1>, (const void*)inception_fused_split_kernel<2>,
+    const void* fns[9] = {(const void*)dense_split_kernel<4, 3, 2, 2>, (const void*)stem23_split_kernel, (const void*)inception_fused_split_kernel<1>, (const void*)inception_fused_split_kernel<2>,
                           (const void*)inception_fused_split_kernel<3>, (const void*)lstm_cell_split_kernel<1, 1>,
                           (const void*)lstm_cell_split_kernel<1, 2>, (const void*)lstm_cell_split_kernel<2, 2>,
-                          (const void*)dense_split_kernel<2, 2, 2, 2>, (const void*)dense_split_kernel<1, 3, 4, 1>};
+                          (const void*)dense_split_kernel<1, 3, 4, 1>};
     for (const void* f : fns) {
         const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;

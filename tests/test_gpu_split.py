@@ -99,6 +99,26 @@ def test_split_lstm_tile_shapes_give_the_same_bits(small_weights):
         assert np.array_equal(a, outs[0][0]) and np.array_equal(p, outs[0][1])
 
 
+def test_split_dense_in_ranges_of_k_at_every_forward_size(small_weights):
+    """dense(J, J) of the three-step joint model runs a 256 x 192 tile with K in 4 / 2 / 1 ranges by forward size (64 / 128 / 256 tiles);
+    head_kernel adds the partial products while it reads its row and the fc1 tap adds them on the host. Every size (ragged m-blocks,
+    one m-tile, two ranges, one range) against the native fp32 engine: the dense is linear in its inputs, so the fp32 bars hold."""
+    from deepsignal_amd.engine import Engine
+    n_max = 2048
+    feats = synth.synthetic_features(n_max, seed=4107)
+    ref = _engine(small_weights, max_batch=n_max, slots=1, precision="fp32", fold_fc=False)
+    eng = _engine(small_weights, max_batch=n_max, slots=1, precision="bf16x3", fold_fc=False)
+    for n in (2048, 1024, 1100, 513, 300, 32, 5):
+        args = [feats[k][:n] for k in KEYS]
+        a0, p0 = ref.run(*args)
+        a1, p1 = eng.run(*args)
+        f0 = ref.intermediate("fc1", (n, 6032))
+        f1 = eng.intermediate("fc1", (n, 6032))
+        assert np.abs(f1 - f0).max() <= 2e-5 * max(1.0, float(np.abs(f0).max())), (n, float(np.abs(f1 - f0).max()))
+        assert np.abs(a1 - a0).max() <= 2e-5 and np.array_equal(p0, p1), (n, float(np.abs(a1 - a0).max()))
+    ref.close(); eng.close()
+
+
 def test_split_mode_refuses_what_it_does_not_implement(small_weights):
     from deepsignal_amd.engine import Engine
     with pytest.raises(RuntimeError, match="BF16X3"):
