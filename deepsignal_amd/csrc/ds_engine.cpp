@@ -1005,13 +1005,15 @@ int build_plan(ds_handle* h, int n, Plan* plan)
         d.A = h->cur->jsplit; d.Bp = reinterpret_cast<const char*>(h->fc1.Bps); d.C = h->cur->fc1o;
         d.n = n; d.N = h->J; d.mtiles = (n + 31) / 32; d.ntiles = (h->J + 31) / 32; d.ntiles_alloc = d.ntiles;
         d.ksteps = h->J / 16; d.kg_stride = (h->J + 63) / 64 * 64 / 16;
-        // the 256 x 192 tile, K in as many ranges (<= DS_SPLIT_DENSE_PARTS) as it takes to put ~256 workgroups on the 256 CUs: 4 at 512
-        // sites, 2 at 1,024, 1 from 2,048 (us per forward against the 128 x 96 / 128 x 128 tiles of mid-round with the same piped loop:
+        // the 256 x 192 tile, K in as many ranges (<= DS_SPLIT_DENSE_PARTS) as it takes to put ~256 workgroups on the 256 CUs: 4 for engines
+        // of up to 512 sites per forward, 2 up to 1,024, 1 from 2,048 (us per forward against the 128 x 96 / 128 x 128 tiles of mid-round with the same piped loop:
         // 168 / 177 at 512 sites, 326 / 405 at 1,024, 633 / 683 at 2,048, 1,262 / 1,376 at 4,096). DS_SPLIT_DENSE_WIDE=0: the 128 x 96 tile
         static const bool wide = !getenv("DS_SPLIT_DENSE_WIDE") || atoi(getenv("DS_SPLIT_DENSE_WIDE")) != 0;
         d.wide = wide && d.ntiles >= 6;
         d.splits = 1;
-        if (d.wide) d.splits = std::max(1, std::min(DS_SPLIT_DENSE_PARTS, 256 / (((d.mtiles + 7) / 8) * ((d.ntiles + 5) / 6))));
+        // (the ranges follow the ENGINE's forward size, not this forward's: a site's bits then do not depend on how many sites share its
+        // forward -- ragged tails run with few workgroups instead; always 4 ranges cost 8 - 12 % from 1,024 sites)
+        if (d.wide) d.splits = std::max(1, std::min(DS_SPLIT_DENSE_PARTS, 256 / ((((h->B + 31) / 32 + 7) / 8) * ((d.ntiles + 5) / 6))));
         d.part_stride = (size_t)h->B * h->J;
         plan->fc1_parts = d.splits;
         op.flops = 2.0 * n * (double)h->J * h->J;

@@ -100,23 +100,28 @@ def test_split_lstm_tile_shapes_give_the_same_bits(small_weights):
 
 
 def test_split_dense_in_ranges_of_k_at_every_forward_size(small_weights):
-    """dense(J, J) of the three-step joint model runs a 256 x 192 tile with K in 4 / 2 / 1 ranges by forward size (64 / 128 / 256 tiles);
-    head_kernel adds the partial products while it reads its row and the fc1 tap adds them on the host. Every size (ragged m-blocks,
-    one m-tile, two ranges, one range) against the native fp32 engine: the dense is linear in its inputs, so the fp32 bars hold."""
-    from deepsignal_amd.engine import Engine
-    n_max = 2048
-    feats = synth.synthetic_features(n_max, seed=4107)
-    ref = _engine(small_weights, max_batch=n_max, slots=1, precision="fp32", fold_fc=False)
-    eng = _engine(small_weights, max_batch=n_max, slots=1, precision="bf16x3", fold_fc=False)
-    for n in (2048, 1024, 1100, 513, 300, 32, 5):
-        args = [feats[k][:n] for k in KEYS]
-        a0, p0 = ref.run(*args)
-        a1, p1 = eng.run(*args)
-        f0 = ref.intermediate("fc1", (n, 6032))
-        f1 = eng.intermediate("fc1", (n, 6032))
-        assert np.abs(f1 - f0).max() <= 2e-5 * max(1.0, float(np.abs(f0).max())), (n, float(np.abs(f1 - f0).max()))
-        assert np.abs(a1 - a0).max() <= 2e-5 and np.array_equal(p0, p1), (n, float(np.abs(a1 - a0).max()))
-    ref.close(); eng.close()
+    """dense(J, J) of the three-step joint model runs a 256 x 192 tile with K in 4 / 2 / 1 ranges by the ENGINE's forward size (64 / 128 /
+    256 tiles); head_kernel adds the partial products while it reads its row and the fc1 tap adds them on the host. Every size (ragged
+    m-blocks, one m-tile) against the native fp32 engine -- the dense is linear in its inputs, so the fp32 bars hold -- and a site's
+    bits do not depend on how many sites share its forward (the ranges follow max_batch, not n)."""
+    feats = synth.synthetic_features(2048, seed=4107)
+    for n_max, sizes in ((2048, (2048, 1100, 33)), (1024, (1024, 513, 300)), (512, (512, 300, 32, 5))):
+        ref = _engine(small_weights, max_batch=n_max, slots=1, precision="fp32", fold_fc=False)
+        eng = _engine(small_weights, max_batch=n_max, slots=1, precision="bf16x3", fold_fc=False)
+        full = None
+        for n in sizes:
+            args = [feats[k][:n] for k in KEYS]
+            a0, p0 = ref.run(*args)
+            a1, p1 = eng.run(*args)
+            f0 = ref.intermediate("fc1", (n, 6032))
+            f1 = eng.intermediate("fc1", (n, 6032))
+            assert np.abs(f1 - f0).max() <= 2e-5 * max(1.0, float(np.abs(f0).max())), (n_max, n, float(np.abs(f1 - f0).max()))
+            assert np.abs(a1 - a0).max() <= 2e-5 and np.array_equal(p0, p1), (n_max, n, float(np.abs(a1 - a0).max()))
+            if full is None:
+                full = (a1, f1)
+            else:
+                assert np.array_equal(a1, full[0][:n]) and np.array_equal(f1, full[1][:n]), (n_max, n)
+        ref.close(); eng.close()
 
 
 def test_split_mode_refuses_what_it_does_not_implement(small_weights):

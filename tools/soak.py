@@ -2,7 +2,7 @@
 every result compared bit for bit with a reference pass over the same sites. Exercises the slot rotation, the bounded
 plan cache (hundreds of distinct sizes), graph capture for recurring sizes and the ragged-tail kernels.
 
-usage: python tools/soak.py [seconds] [precision] [max_batch] [lstm_tiling]
+usage: python tools/soak.py [seconds] [precision] [max_batch] [lstm_tiling] [threestep]
 (with an lstm_tiling override the reference pass comes from a default engine: every tiling must give its bits)"""
 import os, sys, time
 sys.path.insert(0, os.getcwd())
@@ -17,13 +17,14 @@ POOL = max(8192, 4 * B)
 keys = ("kmer", "means", "stds", "sanums", "signals")
 feats = synth.synthetic_features(POOL, seed=77)
 tiling = sys.argv[4] if len(sys.argv) > 4 else "auto"
+extra = {"fold_fc": False} if len(sys.argv) > 5 and sys.argv[5] == "threestep" else {}      # the reference graph's three-step joint model
 w = W.random_weights(seed=5, lstm_bias_std=0.1)
 if tiling != "auto":
-    ref_eng = Engine(max_batch=B, precision=prec)
+    ref_eng = Engine(max_batch=B, precision=prec, **extra)
     ref_eng.load_weights(w)
     ref_act, ref_pred = ref_eng.run(*(feats[k] for k in keys))
     ref_eng.close()
-eng = Engine(max_batch=B, precision=prec, lstm_tiling=tiling)
+eng = Engine(max_batch=B, precision=prec, lstm_tiling=tiling, **extra)
 eng.load_weights(w)
 if tiling == "auto":
     ref_act, ref_pred = eng.run(*(feats[k] for k in keys))
