@@ -176,6 +176,9 @@ def pmc_mfma_busy(kernel_name, pattern="r[0-9][0-9]_pmc_mfma_util.json"):
         for name, v in rec["kernels"].items():
             if _norm_kernel(name) == _norm_kernel(kernel_name):
                 return {"mfma_busy_pmc": v["mfma_busy_frac_at_inkernel_clock"],
+                        # GRBM_GUI_ACTIVE / duration: the clock the chip ran THIS kernel at -- it lowers the clock under matrix load
+                        # (2.40 GHz idle, 1.92 GHz with every CU on bf16 MFMAs: tools/attic/clock_probe.hip), and `peak` is quoted at 2.4
+                        "in_kernel_clock_ghz": v.get("gui_active_over_duration_ghz"),
                         "mfma_busy_source": "committed constant, NOT measured in this run: profiles/%s (%s)"
                                             % (os.path.basename(path), _build_of(rec))}
     except (OSError, ValueError, KeyError, TypeError):
