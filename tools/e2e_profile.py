@@ -49,7 +49,7 @@ for label, sink in (("format + discard", lambda tag, data: None),):
 # submit / wait only (no formatting), same arrays every time
 arrs = tuple(np.concatenate([getattr(it, k) for it in items[:2]])[:512] for k in ("kmer", "means", "stds", "lens", "signals"))
 import collections
-for depth in (8,):
+for depth in (min(8, eng.slots),):      # (engines of large forwards have four slots)
     q = collections.deque(); t0 = time.perf_counter()
     for i in range(320):
         if len(q) >= depth: eng.wait(q.popleft())
