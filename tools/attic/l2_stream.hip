@@ -32,7 +32,7 @@ __global__ __launch_bounds__(256) void walk(const uint4* __restrict__ src, int f
 #pragma unroll
             for (int u = 0; u < INFLIGHT; ++u) v[u] = base[(size_t)((f0 + u) * 4 + wave) * 64];
 #pragma unroll
-            for (int u = 0; u < INFLIGHT; ++u) acc += v[u].x ^ v[u].w;
+            for (int u = 0; u < INFLIGHT; ++u) acc += v[u].x ^ v[u].y ^ v[u].z ^ v[u].w;      // (all four words: hipcc narrows the load to the words used)
         }
     } else {
         const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)ring + wave * INFLIGHT * 1024);
