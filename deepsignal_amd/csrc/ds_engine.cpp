@@ -169,6 +169,7 @@ struct ds_handle {
     int B = 512;
     bool is_cnn = true, is_rnn = true, is_base = true;   // model.py:28-29,59-75,89-95
     bool bf16 = false;    // DS_PRECISION_BF16: bf16 conv + FC operands (fp32 accumulate), fp32 BiLSTM
+    bool split_dense_narrow = false;      // DS_TUNE_SPLIT_DENSE_NARROW
     int split_dense_min_n = DS_SPLIT_DENSE_MIN_N;   // sites per forward from which dense(J, J) runs split (below: the native fp32 GEMM)
     bool split = false;   // DS_PRECISION_BF16X3: fp32 activations / weights carried as three bf16 terms through the bf16 matrix pipe
                           // (six products per MAC, fp32 accumulate) in the fused inception chains; everything else as fp32
@@ -1007,9 +1008,8 @@ int build_plan(ds_handle* h, int n, Plan* plan)
         d.ksteps = h->J / 16; d.kg_stride = (h->J + 63) / 64 * 64 / 16;
         // the 256 x 192 tile, K in as many ranges (<= DS_SPLIT_DENSE_PARTS) as it takes to put ~256 workgroups on the 256 CUs: 4 for engines
         // of up to 512 sites per forward, 2 up to 1,024, 1 from 2,048 (us per forward against the 128 x 96 / 128 x 128 tiles of mid-round with the same piped loop:
-        // 168 / 177 at 512 sites, 326 / 405 at 1,024, 633 / 683 at 2,048, 1,262 / 1,376 at 4,096). DS_SPLIT_DENSE_WIDE=0: the 128 x 96 tile
-        static const bool wide = !getenv("DS_SPLIT_DENSE_WIDE") || atoi(getenv("DS_SPLIT_DENSE_WIDE")) != 0;
-        d.wide = wide && d.ntiles >= 6;
+        // 168 / 177 at 512 sites, 326 / 405 at 1,024, 633 / 683 at 2,048, 1,262 / 1,376 at 4,096). DS_TUNE_SPLIT_DENSE_NARROW: the 128 x 96 tile
+        d.wide = !h->split_dense_narrow && d.ntiles >= 6;
         d.splits = 1;
         // (the ranges follow the ENGINE's forward size, not this forward's: a site's bits then do not depend on how many sites share its
         // forward -- ragged tails run with few workgroups instead; always 4 ranges cost 8 - 12 % from 1,024 sites)
@@ -1410,6 +1410,7 @@ static int ds_create_impl(const ds_config* cfg, ds_handle** out)
     if (cfg->reserved[4] > 0) h->fuse_max_spt = cfg->reserved[4];
     if (cfg->reserved[5] > 0) h->fuse_min_tiles = cfg->reserved[5];
     if (cfg->reserved[6] > 0) h->split_dense_min_n = cfg->reserved[6];
+    h->split_dense_narrow = (flags & DS_TUNE_SPLIT_DENSE_NARROW) != 0;
     h->lstm_frag = h->is_rnn && !h->lstm_bf16;
     h->Bp32 = (h->B + 31) / 32 * 32;
     h->JP = (h->J + 31) / 32 * 32;

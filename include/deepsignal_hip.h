@@ -92,6 +92,10 @@ typedef struct ds_config {
    forwards are issued eagerly (no captured graphs): the configuration in which round 4's persistent-BiLSTM experiment faulted
    (DESIGN.md section 9). Results are unchanged (same bits); slower than the default. */
 #define DS_TUNE_SHARED_EVENT_STREAM 32
+/* Timing diagnostic, DS_PRECISION_BF16X3 with the three-step joint model only: dense(J, J) runs its 128 x 96 tile with K in one range
+   instead of the 256 x 192 tile with K in 4 / 2 / 1 ranges (by max_batch) whose partial products the head adds up. Same results within
+   fp32 summation order. */
+#define DS_TUNE_SPLIT_DENSE_NARROW 64
 /* ds_config.reserved[3] */
 #define DS_LSTM_TILING_AUTO 0    /* by forward size */
 #define DS_LSTM_TILING_NARROW 1  /* one 32-column n-tile per wave  */

@@ -121,6 +121,12 @@ def test_split_dense_in_ranges_of_k_at_every_forward_size(small_weights):
                 full = (a1, f1)
             else:
                 assert np.array_equal(a1, full[0][:n]) and np.array_equal(f1, full[1][:n]), (n_max, n)
+        if n_max == 512:      # DS_TUNE_SPLIT_DENSE_NARROW (timing diagnostic): the 128 x 96 tile with K in one range, same bars
+            nar = _engine(small_weights, max_batch=n_max, slots=1, precision="bf16x3", fold_fc=False, split_dense_narrow=True)
+            a2, p2 = nar.run(*[feats[k][:300] for k in KEYS])
+            a0, p0 = ref.run(*[feats[k][:300] for k in KEYS])
+            assert np.abs(a2 - a0).max() <= 2e-5 and np.array_equal(p0, p2)
+            nar.close()
         ref.close(); eng.close()
 
 

@@ -1,5 +1,5 @@
 for round in 1 2; do for w in 0 1; do
-echo "DS_SPLIT_DENSE_WIDE=$w"; DS_SPLIT_DENSE_WIDE=$w python3 tools/kernel_time.py bf16x3 512 10 5 "" fold_fc=false 2>/dev/null | python3 -c "
+echo "wide tile=$w"; python3 tools/kernel_time.py bf16x3 512 10 5 "" fold_fc=false split_dense_narrow=$([ $w = 0 ] && echo true || echo false) 2>/dev/null | python3 -c "
 import json,sys
 d=json.load(sys.stdin)
 print(' '.join('%s=%.1f'%(k.split('<')[0][:24],v['median_us_per_step']) for k,v in d['kernels'].items() if 'dense' in k or 'head' in k))"

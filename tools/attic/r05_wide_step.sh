@@ -1,6 +1,6 @@
 # bf16x3 three-step pipelined rate with the 256 x 192 split-K dense tile on / off (same library, same box)
 for round in 1 2 3; do for w in 0 1; do
-DS_SPLIT_DENSE_WIDE=$w python - $w <<'PY' 2>/dev/null
+python - $w <<'PY' 2>/dev/null
 import json, os, sys, time
 sys.path.insert(0, os.getcwd())
 import torch
@@ -25,7 +25,7 @@ def rate(e, steps=300):
     return round(sorted(r)[2])
 out = []
 for slots in (8, 1):
-    e = Engine(max_batch=B, precision="bf16x3", fold_fc=False, slots=slots); e.load_weights(w)
+    e = Engine(max_batch=B, precision="bf16x3", fold_fc=False, slots=slots, split_dense_narrow=(sys.argv[1] == "0")); e.load_weights(w)
     out.append((slots, rate(e))); e.close()
 print("wide", sys.argv[1], out)
 PY
