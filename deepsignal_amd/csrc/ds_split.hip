@@ -725,8 +725,8 @@ constexpr int SPLIT_KSTEP_BYTES = 3 * 1024;               // the three term frag
 constexpr int SPLIT_MT_BYTES = 16 * SPLIT_KSTEP_BYTES;    // one m-tile of a split h buffer (256 units = 16 k-steps)
 
 #ifndef DS_SPLIT_PIPED
-#define DS_SPLIT_PIPED 3        // SplitRing::run: 0 = one stage at a time (run_simple), 1 / 2 = fragments double-buffered in registers with the
-#endif                          // stage's requests in one burst before / after its MFMAs, 3 = requests spread between the MFMAs (shipped)
+#define DS_SPLIT_PIPED 1        // SplitRing::run: 1 = the register-piped K loop with the pinned instruction order (shipped), 0 = one stage at a
+#endif                          // time (run_simple: the loop of mid-round 5, kept for same-box A/Bs through tools/build_variant.sh)
 #ifndef DS_SPLIT_KGS11
 #define DS_SPLIT_KGS11 1
 #endif
@@ -737,7 +737,7 @@ constexpr int SPLIT_MT_BYTES = 16 * SPLIT_KSTEP_BYTES;    // one m-tile of a spl
 #define DS_RING_SCHED 1
 #endif
 #ifndef DS_RING_BISECT
-#define DS_RING_BISECT 0      // timing experiments only: 1 = no MFMAs, 2 = no LDS-DMA requests, 3 = no barrier, 4 = no K loop at all; (piped loop) no MFMAs and 5 = A requests only, 6 = B requests only, 7 = no LDS reads either
+#define DS_RING_BISECT 0      // timing experiments only (results WRONG): 4 = no K loop at all; with DS_SPLIT_PIPED=0 also 1 = no MFMAs, 2 = no LDS-DMA requests, 3 = no barrier
 #endif
 #ifndef DS_SPLIT_LSTM_SLOTS
 #define DS_SPLIT_LSTM_SLOTS 3
@@ -760,11 +760,8 @@ struct SplitRing {
     static constexpr int LPS = (NF + 3) / 4;                 // LDS-DMA requests per wave and stage (waves >= NF % 4: one fewer if NF % 4)
     static constexpr int STAGE = NF * 256;                   // floats
     // (piped loop: waves with one fragment fewer send a filler request into a pad, so that every wave counts the same vmcnt)
-    static constexpr int PAD_BYTES = (DS_SPLIT_PIPED == 3 && NF % 4 != 0) ? 4096 : 0;
+    static constexpr int PAD_BYTES = (DS_SPLIT_PIPED && NF % 4 != 0) ? 4096 : 0;
     static constexpr size_t LDS_BYTES = (size_t)NSLOT * STAGE * 4 + PAD_BYTES;
-#ifndef DS_RING_STAGGER
-#define DS_RING_STAGGER 0
-#endif
 #ifndef DS_RING_CLOCK
 #define DS_RING_CLOCK 0       // 1: s_memtime around the piped loop's wait / barrier / requests / rest, printed by two workgroups of the dense kernel
 #endif
@@ -812,20 +809,10 @@ struct SplitRing {
 #pragma unroll
         for (int j = 0; j < LPS; ++j) {
             if (NF % 4 != 0 && j == LPS - 1 && wave >= NF % 4) break;      // wave-uniform: this wave has no fragment 4 j + wave
-            if ((DS_RING_BISECT == 5 && !is_a[j]) || (DS_RING_BISECT == 6 && is_a[j])) continue;
             const int ks = st * KGS + kgi_[j];
             const long off = (long)st * (KGS * SPLIT_KSTEP_BYTES) + ((is_a[j] && ks >= s0) ? dseg : 0);
             glds16s(src[j] + off, lane16, dst + j * 4096);      // fragment q = wave + 4 j of the stage
         }
-    }
-    // request j of this wave for stage st (the piped loop spreads a stage's requests between its MFMAs)
-    template <int J>
-    __device__ __forceinline__ void request_one(int st, unsigned dst) const
-    {
-        if (NF % 4 != 0 && J == LPS - 1 && wave >= NF % 4) return;
-        const int ks = st * KGS + kgi_[J];
-        const long off = (long)st * (KGS * SPLIT_KSTEP_BYTES) + ((is_a[J] && ks >= s0) ? dseg : 0);
-        glds16s(src[J] + off, lane16, dst + J * 4096);
     }
     // ---- piped loop, requests: the source of request J is (wave-uniform base rs[J]) + (lane offset + stage offset, ONE vector add per
     // stage): no scalar address arithmetic per request; no branch either -- past the last stage the requests repeat it into the slot
@@ -854,7 +841,7 @@ struct SplitRing {
     }
     __device__ __forceinline__ void prologue(int nstages) const
     {
-#if DS_SPLIT_PIPED == 3
+#if DS_SPLIT_PIPED
         static_assert(KGS == 1 && (NSLOT - 1) * LPS <= 63, "one k-step per stage; vmcnt holds six bits");
         if (nstages <= 0 || DS_RING_BISECT == 4) return;
         unsigned keep_m0;
@@ -868,7 +855,7 @@ struct SplitRing {
         return;
 #endif
 #pragma unroll
-        for (int s = 0; s < NSLOT - (DS_SPLIT_PIPED ? 0 : 1); ++s)
+        for (int s = 0; s < NSLOT - 1; ++s)
             if (DS_RING_BISECT != 2 && DS_RING_BISECT != 4 && s < nstages) request(s, s);
     }
     // wait until all but the last K stages requested have landed (this wave's share; waves >= NF % 4 request one fragment fewer)
@@ -935,13 +922,12 @@ struct SplitRing {
     // k-step WITHOUT any operand traffic, for 576 of MFMA). Here iteration st holds stage st in registers; it waits until stage st + 1
     // has landed, passes the barrier (everybody's share of st + 1 has landed, everybody has READ stage st: its slot is free), requests
     // stage st + NSLOT into that slot and then issues the LDS reads of stage st + 1 BETWEEN the MFMAs of stage st -- the interleave is
-    // pinned with sched_group_barrier, hipcc's own schedule serialises read -> wait -> MFMA. NSLOT stages are requested ahead.
+    // pinned instruction by instruction (sched_barrier), hipcc's own schedule serialises read -> wait -> MFMA. NSLOT stages are requested ahead.
     // The MFMAs of one accumulator keep their order: bit-identical to run_simple.
     static_assert(!DS_SPLIT_PIPED || KGS == 1, "the piped loop takes one k-step per stage");
     typedef float4 Frag[MTW + NTW][3];
     __device__ __forceinline__ void read_frags(const float* fa0, const float* fb0, int slot, Frag& f) const
     {
-        if (DS_RING_BISECT == 7) return;
         const float* fa = fa0 + slot * STAGE;
         const float* fb = fb0 + slot * STAGE;
 #pragma unroll
@@ -953,30 +939,17 @@ struct SplitRing {
 #pragma unroll
             for (int p = 0; p < 3; ++p) f[MTW + j][p] = *reinterpret_cast<const float4*>(fb + (j * 3 + p) * 256);
     }
-    __device__ __forceinline__ void mfma_frags(const Frag& f, floatx16 (&acc)[MTW][NTW]) const
+    static constexpr int req_pos(int j)        // request j of a stage goes behind MFMA (j NM) / LPS + 1 of the pinned sequence
     {
-#pragma unroll
-        for (int i = 0; i < MTW; ++i)
-#pragma unroll
-            for (int j = 0; j < NTW; ++j) {
-                if (DS_RING_BISECT == 7) continue;
-                if (DS_RING_BISECT == 1 || DS_RING_BISECT == 5 || DS_RING_BISECT == 6) { acc[i][j][0] += f[MTW + j][0].x + f[MTW + j][1].y + f[MTW + j][2].z + f[i][0].x + f[i][1].y + f[i][2].z; continue; }
-                acc[i][j] = mfma3_lo(f[MTW + j], f[i][0], f[i][1], f[i][2], acc[i][j]);
-                acc[i][j] = mfma3_hi(f[MTW + j], f[i][0], f[i][1], acc[i][j]);
-            }
-    }
-    static constexpr int req_pos(int j, bool odd)
-    {
-        const int nm = 6 * MTW * NTW, sp = nm / LPS, half = (DS_RING_STAGGER && sp >= 2) ? sp / 2 : 0;
-        const int p = (j * nm + LPS - 1) / LPS + 1 + (odd ? half : 0);
+        const int nm = 6 * MTW * NTW, p = (j * nm + LPS - 1) / LPS + 1;
         return p < nm ? p : nm - 1;
     }
     template <int M, int J>
-    __device__ __forceinline__ void piped_req(int st, bool more, unsigned rdst) const
+    __device__ __forceinline__ void piped_req(unsigned voff, unsigned rdst) const
     {
         if constexpr (J < LPS) {
-            if constexpr (req_pos(J, false) == M) request3<J>((unsigned)st, rdst);      // (st carries the stage's vector offset)
-            piped_req<M, J + 1>(st, more, rdst);
+            if constexpr (req_pos(J) == M) request3<J>(voff, rdst);
+            piped_req<M, J + 1>(voff, rdst);
         }
     }
     static constexpr bool ROLL = MTW >= 3;
@@ -994,9 +967,9 @@ struct SplitRing {
         return -1;
     }
     static_assert(!ROLL || 3 * NTW + 3 <= 6 * NTW, "the early reads end before the first m-tile's MFMAs do");
-    // element M of the pinned sequence (PIPED == 3)
+    // element M of the pinned sequence
     template <int M>
-    __device__ __forceinline__ void piped_seq(int st, bool more, unsigned rdst, const float* fa, const float* fb, const Frag& cur, Frag& nxt,
+    __device__ __forceinline__ void piped_seq(unsigned voff, unsigned rdst, const float* fa, const float* fb, const Frag& cur, Frag& nxt,
                                               floatx16 (&acc)[MTW][NTW]) const
     {
         constexpr int NT_ = MTW * NTW, NM = 6 * NT_;
@@ -1014,26 +987,19 @@ struct SplitRing {
                 constexpr int F = RF / 3, TERM = RF % 3;
                 nxt[F][TERM] = *reinterpret_cast<const float4*>((F < MTW ? fa + (F * 3 + TERM) * 256 : fb + ((F - MTW) * 3 + TERM) * 256));
             }
-            // request j goes behind MFMA (j NM) / LPS + 1 in waves 0 and 2, half a spacing later in waves 1 and 3: the four waves run in
-            // step, and four requests at once hold each wave for the address unit's 4 x 16 cycles instead of 16
-            piped_req<M, 0>(st, more, rdst);
+            piped_req<M, 0>(voff, rdst);
             __builtin_amdgcn_sched_barrier(0);
-            piped_seq<M + 1>(st, more, rdst, fa, fb, cur, nxt, acc);
+            piped_seq<M + 1>(voff, rdst, fa, fb, cur, nxt, acc);
         }
     }
-    // one iteration with a successor stage: slot = ring slot of stage st
+    // one iteration: registers `cur` hold stage st (slot = its ring slot), `nxt` take stage st + 1
     __device__ __forceinline__ void piped(int st, int slot, int nstages, const float* fa0, const float* fb0, const Frag& cur, Frag& nxt, floatx16 (&acc)[MTW][NTW]) const
     {
 #if DS_RING_CLOCK
         const unsigned long long c0 = __builtin_amdgcn_s_memtime();
         if (clk[4]) clk[3] += c0 - clk[4];
 #endif
-#if DS_SPLIT_PIPED == 3
         asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((NSLOT - 2) * LPS) : "memory");
-#else
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        wait_but<NSLOT - 2>(nstages - 2 - st);
-#endif
 #if DS_RING_CLOCK
         const unsigned long long c1 = __builtin_amdgcn_s_memtime();
 #endif
@@ -1041,14 +1007,6 @@ struct SplitRing {
 #if DS_RING_CLOCK
         const unsigned long long c2 = __builtin_amdgcn_s_memtime();
 #endif
-#if DS_SPLIT_PIPED == 1
-        if (DS_RING_BISECT != 2 && st + NSLOT < nstages) request(st + NSLOT, slot);
-#endif
-#if DS_RING_CLOCK
-        const unsigned long long c3 = __builtin_amdgcn_s_memtime();
-        clk[0] += c1 - c0; clk[1] += c2 - c1; clk[2] += c3 - c2; clk[4] = c3;
-#endif
-#if DS_SPLIT_PIPED == 3
         // the order is pinned instruction by instruction: MFMA m (round robin over the accumulators, the six products of one accumulator
         // in mfma3_lo / mfma3_hi order), behind it LDS read m of the next stage, and every NM / LPS MFMAs one LDS-DMA request. In one
         // burst behind the barrier the four waves' 21 requests held every wave for 350 cycles per k-step in front of its MFMAs
@@ -1058,63 +1016,36 @@ struct SplitRing {
         const int nslot = slot + 1 == NSLOT ? 0 : slot + 1;
         const float* fa = fa0 + nslot * STAGE;
         const float* fb = fb0 + nslot * STAGE;
+#if DS_RING_CLOCK
+        const unsigned long long c3 = __builtin_amdgcn_s_memtime();
+        clk[0] += c1 - c0; clk[1] += c2 - c1; clk[2] += c3 - c2; clk[4] = c3;
+#endif
         unsigned keep_m0;
         asm volatile("s_mov_b32 %0, m0" : "=s"(keep_m0));
         __builtin_amdgcn_sched_barrier(0);
-        piped_seq<0>((int)voff, true, rdst, fa, fb, cur, nxt, acc);
+        piped_seq<0>(voff, rdst, fa, fb, cur, nxt, acc);
         asm volatile("s_mov_b32 m0, %0" ::"s"(keep_m0));
-#else
-        read_frags(fa0, fb0, slot + 1 == NSLOT ? 0 : slot + 1, nxt);
-        mfma_frags(cur, acc);
-        constexpr int NR = 3 * (MTW + NTW), NM = 6 * MTW * NTW;
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-#pragma unroll
-        for (int r = 0; r < NR; ++r) {
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        }
-        __builtin_amdgcn_sched_group_barrier(0x008, NM - NR - 1, 0);
-#endif
-#if DS_SPLIT_PIPED == 2
-        if (st + NSLOT < nstages) request(st + NSLOT, slot);
-#endif
         __builtin_amdgcn_sched_barrier(0);      // (the next iteration's lgkmcnt(0) stays behind this iteration's last MFMAs)
     }
     __device__ __forceinline__ void run_piped(int nstages, const float* fa0, const float* fb0, floatx16 (&acc)[MTW][NTW]) const
     {
         if (nstages <= 0) return;
         // (prologue() has requested stages 0 .. NSLOT - 1)
-#if DS_SPLIT_PIPED == 3
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSLOT - 1) * LPS) : "memory");
-#else
-        wait_but<NSLOT - 1>(nstages - 1);
-#endif
         __builtin_amdgcn_s_barrier();
         Frag f0, f1;
         read_frags(fa0, fb0, 0, f0);
         int slot = 0, st = 0;
-#if DS_SPLIT_PIPED == 3
-        // every stage through the same pinned sequence -- the last one reads a "next stage" nobody uses: a separate tail of plain MFMAs
-        // made hipcc keep the 256 x 192 tile's accumulators in two places and spill inside the loop
-        const int n1 = nstages;
-#else
-        const int n1 = nstages - 1;                 // iterations with a successor stage, two per trip (the register sets swap roles)
-#endif
-        for (int p = 0; p < (n1 >> 1); ++p) {
+        // every stage through the same pinned sequence, two per trip (the register sets swap roles) -- the last one reads a "next stage"
+        // nobody uses: a separate tail of plain MFMAs made hipcc keep the 256 x 192 tile's accumulators in two places and spill inside the loop
+        for (int p = 0; p < (nstages >> 1); ++p) {
             piped(st, slot, nstages, fa0, fb0, f0, f1, acc);
             ++st; slot = slot + 1 == NSLOT ? 0 : slot + 1;
             piped(st, slot, nstages, fa0, fb0, f1, f0, acc);
             ++st; slot = slot + 1 == NSLOT ? 0 : slot + 1;
         }
-#if DS_SPLIT_PIPED == 3
-        if (n1 & 1) piped(st, slot, nstages, fa0, fb0, f0, f1, acc);
+        if (nstages & 1) piped(st, slot, nstages, fa0, fb0, f0, f1, acc);
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // (the filler requests and reads of the last iterations)
-#else
-        if (n1 & 1) {
-            piped(st, slot, nstages, fa0, fb0, f0, f1, acc);
-            mfma_frags(f1, acc);
-        } else mfma_frags(f0, acc);
-#endif
     }
     __device__ __forceinline__ void run(int nstages, const float* fa0, const float* fb0, floatx16 (&acc)[MTW][NTW]) const
     {
