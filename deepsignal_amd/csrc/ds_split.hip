@@ -1186,15 +1186,17 @@ hipError_t launch_lstm_cells_split(int tile, const LstmLaunch& L, hipStream_t s)
 // [h_fw(T-1) | h_bw(0) | signal features] as a fragment-major term image (pack_joint_split_kernel), B = W1's panels.
 __global__ __launch_bounds__(256) void pack_joint_split_kernel(const SplitDense d)
 {
-    // one thread per (row, k-step half): 8 consecutive k of one row -> the 16 bytes of its lane slot in each of the three term fragments
+    // one thread per (row, k-step half): 8 consecutive k of one row -> the 16 bytes of its lane slot in each of the three term fragments.
+    // A wave = the 64 lane slots of ONE (m-tile, k-step): its three stores are whole 1 KiB fragments (with the k-step half fastest over
+    // the threads every store was a lone 16 bytes: 38 MB written for the image's 18.5 MB, PMC)
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
     const int ksteps = d.ksteps;
     const long total = (long)d.mtiles * 32 * ksteps * 2;
     if (idx >= total) return;
-    const int half = (int)(idx & 1);
-    const long t = idx >> 1;
+    const int half = (int)((idx >> 5) & 1);
+    const long t = idx >> 6;
     const int ks = (int)(t % ksteps);
-    const int row = (int)(t / ksteps);
+    const int row = (int)(t / ksteps) * 32 + (int)(idx & 31);
     const int k0 = ks * 16 + half * 8;
     float v[8];
 #pragma unroll
