@@ -178,7 +178,10 @@ def pmc_mfma_busy(kernel_name, pattern="r[0-9][0-9]_pmc_mfma_util.json"):
                 return {"mfma_busy_pmc": v["mfma_busy_frac_at_inkernel_clock"],
                         # GRBM_GUI_ACTIVE / duration: the clock the chip ran THIS kernel at -- it lowers the clock under matrix load
                         # (2.40 GHz idle, 1.92 GHz with every CU on bf16 MFMAs: tools/attic/clock_probe.hip), and `peak` is quoted at 2.4
-                        "in_kernel_clock_ghz": v.get("gui_active_over_duration_ghz"),
+                        # (only for dispatches of >= 100 us and never above the part's 2.4 GHz: on 20 us launches the quotient over-counts)
+                        "in_kernel_clock_ghz": (v.get("gui_active_over_duration_ghz")
+                                                if (v.get("gui_active_over_duration_ghz") or 9.9) <= 2.4 and v.get("mean_us", 0) >= 100.0 else None),
+                        "mfma_busy_definition": "SQ_VALU_MFMA_BUSY_CYCLES per SIMD / (dispatch duration x 2.17 GHz)",
                         "mfma_busy_source": "committed constant, NOT measured in this run: profiles/%s (%s)"
                                             % (os.path.basename(path), _build_of(rec))}
     except (OSError, ValueError, KeyError, TypeError):

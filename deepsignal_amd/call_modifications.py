@@ -531,7 +531,8 @@ def call_mods(input_path, model_path, result_file, kmer_len, cent_signals_len,
     if precision in ("bf16", "bf16_all") and rank == 0 and engine is None:
         # measured, DESIGN.md section 9: harmless on random-init weights, NOT on weights at a trained model's scale
         print("note: --precision %s stores activations as bf16: on trained-scale weights expect probabilities to move by ~0.02 (up "
-              "to ~0.2) and a few per cent of the calls nearest the threshold to change label; fp32 is the reference numerics"
+              "to ~0.2) and a few per cent of the calls nearest the threshold to change label. --precision bf16x3 is the fast mode "
+              "with fp32-class results (held to the fp32 parity bars, ~1.4-1.5x the fp32 rate); fp32 is the reference numerics"
               % precision, file=sys.stderr)
     device = None
     if dist is not None and (world > 1 or force_sharded) and dist.get_backend() == "nccl":

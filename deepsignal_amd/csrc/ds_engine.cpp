@@ -152,6 +152,7 @@ struct Slot {
 
     std::map<int, Plan> plans;
     int last_n = 0;
+    int last_fc1_parts = 1;               // partial products the last forward's dense left in fc1o (kept here: its plan may be evicted)
 };
 
 // dense(J, J) with split operands moves 1.5x the operand bytes of the fp32 GEMM for 0.375x its matrix time and is bound by operand
@@ -233,8 +234,10 @@ int fail(ds_handle* h, int code, const std::string& msg)
 #define HIPCHK(h, expr)                                                                                  \
     do {                                                                                                 \
         hipError_t e_ = (expr);                                                                          \
-        if (e_ != hipSuccess)                                                                            \
+        if (e_ != hipSuccess) {                                                                          \
+            (void)hipGetLastError(); /* the thread's sticky error: the launchers end with hipGetLastError() */ \
             return fail(h, DS_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));              \
+        }                                                                                                \
     } while (0)
 
 template <class T>
@@ -243,7 +246,13 @@ int dalloc(ds_handle* h, T** p, size_t count)
     void* q = nullptr;
     size_t bytes = std::max<size_t>(count * sizeof(T), 256);
     hipError_t e = hipMalloc(&q, bytes);
-    if (e != hipSuccess) return fail(h, DS_ERR_NOMEM, std::string("hipMalloc: ") + hipGetErrorString(e));
+    if (e != hipSuccess) {
+        // hipGetLastError() returns (and clears) the thread's last error; every launcher ends with it. Left in place, a failed
+        // hipMalloc would be reported by the first launch of the NEXT handle this thread creates (call_modifications.make_engine's
+        // fall-back to the user's batch size after an out-of-memory ds_create)
+        (void)hipGetLastError();
+        return fail(h, DS_ERR_NOMEM, std::string("hipMalloc: ") + hipGetErrorString(e));
+    }
     h->allocs.push_back(q);
     *p = static_cast<T*>(q);
     return DS_OK;
@@ -1283,6 +1292,7 @@ int run_resident(ds_handle* h, int n)
     int rc = get_plan(h, n, &plan);
     if (rc) return rc;
     h->cur->last_n = n;
+    h->cur->last_fc1_parts = plan->fc1_parts;
     if (h->profiling) {
         rc = collect_stage_times(h);      // events of a previous profiled forward are reused below
         if (rc) return rc;
@@ -1457,9 +1467,12 @@ void ds_destroy(ds_handle* h)
 {
     if (!h) return;
     hipSetDevice(h->cfg.device);
+    // every stream is drained before any is destroyed: with DS_TUNE_SHARED_EVENT_STREAM the slots share slot 0's s1
     for (Slot& sl : h->slots) {
         if (sl.s0) hipStreamSynchronize(sl.s0);
         if (sl.s1) hipStreamSynchronize(sl.s1);
+    }
+    for (Slot& sl : h->slots) {
         for (auto& kv : sl.plans) {
             if (kv.second.graph) hipGraphExecDestroy(kv.second.graph);
             for (Op& op : kv.second.ops) { if (op.ev0) hipEventDestroy(op.ev0); if (op.ev1) hipEventDestroy(op.ev1); }
@@ -1472,6 +1485,7 @@ void ds_destroy(ds_handle* h)
         if (sl.s1 && sl.owns_s1) hipStreamDestroy(sl.s1);
     }
     for (void* p : h->allocs) hipFree(p);
+    (void)hipGetLastError();      // nothing a teardown call returned may surface in a later handle's first launch
     delete h;
 }
 
@@ -1784,8 +1798,7 @@ int64_t ds_get_intermediate(ds_handle* h, const char* name, float* out, int64_t 
     if (s == "stem_conv3") return copy(h->cur->conv3o, (int64_t)n * h->wa * 256);
     if (s == "signal_feat") return copy(h->cur->sigfeat, (int64_t)n * h->SF);
     if (s == "fc1") {
-        const auto it = h->cur->plans.find((int)n);
-        const int parts = it != h->cur->plans.end() ? it->second.fc1_parts : 1;
+        const int parts = h->cur->last_fc1_parts;
         const int64_t got = copy(h->cur->fc1o, (int64_t)n * h->J);
         if (got < 0 || parts == 1) return got;
         std::vector<float> part((size_t)n * h->J);            // the split dense's partial products, added in launch_head's order

@@ -832,7 +832,7 @@ struct SplitRing {
     {
         unsigned dst = rdst + J * 4096;
         if (NF % 4 != 0 && J == LPS - 1 && wave >= NF % 4) dst = ring_lds + NSLOT * STAGE * 4 + wave * 1024;
-        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(rs[J]), "s"(dst) : "memory");      // (m0: saved and restored around the run of requests by the caller)
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(rs[J]), "s"(dst) : "memory");      // (m0: saved and restored around the run of requests by the caller; hipcc rejects m0 as a clobber -- "reserved register" -- so tests/test_kernel_resources.py holds what the save/restore relies on: no SGPR spill, hence no compiler use of m0, in these kernels)
     }
     template <int J>
     __device__ __forceinline__ void request3_all(unsigned voff, unsigned rdst) const

@@ -99,10 +99,11 @@ def test_plain_c_client_matches_python_engine(small_weights, tmp_path):
     assert np.array_equal(act2, e_act) and np.array_equal(pred2, e_pred)
 
 
-def test_cli_accepts_a_tf_checkpoint_prefix_and_precision(small_weights, tmp_path):
+def test_cli_accepts_a_tf_checkpoint_prefix_and_precision(small_weights, tmp_path, capsys):
     """`--model_path` is a TensorFlow checkpoint prefix in the reference (call_modifications.py:210-211): the CLI must
     take one as is (plus Adam slots it has to ignore) and give the bytes it gives for the flat weight file; and
-    `--precision bf16_all` must stay within the documented distance of fp32."""
+    `--precision bf16_all` must stay within the documented distance of fp32 and must point its user at `--precision bf16x3`, the
+    fast mode with fp32-class results."""
     from deepsignal_amd import tf_checkpoint
     from deepsignal_amd.deepsignal import main
     n = 400
@@ -120,6 +121,8 @@ def test_cli_accepts_a_tf_checkpoint_prefix_and_precision(small_weights, tmp_pat
     for tag, model, extra in (("dsw", dsw, []), ("ckpt", ckpt, []), ("bf16", ckpt, ["--precision", "bf16_all"])):
         outs[tag] = str(tmp_path / (tag + ".tsv"))
         assert main(["call_mods", "-i", tsv, "-m", model, "-o", outs[tag], "-b", "128"] + extra) == 0
+        err = capsys.readouterr().err
+        assert ("--precision bf16x3" in err) == (tag == "bf16"), err
     a, b = open(outs["dsw"], "rb").read(), open(outs["ckpt"], "rb").read()
     assert a == b and a.count(b"\n") == n
     p32 = np.array([[float(x) for x in l.split("\t")[6:8]] for l in open(outs["dsw"])])
@@ -159,3 +162,29 @@ def test_row_pipeline_fills_batches_across_items_with_identical_bits(small_weigh
     info_all = np.frombuffer(("r%04d" * n % tuple(range(n))).encode(), np.uint8)
     expect = fastio.format_rows(info_all, np.arange(n + 1, dtype=np.int64) * 5, ra, rp, feats["kmer"]).decode().splitlines()
     assert rows == expect
+
+
+def test_engine_after_a_failed_create_in_the_same_thread(small_weights, tmp_path, capsys):
+    """An engine too large for the device fails in ds_create (hipMalloc) -- and the NEXT engine the same thread creates must
+    work: every launcher of the library ends with hipGetLastError(), which would otherwise hand the stale out-of-memory error
+    to that engine's first launch. Then the product's own use of it: make_engine's fall-back from an engine batch
+    the GPU has no room for to the user's --batch_size."""
+    from deepsignal_amd import call_modifications as cm
+    from deepsignal_amd.engine import Engine
+    from oracle import oracle
+    feats = synth.synthetic_features(40, seed=77)
+    with pytest.raises(RuntimeError, match="hipMalloc"):
+        Engine(device=0, max_batch=1 << 21)
+    eng = Engine(device=0, max_batch=64)
+    eng.load_weights(small_weights)                 # finalize_weights launches embed_table_kernel: the first `return hipGetLastError()`
+    act, pred = eng.run(feats["kmer"], feats["means"], feats["stds"], feats["sanums"], feats["signals"])
+    eng.close()
+    o_act, _ = oracle.forward(small_weights, feats, "f32")
+    assert np.abs(act - o_act).max() <= 1e-5
+    wfile = str(tmp_path / "model.dsw")
+    W.save_weights(wfile, small_weights)
+    eng = cm.make_engine(wfile, 17, 360, 2, 64, engine_batch=1 << 21)
+    assert "falling back to --batch_size 64" in capsys.readouterr().err
+    act2, _ = eng.run(feats["kmer"], feats["means"], feats["stds"], feats["sanums"], feats["signals"])
+    eng.close()
+    assert np.array_equal(act2, act)

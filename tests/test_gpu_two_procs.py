@@ -67,24 +67,28 @@ def job(tmp_path_factory, balanced_weights):
     tsv, wfile, plain = os.path.join(tmp, "features.tsv"), os.path.join(tmp, "w.dsw"), os.path.join(tmp, "plain.tsv")
     _write_feature_tsv(tsv, feats, reads)
     W.save_weights(wfile, balanced_weights)
-    eng = Engine(device=0, max_batch=512)
-    eng.load_weights_file(wfile)
-    n = cm.call_mods(tsv, "unused", plain, 17, 360, 512, 0.001, 2, 1, True, True, True, True, None, engine=eng, f5_batch_num=20)
-    eng.close()
-    assert n == len(reads)
+    # the single-process result file of either fp32-class precision (the split-operand engine under the launcher: VERDICT r05 item 7)
+    for prec, path in (("fp32", plain), ("bf16x3", plain + ".bf16x3")):
+        eng = Engine(device=0, max_batch=512, precision=prec)
+        eng.load_weights_file(wfile)
+        n = cm.call_mods(tsv, "unused", path, 17, 360, 512, 0.001, 2, 1, True, True, True, True, None, engine=eng, f5_batch_num=20)
+        eng.close()
+        assert n == len(reads)
     labels = np.array([int(l.split("\t")[-2]) for l in open(plain).read().splitlines()])
     assert 0.2 < labels.mean() < 0.8, "the reference file holds one label only"
     return {"tmp": tmp, "tsv": tsv, "wfile": wfile, "plain": plain, "n": n}
 
 
-@pytest.mark.parametrize("nproc", [2, 3])
-def test_sharded_call_mods_two_processes_on_one_gpu(job, nproc):
+@pytest.mark.parametrize("nproc,precision", [(2, "fp32"), (3, "fp32"), (2, "bf16x3")])
+def test_sharded_call_mods_two_processes_on_one_gpu(job, nproc, precision):
     """Each rank parses its own byte ranges, runs them on its own engine (own HIP context, streams, weight replica) and
-    rank 0 writes the gathered rows: byte-identical to the single-process file, about 20 rounds of the row gather."""
-    out = os.path.join(job["tmp"], "sharded_%d.tsv" % nproc)
-    res, dt = _launch(nproc, [WORKER, "ok", job["tsv"], job["wfile"], out, str(1 << 19)], timeout=600)
+    rank 0 writes the gathered rows: byte-identical to the single-process file of the same precision, about 20 rounds of the
+    row gather."""
+    out = os.path.join(job["tmp"], "sharded_%d_%s.tsv" % (nproc, precision))
+    res, dt = _launch(nproc, [WORKER, "ok", job["tsv"], job["wfile"], out, str(1 << 19)], timeout=600,
+                      extra_env={"DS_TEST_PRECISION": precision})
     assert res.returncode == 0, res.stderr.decode()[-3000:]
-    assert open(out, "rb").read() == open(job["plain"], "rb").read()
+    assert open(out, "rb").read() == open(job["plain"] + (".bf16x3" if precision == "bf16x3" else ""), "rb").read()
     for r in range(nproc):
         assert int(open(out + ".rank%d.count" % r).read()) == job["n"]           # every rank learns the job-wide count
         assert r == 0 or not os.path.exists(out + ".rank%d" % r)

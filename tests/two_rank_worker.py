@@ -5,6 +5,7 @@ usage: two_rank_worker.py <mode> <features.tsv> <weights.dsw> <result.tsv> [chun
   mode ok     the product's sharded call_mods route, end to end
   mode raise  the same, but the last rank's engine raises on its third batch (every rank must exit non-zero, no hang)
   mode die    the same, but the last rank's process dies without a word on its third batch
+DS_TEST_PRECISION (fp32 | bf16x3) picks the engines' precision.
 """
 import datetime
 import os
@@ -42,7 +43,7 @@ def main():
             return Engine.submit_parts(self, parts)
 
     cls = Faulty if (mode in ("raise", "die") and rank == world - 1) else Engine
-    eng = cls(device=0, max_batch=512)
+    eng = cls(device=0, max_batch=512, precision=os.environ.get("DS_TEST_PRECISION", "fp32"))
     eng.load_weights_file(wfile)
     cm.SHARD_CHUNK_BYTES = chunk
     n = cm.call_mods(tsv, "unused", out, 17, 360, 512, 0.001, 2, 1, True, True, True, True, None, engine=eng, dist=dist,

@@ -3,7 +3,7 @@
 #   tools/collect_profiles.sh r03      -> gpurun_out/prof_r03/{bench.json, kernel_stats.csv, fetch/, write/, mfma/}
 # Counter passes are separate runs with --pmc only (no trace domains), as the pool requires.
 set -u
-R=${1:-r05}
+R=${1:-r06}
 OUT=gpurun_out/prof_$R
 mkdir -p $OUT
 export TMPDIR=/tmp
@@ -17,7 +17,7 @@ rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 bench.py
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 bench.py --steps 4 --warmup 1 --windows 1 --no-cpu-baseline --no-host-path --no-fast-mode --no-configs2 --no-profile-pass > /dev/null 2> $OUT/write.err
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/mfma -- python3 tools/probe_engine.py fp32 512 threestep > /dev/null 2> $OUT/mfma.err
 python3 tools/pmc_traffic.py $OUT/fetch $OUT/write $OUT/pmc_traffic.json > $OUT/pmc_traffic.txt 2>&1
-python3 tools/pmc_mfma_util.py $OUT/mfma $OUT/pmc_mfma_util.json > $OUT/pmc_mfma_util.txt 2>&1
+python3 tools/pmc_mfma_util.py $OUT/mfma $OUT/pmc_mfma_util.json "python3 tools/probe_engine.py fp32 512 threestep" > $OUT/pmc_mfma_util.txt 2>&1
 cp $(ls $OUT/fetch/*/*counter_collection.csv | head -1) $OUT/fetch_size_counter_collection.csv 2>/dev/null
 cp $(ls $OUT/write/*/*counter_collection.csv | head -1) $OUT/write_size_counter_collection.csv 2>/dev/null
 cp $(ls $OUT/mfma/*/*counter_collection.csv | head -1) $OUT/mfma_busy_counter_collection.csv 2>/dev/null
@@ -41,7 +41,7 @@ rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/xfetch -- python3 tools/p
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/xwrite -- python3 tools/probe_engine.py bf16x3 512 threestep > /dev/null 2> $OUT/xwrite.err
 python3 tools/pmc_traffic.py $OUT/xfetch $OUT/xwrite $OUT/bf16x3_pmc_traffic.json > $OUT/bf16x3_pmc_traffic.txt 2>&1
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/xmfma -- python3 tools/probe_engine.py bf16x3 512 threestep > /dev/null 2> $OUT/xmfma.err
-python3 tools/pmc_mfma_util.py $OUT/xmfma $OUT/bf16x3_pmc_mfma_util.json > $OUT/bf16x3_pmc_mfma_util.txt 2>&1
+python3 tools/pmc_mfma_util.py $OUT/xmfma $OUT/bf16x3_pmc_mfma_util.json "python3 tools/probe_engine.py bf16x3 512 threestep" > $OUT/bf16x3_pmc_mfma_util.txt 2>&1
 rm -rf $OUT/xtrace $OUT/xfetch $OUT/xwrite $OUT/xmfma
 cat $OUT/bf16x3_pmc_traffic.txt $OUT/bf16x3_pmc_mfma_util.txt
 # wave states of the kernels that changed this round (and the unchanged ones beside them)

@@ -28,7 +28,17 @@ def kernel_resources():
         get = lambda key: int(re.search(r"\.amdhsa_%s (\d+)" % key, body).group(1))
         name = subprocess.run(["c++filt", m.group(1)], capture_output=True, text=True).stdout.strip() or m.group(1)
         res[name] = {"vgprs": get("next_free_vgpr"), "scratch_bytes": get("private_segment_fixed_size"),
-                     "static_lds_bytes": get("group_segment_fixed_size")}
+                     "static_lds_bytes": get("group_segment_fixed_size"), "sgpr_spills": 0, "vgpr_spills": 0}
+        res[name]["mangled"] = m.group(1)
+    # spill counts live in the amdhsa.kernels metadata (one YAML entry per kernel)
+    by_mangled = {r.pop("mangled"): r for r in res.values()}
+    for m in re.finditer(r"- \.agpr_count:.*?(?=\n  - \.agpr_count:|\namdhsa\.target|\Z)", text, re.S):
+        ent = m.group(0)
+        nm = re.search(r"\.name:\s+(\S+)", ent)
+        if nm and nm.group(1) in by_mangled:
+            for key in ("sgpr_spill", "vgpr_spill"):
+                c = re.search(r"\.%s_count:\s+(\d+)" % key, ent)
+                by_mangled[nm.group(1)][key + "s"] = int(c.group(1)) if c else -1
     return res
 
 
@@ -36,4 +46,4 @@ if __name__ == "__main__":
     flt = sys.argv[1] if len(sys.argv) > 1 else ""
     for name, r in sorted(kernel_resources().items()):
         if flt in name:
-            print("%4d VGPRs  %5d B scratch  %6d B static LDS  %s" % (r["vgprs"], r["scratch_bytes"], r["static_lds_bytes"], name[:110]))
+            print("%4d VGPRs  %5d B scratch  %6d B static LDS  %d/%d SGPR/VGPR spills  %s" % (r["vgprs"], r["scratch_bytes"], r["static_lds_bytes"], r["sgpr_spills"], r["vgpr_spills"], name[:110]))

@@ -12,7 +12,8 @@ for cfg in "$@"; do
   rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_LDS_ADDR_CONFLICT --output-format csv -d $O/${tag}_p3 -- python3 tools/probe_engine.py $cfg > /dev/null 2> $O/${tag}_p3.err
   python3 tools/pmc_wave_states.py $O/${tag}_p1 $O/${tag}_p2 $O/${tag}_p3 > $O/${tag}.txt 2>&1
   cat $O/${tag}.txt
-  tail -n 3 $O/${tag}_p2.err $O/${tag}_p3.err
+  # (profiler logs go to stderr, not into the summary the caller redirects to profiles/<tag>_wave_states.txt)
+  tail -n 3 $O/${tag}_p2.err $O/${tag}_p3.err 1>&2
   rm -rf $O/${tag}_p1 $O/${tag}_p2 $O/${tag}_p3
 done
 
