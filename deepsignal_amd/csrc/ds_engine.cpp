@@ -44,7 +44,7 @@ struct PackedGemm {      // device-resident packed weights of one GEMM
     float* Bps = nullptr;   // DS_PRECISION_BF16X3: the same matrix as three bf16 term panels (pack_b_split)
 };
 
-enum OpKind { OP_GEMM, OP_STEM1, OP_MAXPOOL, OP_AVGPOOL, OP_HEAD, OP_FUSED, OP_PACKEV, OP_LSTM, OP_STEM23, OP_HEADF, OP_DENSES };
+enum OpKind { OP_GEMM, OP_STEM1, OP_MAXPOOL, OP_AVGPOOL, OP_HEAD, OP_FUSED, OP_PACKEV, OP_LSTM, OP_STEM23, OP_HEADF, OP_DENSES, OP_XPROJ };
 
 struct Op {
     OpKind kind;
@@ -62,6 +62,7 @@ struct Op {
     Stem23Args sa{};                      // OP_STEM23
     HeadFoldedArgs ha{};                  // OP_HEADF
     SplitDense sd{};                      // OP_DENSES
+    LstmXproj xp{};                       // OP_XPROJ
     int tm = 0;
     double flops = 0;                     // algorithmic FLOPs of this launch
     hipEvent_t ev0 = nullptr, ev1 = nullptr;   // profiling mode only
@@ -72,7 +73,7 @@ struct Op {
 
 // per-kernel accumulators (one entry per __global__ function / template instantiation)
 enum KernelClass { K_GEMM_CONV = 0, K_GEMM_FC, K_GEMM_LSTM, K_GEMM_CONV_WIDE, K_GEMM_CONV_POOL, K_GEMM_FC_DENSE, K_GEMM_LSTM_DENSE, K_FUSED1, K_FUSED2, K_FUSED3, K_STEM1, K_MAXPOOL, K_AVGPOOL, K_HEAD,
-                   K_GEMM_BCONV, K_GEMM_BCONV_POOL, K_GEMM_BFC, K_GEMM_BFC_DENSE, K_PACKEV, K_GEMM_BLSTM, K_GEMM_BLSTM_DENSE, K_FUSEDB1, K_FUSEDB2, K_FUSEDB3, K_GEMM_LSTM_T, K_GEMM_LSTM_T_DENSE, K_GEMM_BLSTM_T, K_GEMM_BLSTM_T_DENSE, K_LSTM_CELL1, K_LSTM_CELL2, K_LSTM_CELL4, K_LSTM_LDS1, K_LSTM_LDS2, K_STEM23, K_HEADF, K_LSTM_B11, K_LSTM_B12, K_LSTM_B22, K_STEM23B, K_FUSEDS1, K_FUSEDS2, K_FUSEDS3, K_LSTM_S11, K_LSTM_S12, K_LSTM_S22, K_DENSE_SPLIT, K_STEM23S, K_COUNT };
+                   K_GEMM_BCONV, K_GEMM_BCONV_POOL, K_GEMM_BFC, K_GEMM_BFC_DENSE, K_PACKEV, K_GEMM_BLSTM, K_GEMM_BLSTM_DENSE, K_FUSEDB1, K_FUSEDB2, K_FUSEDB3, K_GEMM_LSTM_T, K_GEMM_LSTM_T_DENSE, K_GEMM_BLSTM_T, K_GEMM_BLSTM_T_DENSE, K_LSTM_CELL1, K_LSTM_CELL2, K_LSTM_CELL4, K_LSTM_LDS1, K_LSTM_LDS2, K_STEM23, K_HEADF, K_LSTM_B11, K_LSTM_B12, K_LSTM_B22, K_STEM23B, K_FUSEDS1, K_FUSEDS2, K_FUSEDS3, K_LSTM_S11, K_LSTM_S12, K_LSTM_S22, K_DENSE_SPLIT, K_STEM23S, K_LSTM_XPROJ, K_COUNT };
 const char* const kKernelNames[K_COUNT] = {"gemm_kernel<1,2,4,1,0,0,1,1>", "gemm_kernel<1,3,4,1,0,0,2,1>", "gemm_kernel<1,4,4,1,1,0,1,1>",
                                            "gemm_kernel<2,2,2,2,0,0,1,1>", "gemm_kernel<1,2,4,1,0,1,1,1>", "gemm_kernel<1,3,4,1,0,2,2,1>",
                                            "gemm_kernel<1,4,4,1,1,2,1,1>", "inception_fused_kernel<1>",
@@ -90,7 +91,7 @@ const char* const kKernelNames[K_COUNT] = {"gemm_kernel<1,2,4,1,0,0,1,1>", "gemm
                                            "lstm_cell_bf16_kernel<1,1>", "lstm_cell_bf16_kernel<1,2>", "lstm_cell_bf16_kernel<2,2>", "stem23_bf16_kernel",
                                            "inception_fused_split_kernel<1>", "inception_fused_split_kernel<2>", "inception_fused_split_kernel<3>",
                                            "lstm_cell_split_kernel<1,1>", "lstm_cell_split_kernel<1,2>", "lstm_cell_split_kernel<2,2>",
-                                           "dense_split_kernel (+ pack_joint_split_kernel)", "stem23_split_kernel"};
+                                           "dense_split_kernel (+ pack_joint_split_kernel)", "stem23_split_kernel", "lstm_xproj_kernel"};
 struct KernelStat {
     int64_t launches = 0;
     double total_ms = 0;
@@ -138,6 +139,7 @@ struct Slot {
     float* H[2][NLAYER] = {{nullptr}};   // h of every step: fp32 cells [T][m-tiles][32 k-groups][64][4] (MFMA-fragment-major,
                                          // ds_internal.h LstmCell); bf16-operand cells [T][B][256] bf16 row-major
     float* Cst[2][NLAYER] = {{nullptr}}; // cell state, same layout as one step of H (fp32)
+    float* xproj[2] = {nullptr, nullptr};   // split cells: layer 0's accumulator-initial values of every step (lstm_xproj_kernel), [T][Bp32][1024]
     float* hlast[2] = {nullptr, nullptr};   // fp32 cells: row-major [B][256] copy of the top layer's final h (fw t = T-1, bw t = 0)
     float *fc1o = nullptr, *logits = nullptr, *act = nullptr;
     int* pred = nullptr;
@@ -171,6 +173,8 @@ struct ds_handle {
     bool is_cnn = true, is_rnn = true, is_base = true;   // model.py:28-29,59-75,89-95
     bool bf16 = false;    // DS_PRECISION_BF16: bf16 conv + FC operands (fp32 accumulate), fp32 BiLSTM
     bool split_dense_narrow = false;      // DS_TUNE_SPLIT_DENSE_NARROW
+    bool lstm_xproj = false;              // split cells: the first step's layer-0 cells (no matrix product) by lstm_xproj_kernel instead of a diagonal of their own
+    bool lstm_xproj_all = false;          // ... and layer 0's accumulator-initial values of ALL steps as an image (DS_TUNE_LSTM_XPROJ_ALL)
     int split_dense_min_n = DS_SPLIT_DENSE_MIN_N;   // sites per forward from which dense(J, J) runs split (below: the native fp32 GEMM)
     bool split = false;   // DS_PRECISION_BF16X3: fp32 activations / weights carried as three bf16 terms through the bf16 matrix pipe
                           // (six products per MAC, fp32 accumulate) in the fused inception chains; everything else as fp32
@@ -593,6 +597,7 @@ int alloc_workspace(ds_handle* h)
         for (int l = 0; l < NLAYER; ++l) {
             // split cells keep h as three bf16 terms (6 bytes per unit) where the fp32 cells keep a float
             A(&h->cur->H[d][l], (size_t)h->T * h->Bp32 * HID * (h->split ? 3 : 2) / 2); A(&h->cur->Cst[d][l], (size_t)h->Bp32 * HID);
+            if (l == 0 && h->lstm_xproj_all) A(&h->cur->xproj[d], (size_t)h->T * h->Bp32 * 4 * HID);
         }
     if (h->is_rnn)
         for (int d = 0; d < 2; ++d) A(&h->cur->hlast[d], B * HID);
@@ -916,7 +921,24 @@ int build_plan(ds_handle* h, int n, Plan* plan)
         const int nt_split = h->lstm_variant == DS_LSTM_TILING_NARROW ? 311 : h->lstm_variant == DS_LSTM_TILING_LDS1 ? 312
                              : h->lstm_variant == DS_LSTM_TILING_WIDE ? 322 : DS_SPLIT_LSTM_TILE(n);
         const size_t step = lsp ? (size_t)h->Bp32 * HID * 3 / 2 : (size_t)h->Bp32 * HU;      // floats of one time step in H (bf16 h: half; split h: 3/2)
-        for (int d = 0; d < T + NLAYER - 1; ++d) {
+        const bool xpj = h->lstm_xproj && lsp;
+        const size_t xstep = (size_t)h->Bp32 * 4 * HID;
+        if (xpj) {
+            Op op{};
+            op.kind = OP_XPROJ; op.stream = 1; op.stage = st;
+            LstmXproj& X = op.xp;
+            for (int dir = 0; dir < 2; ++dir) {
+                LstmCell& C = X.cell[dir];
+                C.bias = h->lstm_n[dir][0].bias; C.table = h->lstm_table[dir]; C.wfeat = h->lstm_wfeat[dir];
+                C.codes = h->cur->d_kmer; C.means = h->cur->d_means; C.stds = h->cur->d_stds; C.lens = h->cur->d_sanums;
+                C.c = h->cur->Cst[dir][0]; C.h_out = h->cur->H[dir][0]; C.use_feat = 1; C.c_zero = 1;
+                X.xinit[dir] = h->cur->xproj[dir];
+            }
+            X.h_step = step; X.x_step = xstep; X.n = n; X.mtiles = mtiles; X.T = T; X.nsteps = h->lstm_xproj_all ? T : 1;
+            rnn.push_back(op);
+            if (first_plan) h->stages[st].launches += 1;
+        }
+        for (int d = xpj ? 1 : 0; d < T + NLAYER - 1; ++d) {      // (diagonal 0 = the two first-step cells of layer 0: done by lstm_xproj_kernel)
             LstmLaunch L;
             memset(&L, 0, sizeof L);
             L.n = n; L.mtiles = mtiles; L.T = T;
@@ -939,6 +961,7 @@ int build_plan(ds_handle* h, int n, Plan* plan)
                     C.table = l == 0 ? h->lstm_table[dir] : nullptr;
                     C.wfeat = h->lstm_wfeat[dir];
                     C.codes = h->cur->d_kmer; C.means = h->cur->d_means; C.stds = h->cur->d_stds; C.lens = h->cur->d_sanums;
+                    C.xinit = (xpj && h->lstm_xproj_all && l == 0) ? h->cur->xproj[dir] + (size_t)t * xstep : nullptr;
                     C.c = h->cur->Cst[dir][l];
                     C.h_out = h->cur->H[dir][l] + (size_t)t * step;
                     // the joint FC reads the top layer's final h (fw: t = T-1, bw: t = 0) row-major   layers.py:171-172
@@ -1099,6 +1122,9 @@ int issue_op(ds_handle* h, Plan& plan, const Op& op, hipStream_t s)
     case OP_DENSES:
         HIPCHK(h, launch_dense_split(op.sd, s));
         break;
+    case OP_XPROJ:
+        HIPCHK(h, launch_lstm_xproj(op.xp, s));
+        break;
     case OP_STEM23:
         if (op.a == 2) HIPCHK(h, launch_stem23_split(op.sa, s));
         else if (op.a) HIPCHK(h, launch_stem23_bf16(op.sa, s));
@@ -1202,6 +1228,7 @@ int kernel_class(const Op& op)
     case OP_HEAD: return K_HEAD;
     case OP_PACKEV: return K_PACKEV;
     case OP_DENSES: return K_DENSE_SPLIT;
+    case OP_XPROJ: return K_LSTM_XPROJ;
     case OP_LSTM: if (op.c >= 300) return op.c == 311 ? K_LSTM_S11 : op.c == 312 ? K_LSTM_S12 : K_LSTM_S22;
         return op.c == 1 ? K_LSTM_CELL1 : op.c == 2 ? K_LSTM_CELL2 : op.c == 4 ? K_LSTM_CELL4 : op.c == 101 ? K_LSTM_LDS1
                : op.c == 211 ? K_LSTM_B11 : op.c == 212 ? K_LSTM_B12 : op.c == 222 ? K_LSTM_B22 : K_LSTM_LDS2;
@@ -1421,6 +1448,8 @@ static int ds_create_impl(const ds_config* cfg, ds_handle** out)
     if (cfg->reserved[5] > 0) h->fuse_min_tiles = cfg->reserved[5];
     if (cfg->reserved[6] > 0) h->split_dense_min_n = cfg->reserved[6];
     h->split_dense_narrow = (flags & DS_TUNE_SPLIT_DENSE_NARROW) != 0;
+    h->lstm_xproj = h->split && h->is_rnn && !(flags & DS_TUNE_NO_LSTM_XPROJ);
+    h->lstm_xproj_all = h->lstm_xproj && (flags & DS_TUNE_LSTM_XPROJ_ALL);
     h->lstm_frag = h->is_rnn && !h->lstm_bf16;
     h->Bp32 = (h->B + 31) / 32 * 32;
     h->JP = (h->J + 31) / 32 * 32;

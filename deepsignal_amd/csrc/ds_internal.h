@@ -81,6 +81,8 @@ struct LstmCell {
     const float* means;   // [n][T]
     const float* stds;
     const float* lens;
+    const float* xinit;   // layer 0, optional: this step's accumulator-initial-value image [m-tile][32 n-tiles][4 gates][64 lanes][4] written by
+                          // lstm_xproj_kernel (bias + forget bias + table row + rank-1 terms, lstm_acc_init's bits); nullptr: computed in the cell
     float* c;             // cell state, fragment-major (read-modify-write)
     float* h_out;         // fragment-major
     float* h_row;         // optional row-major [n][256] copy of h_out (what the joint FC reads), or nullptr
@@ -95,6 +97,20 @@ struct LstmLaunch {
     int cls_tiles[2];          // workgroup tiles of the K = 512 cells and of the K = 256 cells (cells are sorted by K)
     unsigned long long* dbg;   // diagnostic (DS_TUNE_DEBUG_STAMPS): [DBG_MAX_WGS workgroups][8] time stamps of wave 0, null in normal runs
 };
+// Layer 0's input projection for ALL steps of both directions in one launch, in front of the diagonals (ds_split.hip): x_t W_x is
+// a table row plus three rank-1 terms plus the bias (model.py:61-69 folded at load), i.e. it depends on the forward's inputs only.
+// A 128 x 128 cell tile otherwise gathers ~80 L2-hot float4 per lane through the texture path in front of its K loop (16 - 24 k
+// cycles); with the image a layer-0 cell starts like any other: four coalesced loads per 32 x 32 tile. The first
+// step's cells (no h yet: K = 0) are finished here as well -- gates, c, h -- so the 2-cell diagonal 0 is no launch at all.
+struct LstmXproj {
+    LstmCell cell[2];          // per direction: bias, table, wfeat, codes / means / stds / lens, c = the layer-0 cell state, h_out = H[dir][0] (t = 0)
+    float* xinit[2];           // [T][m-tiles][32][4][64][4] floats per direction
+    size_t h_step, x_step;     // floats between two time steps of h_out / xinit
+    int n, mtiles, T;
+    int nsteps;                // steps the launch covers: 1 = the first step's cells only (no image: the later cells compute their own initial
+                               // values), T = all of them
+};
+hipError_t launch_lstm_xproj(const LstmXproj& X, hipStream_t s);
 // nt = 32-column n-tiles per wave (1, 2 or 4): the same bits for every nt (same K order per output element)
 hipError_t launch_lstm_cells(int nt, const LstmLaunch& L, hipStream_t s);      // L travels as a by-value kernel argument
 

@@ -143,7 +143,7 @@ __device__ __forceinline__ void fuseds_conv_units(const char* T1, const int (&rm
 #endif
 #ifndef DS_SPLIT_BISECT
 #define DS_SPLIT_BISECT 0       // timing-only bisect builds of P1 (results WRONG): 1 no transform / LDS writes, 2 no row loads, 4 no barrier in the
-#endif                          // chunk loop, 8 no weight loads, 16 no fragment reads
+#endif                          // chunk loop, 8 no weight loads, 16 no fragment reads, 32 no transform arithmetic, 64 no staged writes, 128 no raw reads
 #ifndef DS_SPLIT_WNT
 #define DS_SPLIT_WNT 0          // 1: P1 weight fragments by non-temporal loads
 #endif
@@ -155,6 +155,9 @@ __device__ __forceinline__ void fuseds_conv_units(const char* T1, const int (&rm
 #ifndef DS_SPLIT_READS_FIRST
 #define DS_SPLIT_READS_FIRST 1
 #endif
+#ifndef DS_P1_CLOCK
+#define DS_P1_CLOCK 0           // 1: s_memtime inside every P1 step (lo half | LDS drain | barrier | hi half), printed by two workgroups for the chain's
+#endif                          // second module (diagnostic build: tools/attic/r06_p1clk.sh)
 template <int R> struct SplitRole { static constexpr int value = R; };
 
 template <int TM>
@@ -294,18 +297,37 @@ __global__ __launch_bounds__(512, 2) void inception_fused_split_kernel(const Fus
         auto raw_a = [&](int X, int V) __attribute__((always_inline)) {
             if (STG && !(DS_SPLIT_BISECT & 1)) *reinterpret_cast<float4*>(rdst + X * TR32 * S_LDR) = vo[V];
         };
+        float4 rv[3];                                   // (DS_P1_CLOCK 2 only: the raw rows read apart from the transform)
+        auto raw_read = [&](int slot) __attribute__((always_inline)) {
+            if (STG && !(DS_SPLIT_BISECT & 1)) {
+                const char* r = rdst + slot * TR32 * S_LDR;
+                rv[0] = *reinterpret_cast<const float4*>(r);
+                rv[1] = *reinterpret_cast<const float4*>(r + om);
+                rv[2] = *reinterpret_cast<const float4*>(r + op);
+            }
+        };
         auto store_a = [&](int X) __attribute__((always_inline)) {
             if (STG && !(DS_SPLIT_BISECT & 1)) {
                 const char* r = rdst + X * TR32 * S_LDR;
-                const float4 o = *reinterpret_cast<const float4*>(r);
-                const float4 m = *reinterpret_cast<const float4*>(r + om);
-                const float4 n = *reinterpret_cast<const float4*>(r + op);
+                float4 o, m, n;
+                if (DS_SPLIT_BISECT & 128) { o = vo[0]; m = vo[1 % VD]; n = vo[2 % VD]; }      // (timing only: no raw reads)
+                else if (DS_P1_CLOCK == 2) { o = rv[0]; m = rv[1]; n = rv[2]; }
+                else {
+                    o = *reinterpret_cast<const float4*>(r);
+                    m = *reinterpret_cast<const float4*>(r + om);
+                    n = *reinterpret_cast<const float4*>(r + op);
+                }
                 char* d = sdst + X * TR32 * S_LDP;
                 uint2 t0, t1, t2;
-                split3x4(o.x, o.y, o.z, o.w, t0, t1, t2);
-                *reinterpret_cast<uint2*>(d) = t0; *reinterpret_cast<uint2*>(d + 32) = t1; *reinterpret_cast<uint2*>(d + 64) = t2;
-                split3x4(fmaxf(fmaxf(o.x, m.x), n.x), fmaxf(fmaxf(o.y, m.y), n.y), fmaxf(fmaxf(o.z, m.z), n.z), fmaxf(fmaxf(o.w, m.w), n.w), t0, t1, t2);
-                *reinterpret_cast<uint2*>(d + 96) = t0; *reinterpret_cast<uint2*>(d + 128) = t1; *reinterpret_cast<uint2*>(d + 160) = t2;
+                constexpr bool NOARITH = (DS_SPLIT_BISECT & 32) != 0, NOWRITE = (DS_SPLIT_BISECT & 64) != 0;      // (timing-only builds)
+                if (NOARITH) { t0 = make_uint2(__float_as_uint(o.x), __float_as_uint(o.y)); t1 = make_uint2(__float_as_uint(o.z), __float_as_uint(o.w)); t2 = make_uint2(__float_as_uint(m.x), __float_as_uint(m.y)); }
+                else split3x4(o.x, o.y, o.z, o.w, t0, t1, t2);
+                if (NOWRITE) asm volatile("" ::"v"(t0.x), "v"(t0.y), "v"(t1.x), "v"(t1.y), "v"(t2.x), "v"(t2.y));
+                else { *reinterpret_cast<uint2*>(d) = t0; *reinterpret_cast<uint2*>(d + 32) = t1; *reinterpret_cast<uint2*>(d + 64) = t2; }
+                if (NOARITH) { t0 = make_uint2(__float_as_uint(m.z), __float_as_uint(m.w)); t1 = make_uint2(__float_as_uint(n.x), __float_as_uint(n.y)); t2 = make_uint2(__float_as_uint(n.z), __float_as_uint(n.w)); }
+                else split3x4(fmaxf(fmaxf(o.x, m.x), n.x), fmaxf(fmaxf(o.y, m.y), n.y), fmaxf(fmaxf(o.z, m.z), n.z), fmaxf(fmaxf(o.w, m.w), n.w), t0, t1, t2);
+                if (NOWRITE) asm volatile("" ::"v"(t0.x), "v"(t0.y), "v"(t1.x), "v"(t1.y), "v"(t2.x), "v"(t2.y));
+                else { *reinterpret_cast<uint2*>(d + 96) = t0; *reinterpret_cast<uint2*>(d + 128) = t1; *reinterpret_cast<uint2*>(d + 160) = t2; }
             }
         };
         auto load_b = [&](int Bi) __attribute__((always_inline)) {
@@ -329,9 +351,15 @@ __global__ __launch_bounds__(512, 2) void inception_fused_split_kernel(const Fus
         raw_a(0, 0);
         raw_a(1, 1 % VD);
         lds_barrier();
+        if (DS_P1_CLOCK == 2) raw_read(0);
         store_a(0);
         lds_barrier();
         read_frags(0);
+#if DS_P1_CLOCK
+        unsigned long long pk[4] = {0, 0, 0, 0}, pl[4] = {0, 0, 0, 0}, plast = 0, pm = 0;
+        unsigned long long ptop = __builtin_amdgcn_s_memtime();
+        const unsigned long long pbeg = ptop;
+#endif
 #pragma unroll
         for (int cc = 0; cc < 16; ++cc) {
             if (cc < nchunks) {                                   // wave-uniform; only cc = 15 is really conditional
@@ -340,11 +368,38 @@ __global__ __launch_bounds__(512, 2) void inception_fused_split_kernel(const Fus
                 if (has2) raw_a(X, (cc + 2) % VD);                // the raw copy chunk cc lived in was last read at step cc - 1
                 if (cc + VD < nchunks) load_a(cc % VD);           // chunk cc + VD into the register stage chunk cc left two steps ago
                 if (cc + BD - 1 < nchunks) load_b((cc + BD - 1) % BD);
+#if DS_P1_CLOCK == 2
+                // (diagnostic: the lo half taken apart -- loads / raw write | raw reads until they have landed | arithmetic + staged writes issued | MFMAs)
+                __builtin_amdgcn_sched_barrier(0);
+                const unsigned long long l0 = __builtin_amdgcn_s_memtime();
+                if (has1 && STG) { raw_read((cc + 1) & 1); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+                __builtin_amdgcn_sched_barrier(0);
+                const unsigned long long l1 = __builtin_amdgcn_s_memtime();
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
                 if (has1) store_a(X ^ 1);
+                __builtin_amdgcn_sched_barrier(0);
+                const unsigned long long l2 = __builtin_amdgcn_s_memtime();
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                const unsigned long long l3 = __builtin_amdgcn_s_memtime();
+                __builtin_amdgcn_sched_barrier(0);
+                pl[0] += l0 - ptop; pl[1] += l1 - l0; pl[2] += l2 - l1; pl[3] += l3 - l2; plast = l3;
+#else
+                if (has1) store_a(X ^ 1);
+#endif
 #pragma unroll
                 for (int mt = 0; mt < TM; ++mt) acc[mt] = mfma3_lo(bq[cc % BD], af[X][0][mt], af[X][1][mt], af[X][2][mt], acc[mt]);
                 __builtin_amdgcn_sched_barrier(0);
+#if DS_P1_CLOCK
+                const unsigned long long q1 = __builtin_amdgcn_s_memtime();
+                pm += q1 - plast;
+                asm volatile("s_waitcnt lgkmcnt(1)" ::: "memory");      // (everything but the stamp just requested)
+                const unsigned long long q2 = __builtin_amdgcn_s_memtime();
+                asm volatile("s_barrier" ::: "memory");
+                const unsigned long long q3 = __builtin_amdgcn_s_memtime();
+#else
                 if (!(DS_SPLIT_BISECT & 4)) lds_barrier();
+#endif
                 if (has1) read_frags(X ^ 1);
 #pragma unroll
                 for (int mt = 0; mt < TM; ++mt) acc[mt] = mfma3_hi(bq[cc % BD], af[X][0][mt], af[X][1][mt], acc[mt]);
@@ -352,8 +407,18 @@ __global__ __launch_bounds__(512, 2) void inception_fused_split_kernel(const Fus
                 if (has1) __builtin_amdgcn_sched_group_barrier(0x100, 3 * TM, 0);      // the next chunk's fragment reads lead the half-step
 #endif
                 __builtin_amdgcn_sched_barrier(0);
+#if DS_P1_CLOCK
+                const unsigned long long q4 = __builtin_amdgcn_s_memtime();
+                pk[0] += q1 - ptop; pk[1] += q2 - q1; pk[2] += q3 - q2; pk[3] += q4 - q3; ptop = q4;
+#endif
             }
         }
+#if DS_P1_CLOCK
+        if (mi == 1 && (blockIdx.x == 0 || blockIdx.x == 37) && lane == 0)
+            printf("P1CLK block %d wave %d role %d W %d: cycles per step lo %d drain %d barrier %d hi %d | P1 total %d | lo: top %d rawread %d transform %d writes-land %d mfma %d\n", (int)blockIdx.x, wave, ROLE, W,
+                   (int)(pk[0] / nchunks), (int)(pk[1] / nchunks), (int)(pk[2] / nchunks), (int)(pk[3] / nchunks), (int)(ptop - pbeg),
+                   (int)(pl[0] / nchunks), (int)(pl[1] / nchunks), (int)(pl[2] / nchunks), (int)(pl[3] / nchunks), (int)(pm / nchunks));
+#endif
     };
     if (wave < 2 * TM) run_p1(SplitRole<1>{}); else run_p1(SplitRole<0>{});      // wave-uniform
     DS_STAMP(1);
@@ -415,7 +480,7 @@ __global__ __launch_bounds__(512, 2) void inception_fused_split_kernel(const Fus
     DS_STAMP(4);
     // a job: conv KIND (1 b5b, 2 b3b, 3 b4b) on NM m-tiles from m0, n-tile nt, the weights in pf; the NM accumulator chains are
     // interleaved (a single unit is a chain of dependent LDS reads and MFMAs, i.e. latency)
-    auto run_job = [&](auto kind_tag, auto nm_tag, int m0, int nt) __attribute__((always_inline)) {
+    auto run_job = [&](auto kind_tag, auto nm_tag, int m0, int nt, const float4 (&wts)[30]) __attribute__((always_inline)) {
         constexpr int KIND = decltype(kind_tag)::value, NM = decltype(nm_tag)::value;
         if constexpr (NM > 0) {
             floatx16 u[NM];
@@ -430,7 +495,7 @@ __global__ __launch_bounds__(512, 2) void inception_fused_split_kernel(const Fus
 #pragma unroll
             for (int m = 0; m < NM; ++m) rm[m] = rowmap[(m0 + m) * 32 + rlane];
             // T1 channels: b3a 0..31, b4a 32..63, b5a 64..95
-            fuseds_conv_units<KIND == 3 ? 5 : 3, NM>(T1, rm, KIND == 1 ? 128 : KIND == 2 ? 0 : 64, lane, pf, u);
+            fuseds_conv_units<KIND == 3 ? 5 : 3, NM>(T1, rm, KIND == 1 ? 128 : KIND == 2 ? 0 : 64, lane, wts, u);
 #pragma unroll
             for (int m = 0; m < NM; ++m) {
                 const int row = (m0 + m) * 32 + rlane;
@@ -504,7 +569,7 @@ __global__ __launch_bounds__(512, 2) void inception_fused_split_kernel(const Fus
         }
     };
     if (wave < 2) {
-        run_job(SplitRole<1>{}, SplitRole<TM>{}, 0, wave);
+        run_job(SplitRole<1>{}, SplitRole<TM>{}, 0, wave, pf);
         // the tail's twelve weight fragments travel in the unit registers (behind the job's MFMAs; its results are LDS writes)
 #pragma unroll
         for (int g = 0; g < 12; ++g) pf[g] = gload4(a.Bp5c + ((size_t)(wave * 12 + g) * 64 + lane) * 4);
@@ -513,7 +578,7 @@ __global__ __launch_bounds__(512, 2) void inception_fused_split_kernel(const Fus
         DS_STAMP(6);
         tail_and_store();
     } else if (wave < 4) {
-        run_job(SplitRole<2>{}, SplitRole<TM>{}, 0, wave - 2);
+        run_job(SplitRole<2>{}, SplitRole<TM>{}, 0, wave - 2, pf);
         lds_barrier();
     } else {
         // the b1|b2 tile leaves as whole 384-byte row segments, by the four waves whose second-stage job waits for P2b; every
@@ -531,8 +596,8 @@ __global__ __launch_bounds__(512, 2) void inception_fused_split_kernel(const Fus
         DS_STAMP(5);
         lds_barrier();
         DS_STAMP(6);
-        if (wave >= 6) run_job(SplitRole<3>{}, SplitRole<TM - 1>{}, 1, wave - 6);
-        else run_job(SplitRole<3>{}, SplitRole<1>{}, 0, wave - 4);
+        if (wave >= 6) run_job(SplitRole<3>{}, SplitRole<TM - 1>{}, 1, wave - 6, pf);
+        else run_job(SplitRole<3>{}, SplitRole<1>{}, 0, wave - 4, pf);
     }
     DS_STAMP(7);
 #undef DS_STAMP
@@ -738,6 +803,10 @@ constexpr int SPLIT_MT_BYTES = 16 * SPLIT_KSTEP_BYTES;    // one m-tile of a spl
 #endif
 #ifndef DS_RING_BISECT
 #define DS_RING_BISECT 0      // timing experiments only (results WRONG): 4 = no K loop at all; with DS_SPLIT_PIPED=0 also 1 = no MFMAs, 2 = no LDS-DMA requests, 3 = no barrier
+#endif
+#ifndef DS_SPLIT_SCALAR_INIT
+#define DS_SPLIT_SCALAR_INIT 0      // 1: the cells' accumulator-initial values with bias / rank-1 rows on the scalar path (lstm_acc_init_tiles) -- measured round 6:
+                                    // 383 against 373 us per step alone, pipelined +- 0 (eight dependent scalar round trips); 0: lstm_acc_init per tile
 #endif
 #ifndef DS_SPLIT_LSTM_SLOTS
 #define DS_SPLIT_LSTM_SLOTS 3
@@ -1101,12 +1170,27 @@ __global__ __launch_bounds__(256, (SplitRing<MTW, NTW, 2, 2, DS_SPLIT_LSTM_SLOTS
     }
     floatx16 acc[MTW][NTW];
     float4 cp[MTW][NTW];
+    {
+        int ntl[NTW], rowc[MTW];
 #pragma unroll
-    for (int i = 0; i < MTW; ++i) {
-        const int row = mt[i] * 32 + r31;
-        const int rowc = row < n ? row : n - 1;
+        for (int j = 0; j < NTW; ++j) ntl[j] = ng * R::FRB + nj * NTW + j;
 #pragma unroll
-        for (int j = 0; j < NTW; ++j) lstm_acc_init(C, (ng * R::FRB + nj * NTW + j) * 8 + 4 * half, rowc, T, acc[i][j]);
+        for (int i = 0; i < MTW; ++i) rowc[i] = min(mt[i] * 32 + r31, n - 1);
+        if (C.xinit) {                                     // wave-uniform: layer 0 behind lstm_xproj_kernel's image (DS_TUNE_LSTM_XPROJ_ALL)
+#pragma unroll
+            for (int i = 0; i < MTW; ++i)
+#pragma unroll
+                for (int j = 0; j < NTW; ++j) lstm_acc_load(C.xinit, mt[i], ntl[j], lane4, acc[i][j]);
+        } else {
+#if DS_SPLIT_SCALAR_INIT
+            lstm_acc_init_tiles<MTW, NTW>(C, ntl, rowc, half, T, acc);
+#else
+#pragma unroll
+            for (int i = 0; i < MTW; ++i)
+#pragma unroll
+                for (int j = 0; j < NTW; ++j) lstm_acc_init(C, ntl[j] * 8 + 4 * half, rowc[i], T, acc[i][j]);
+#endif
+        }
     }
     const bool c_zero = C.c_zero != 0;
 #pragma unroll
@@ -1167,6 +1251,53 @@ __global__ __launch_bounds__(256, (SplitRing<MTW, NTW, 2, 2, DS_SPLIT_LSTM_SLOTS
         printf("CELL block %d of %d cell %d ksteps %d: cycles init %d loop %d gates+stores issued %d stores done %d\n", (int)blockIdx.x, (int)gridDim.x, ci, KS,
                (int)(k1 - k0), (int)(k2 - k1), (int)(k3 - k2), (int)(k4 - k3));
 #endif
+}
+
+// ---- layer 0's accumulator-initial values for every step of both directions, and the first step's cells (ds_internal.h LstmXproj).
+// One wave = one 32-site x 8-unit tile of one (direction, step): lstm_acc_init's arithmetic (the bits a cell would compute itself),
+// stored as the four 1 KiB fragments lstm_acc_load reads back; step 0 (h = 0, c = 0: no matrix product) goes through the gates here
+// and leaves c and the split h image exactly as lstm_cell_split_kernel's epilogue does.
+__global__ __launch_bounds__(256) void lstm_xproj_kernel(const LstmXproj X)
+{
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int dir = blockIdx.z, sidx = blockIdx.y;
+    const int mtile = blockIdx.x >> 3, ntile = (blockIdx.x & 7) * 4 + wave;
+    const int half = lane >> 5, r31 = lane & 31;
+    const unsigned lane4 = (unsigned)lane * 4;
+    const int t = dir == 0 ? sidx : X.T - 1 - sidx;
+    LstmCell C = X.cell[dir];
+    C.t = t;
+    const int row = mtile * 32 + r31;
+    floatx16 acc;
+    lstm_acc_init(C, ntile * 8 + 4 * half, row < X.n ? row : X.n - 1, X.T, acc);
+    if (sidx > 0) {
+        float* const p = X.xinit[dir] + (size_t)t * X.x_step + ((size_t)(mtile * 32 + ntile) * 4) * 256 + lane4;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const v4f o = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
+            *(__attribute__((address_space(1))) v4f*)(p + g * 256) = o;
+        }
+        return;
+    }
+    float4 cn, hn;
+    lstm_gates(acc, make_float4(0.f, 0.f, 0.f, 0.f), cn, hn);
+    const v4f co = {cn.x, cn.y, cn.z, cn.w};
+    *(__attribute__((address_space(1))) v4f*)(C.c + (size_t)mtile * LSTM_MT_FLOATS + (unsigned)ntile * 256 + lane4) = co;
+    uint2 t0, t1, t2;
+    split3x4(hn.x, hn.y, hn.z, hn.w, t0, t1, t2);
+    char* const hb = reinterpret_cast<char*>(C.h_out + (size_t)t * X.h_step) + (size_t)mtile * SPLIT_MT_BYTES + (unsigned)(ntile >> 1) * SPLIT_KSTEP_BYTES +
+                     (unsigned)(((ntile & 1) * 32 + r31) * 16 + half * 8);
+    typedef unsigned int u2v __attribute__((ext_vector_type(2)));
+    *(__attribute__((address_space(1))) u2v*)hb = u2v{t0.x, t0.y};
+    *(__attribute__((address_space(1))) u2v*)(hb + 1024) = u2v{t1.x, t1.y};
+    *(__attribute__((address_space(1))) u2v*)(hb + 2048) = u2v{t2.x, t2.y};
+}
+
+hipError_t launch_lstm_xproj(const LstmXproj& X, hipStream_t s)
+{
+    if (X.n <= 0 || X.mtiles <= 0) return hipSuccess;
+    hipLaunchKernelGGL(lstm_xproj_kernel, dim3(X.mtiles * 8, X.nsteps, 2), dim3(256), 0, s, X);
+    return hipGetLastError();
 }
 
 hipError_t launch_lstm_cells_split(int tile, const LstmLaunch& L, hipStream_t s)

@@ -50,7 +50,7 @@ class DsConfig(ctypes.Structure):
 # ds_config.precision (include/deepsignal_hip.h): "bf16" = bf16 conv + FC operands with fp32 accumulation, fp32 BiLSTM;
 # "bf16_all" = also bf16 h / weight operands in the LSTM matmuls (fp32 accumulate, gates, cell state)
 PRECISIONS = {"fp32": 0, "bf16": 1, "bf16_all": 2, "bf16x3": 3}
-TUNE_NO_FUSED, TUNE_SERIAL, TUNE_DEBUG_STAMPS, TUNE_NO_FOLD_FC, TUNE_NO_CHAIN, TUNE_SHARED_EVENT_STREAM, TUNE_SPLIT_DENSE_NARROW = 1, 2, 4, 8, 16, 32, 64     # ds_config.reserved[2]
+TUNE_NO_FUSED, TUNE_SERIAL, TUNE_DEBUG_STAMPS, TUNE_NO_FOLD_FC, TUNE_NO_CHAIN, TUNE_SHARED_EVENT_STREAM, TUNE_SPLIT_DENSE_NARROW, TUNE_NO_LSTM_XPROJ, TUNE_LSTM_XPROJ_ALL = 1, 2, 4, 8, 16, 32, 64, 128, 256     # ds_config.reserved[2]
 LSTM_TILINGS = {"auto": 0, "narrow": 1, "wide": 2, "lds1": 3, "lds2": 4}     # ds_config.reserved[3]
 
 _lib: Optional[ctypes.CDLL] = None
@@ -136,7 +136,7 @@ class Engine:
                  debug: bool = False, slots: int = 0, precision: str = "fp32", serial: bool = False,
                  no_fused: bool = False, debug_stamps: bool = False, fold_fc: bool = True, lstm_tiling: str = "auto",
                  fuse_max_spt: int = 0, fuse_min_tiles: int = 0, chain_modules: bool = True, shared_event_stream: bool = False,
-                 split_dense_min_n: int = 0, split_dense_narrow: bool = False):
+                 split_dense_min_n: int = 0, split_dense_narrow: bool = False, lstm_xproj=True):
         self._lib = load_library()
         self._h = ctypes.c_void_p()
         if precision not in PRECISIONS:
@@ -151,7 +151,8 @@ class Engine:
         cfg.reserved[2] = (TUNE_NO_FUSED if no_fused else 0) | (TUNE_SERIAL if serial else 0) | \
                           (TUNE_DEBUG_STAMPS if debug_stamps else 0) | (0 if fold_fc else TUNE_NO_FOLD_FC) | \
                           (0 if chain_modules else TUNE_NO_CHAIN) | (TUNE_SHARED_EVENT_STREAM if shared_event_stream else 0) | \
-                          (TUNE_SPLIT_DENSE_NARROW if split_dense_narrow else 0)
+                          (TUNE_SPLIT_DENSE_NARROW if split_dense_narrow else 0) | \
+                          (0 if lstm_xproj else TUNE_NO_LSTM_XPROJ) | (TUNE_LSTM_XPROJ_ALL if lstm_xproj == "all" else 0)
         if lstm_tiling not in LSTM_TILINGS:
             raise ValueError("lstm_tiling must be one of %s" % (sorted(LSTM_TILINGS),))
         cfg.reserved[3] = LSTM_TILINGS[lstm_tiling]

@@ -96,6 +96,13 @@ typedef struct ds_config {
    instead of the 256 x 192 tile with K in 4 / 2 / 1 ranges (by max_batch) whose partial products the head adds up. Same results within
    fp32 summation order. */
 #define DS_TUNE_SPLIT_DENSE_NARROW 64
+/* Diagnostics (same bits out), DS_PRECISION_BF16X3. By default the first step's layer-0 BiLSTM cells (h = 0: no matrix product, only
+   bias + table row + rank-1 terms through the gates; model.py:61-69, layers.py:45-72) are computed by lstm_xproj_kernel, one small
+   launch, instead of a cell-kernel launch of their own (19 -> 18 dependent diagonals). NO_LSTM_XPROJ: the 19 launches of rounds 2 - 5.
+   LSTM_XPROJ_ALL: the kernel also writes layer 0's accumulator-initial values of ALL steps as an image the cells load (measured:
+   142 MB of traffic per 512-site forward cost more in the pipelined step than the cells' own gathers). */
+#define DS_TUNE_NO_LSTM_XPROJ 128
+#define DS_TUNE_LSTM_XPROJ_ALL 256
 /* ds_config.reserved[3] */
 #define DS_LSTM_TILING_AUTO 0    /* by forward size */
 #define DS_LSTM_TILING_NARROW 1  /* one 32-column n-tile per wave  */

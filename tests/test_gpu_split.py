@@ -99,6 +99,33 @@ def test_split_lstm_tile_shapes_give_the_same_bits(small_weights):
         assert np.array_equal(a, outs[0][0]) and np.array_equal(p, outs[0][1])
 
 
+@pytest.mark.parametrize("variant", [dict(), dict(is_base=False), dict(debug=True)])
+def test_lstm_xproj_gives_the_bits_of_the_cells_own_initial_values(small_weights, variant):
+    """lstm_xproj_kernel writes layer 0's accumulator-initial values of all steps (and finishes the first step's cells) in one launch
+    in front of the diagonals; a cell then loads what it used to compute (lstm_acc_init, the same code in both places): the same bits,
+    also with ragged sizes (a padded last m-tile), sub-batches, without the k-mer embedding, and tap by tap in debug mode."""
+    kw = {k: v for k, v in variant.items() if k != "debug"}
+    from deepsignal_amd import weights as W
+    w = small_weights if not kw else W.random_weights(seed=21, lstm_bias_std=0.1, **kw)
+    feats = synth.synthetic_features(1100, seed=907)
+    args = [feats[k] for k in KEYS]
+    outs = []
+    for xp in (True, "all", False):
+        eng = _engine(w, max_batch=1100, slots=1, precision="bf16x3", lstm_xproj=xp, debug=bool(variant.get("debug")), **kw)
+        eng.set_profiling(1)
+        res = [eng.run(*args), eng.run(*(a[:77] for a in args)), eng.run(*(a[:1] for a in args))]
+        ran = {k["name"]: k["launches"] for k in eng.kernel_stats() if k["launches"]}
+        assert ("lstm_xproj_kernel" in ran) == bool(xp), ran
+        if variant.get("debug"):
+            eng.run(*args)
+            res.append(tuple(eng.intermediate("lstm_%s_l%d" % (d, l), (1100, 17, 256)) for d in ("fw", "bw") for l in range(3)))
+        outs.append(res)
+        eng.close()
+    for other in outs[1:]:
+        for a, b in zip(outs[0], other):
+            assert all(np.array_equal(x, y) for x, y in zip(a, b))
+
+
 def test_split_dense_in_ranges_of_k_at_every_forward_size(small_weights):
     """dense(J, J) of the three-step joint model runs a 256 x 192 tile with K in 4 / 2 / 1 ranges by the ENGINE's forward size (64 / 128 /
     256 tiles); head_kernel adds the partial products while it reads its row and the fc1 tap adds them on the host. Every size (ragged
