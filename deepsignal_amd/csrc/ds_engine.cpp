@@ -73,7 +73,7 @@ struct Op {
 
 // per-kernel accumulators (one entry per __global__ function / template instantiation)
 enum KernelClass { K_GEMM_CONV = 0, K_GEMM_FC, K_GEMM_LSTM, K_GEMM_CONV_WIDE, K_GEMM_CONV_POOL, K_GEMM_FC_DENSE, K_GEMM_LSTM_DENSE, K_FUSED1, K_FUSED2, K_FUSED3, K_STEM1, K_MAXPOOL, K_AVGPOOL, K_HEAD,
-                   K_GEMM_BCONV, K_GEMM_BCONV_POOL, K_GEMM_BFC, K_GEMM_BFC_DENSE, K_PACKEV, K_GEMM_BLSTM, K_GEMM_BLSTM_DENSE, K_FUSEDB1, K_FUSEDB2, K_FUSEDB3, K_GEMM_LSTM_T, K_GEMM_LSTM_T_DENSE, K_GEMM_BLSTM_T, K_GEMM_BLSTM_T_DENSE, K_LSTM_CELL1, K_LSTM_CELL2, K_LSTM_CELL4, K_LSTM_LDS1, K_LSTM_LDS2, K_STEM23, K_HEADF, K_LSTM_B11, K_LSTM_B12, K_LSTM_B22, K_STEM23B, K_FUSEDS1, K_FUSEDS2, K_FUSEDS3, K_LSTM_S11, K_LSTM_S12, K_LSTM_S22, K_DENSE_SPLIT, K_STEM23S, K_LSTM_XPROJ, K_COUNT };
+                   K_GEMM_BCONV, K_GEMM_BCONV_POOL, K_GEMM_BFC, K_GEMM_BFC_DENSE, K_PACKEV, K_GEMM_BLSTM, K_GEMM_BLSTM_DENSE, K_FUSEDB1, K_FUSEDB2, K_FUSEDB3, K_GEMM_LSTM_T, K_GEMM_LSTM_T_DENSE, K_GEMM_BLSTM_T, K_GEMM_BLSTM_T_DENSE, K_LSTM_CELL1, K_LSTM_CELL2, K_LSTM_CELL4, K_LSTM_LDS1, K_LSTM_LDS2, K_STEM23, K_HEADF, K_LSTM_B11, K_LSTM_B12, K_LSTM_B22, K_STEM23B, K_FUSEDS1, K_FUSEDS2, K_FUSEDS3, K_LSTM_S11, K_LSTM_S12, K_LSTM_S22, K_DENSE_SPLIT, K_STEM23S, K_LSTM_XPROJ, K_LSTM_S28, K_COUNT };
 const char* const kKernelNames[K_COUNT] = {"gemm_kernel<1,2,4,1,0,0,1,1>", "gemm_kernel<1,3,4,1,0,0,2,1>", "gemm_kernel<1,4,4,1,1,0,1,1>",
                                            "gemm_kernel<2,2,2,2,0,0,1,1>", "gemm_kernel<1,2,4,1,0,1,1,1>", "gemm_kernel<1,3,4,1,0,2,2,1>",
                                            "gemm_kernel<1,4,4,1,1,2,1,1>", "inception_fused_kernel<1>",
@@ -91,7 +91,7 @@ const char* const kKernelNames[K_COUNT] = {"gemm_kernel<1,2,4,1,0,0,1,1>", "gemm
                                            "lstm_cell_bf16_kernel<1,1>", "lstm_cell_bf16_kernel<1,2>", "lstm_cell_bf16_kernel<2,2>", "stem23_bf16_kernel",
                                            "inception_fused_split_kernel<1>", "inception_fused_split_kernel<2>", "inception_fused_split_kernel<3>",
                                            "lstm_cell_split_kernel<1,1>", "lstm_cell_split_kernel<1,2>", "lstm_cell_split_kernel<2,2>",
-                                           "dense_split_kernel (+ pack_joint_split_kernel)", "stem23_split_kernel", "lstm_xproj_kernel"};
+                                           "dense_split_kernel (+ pack_joint_split_kernel)", "stem23_split_kernel", "lstm_xproj_kernel", "lstm_cell_split_kernel<1,2,4,2>"};
 struct KernelStat {
     int64_t launches = 0;
     double total_ms = 0;
@@ -919,7 +919,7 @@ int build_plan(ds_handle* h, int n, Plan* plan)
                        : (n <= 1024 ? 101 : 102);
         const bool lsp = h->split;                                         // split cells (ds_split.hip): tile code 311 | 312 | 322
         const int nt_split = h->lstm_variant == DS_LSTM_TILING_NARROW ? 311 : h->lstm_variant == DS_LSTM_TILING_LDS1 ? 312
-                             : h->lstm_variant == DS_LSTM_TILING_WIDE ? 322 : DS_SPLIT_LSTM_TILE(n);
+                             : h->lstm_variant == DS_LSTM_TILING_WIDE ? 322 : h->lstm_variant == DS_LSTM_TILING_WIDE8 ? 328 : DS_SPLIT_LSTM_TILE(n);
         const size_t step = lsp ? (size_t)h->Bp32 * HID * 3 / 2 : (size_t)h->Bp32 * HU;      // floats of one time step in H (bf16 h: half; split h: 3/2)
         const bool xpj = h->lstm_xproj && lsp;
         const size_t xstep = (size_t)h->Bp32 * 4 * HID;
@@ -975,7 +975,7 @@ int build_plan(ds_handle* h, int n, Plan* plan)
             });
             {   // workgroup tiles per work class, for lstm_logical_tile
                 const int ntc = lsp ? nt_split - 100 : nt;      // the split tiles deal workgroups like the bf16 tiles of the same shape
-                const int per_cell = ntc == 222 ? ((mtiles + 3) / 4) * 8 : ntc == 212 ? ((mtiles + 1) / 2) * 8 : ntc == 211 ? ((mtiles + 1) / 2) * 16
+                const int per_cell = (ntc == 222 || ntc == 228) ? ((mtiles + 3) / 4) * 8 : ntc == 212 ? ((mtiles + 1) / 2) * 8 : ntc == 211 ? ((mtiles + 1) / 2) * 16
                                      : nt > 100 ? ((mtiles + 1) / 2) * (16 / (nt - 100)) : ((mtiles + 3) / 4) * (32 / nt);
                 L.cls_tiles[0] = L.cls_tiles[1] = 0;
                 for (int i = 0; i < L.ncell; ++i) {
@@ -1229,7 +1229,7 @@ int kernel_class(const Op& op)
     case OP_PACKEV: return K_PACKEV;
     case OP_DENSES: return K_DENSE_SPLIT;
     case OP_XPROJ: return K_LSTM_XPROJ;
-    case OP_LSTM: if (op.c >= 300) return op.c == 311 ? K_LSTM_S11 : op.c == 312 ? K_LSTM_S12 : K_LSTM_S22;
+    case OP_LSTM: if (op.c >= 300) return op.c == 311 ? K_LSTM_S11 : op.c == 312 ? K_LSTM_S12 : op.c == 328 ? K_LSTM_S28 : K_LSTM_S22;
         return op.c == 1 ? K_LSTM_CELL1 : op.c == 2 ? K_LSTM_CELL2 : op.c == 4 ? K_LSTM_CELL4 : op.c == 101 ? K_LSTM_LDS1
                : op.c == 211 ? K_LSTM_B11 : op.c == 212 ? K_LSTM_B12 : op.c == 222 ? K_LSTM_B22 : K_LSTM_LDS2;
     }

@@ -817,19 +817,20 @@ constexpr int SPLIT_MT_BYTES = 16 * SPLIT_KSTEP_BYTES;    // one m-tile of a spl
 // WM x WN waves (= 4), each MTW x NTW tiles of 32 x 32; NSLOT ring slots: stage st + NSLOT - 1 is requested while stage st is consumed
 template <int MTW, int NTW, int WM = 2, int WN = 2, int NSLOT = 3>
 struct SplitRing {
-    static_assert(WM * WN == 4, "four waves per workgroup");
-    static_assert(NSLOT >= 3 && (NSLOT - 2) * ((3 * (WM * MTW + WN * NTW) + 3) / 4) <= 63, "vmcnt holds six bits");
+    static constexpr int NW = WM * WN;                       // waves per workgroup: 4, or 8 (two per SIMD: one wave's waits and requests under the other's MFMAs)
+    static_assert(NW == 4 || NW == 8, "four or eight waves per workgroup");
+    static_assert(NSLOT >= 3 && (NSLOT - 2) * ((3 * (WM * MTW + WN * NTW) + NW - 1) / NW) <= 63, "vmcnt holds six bits");
     static constexpr int FRA = WM * MTW, FRB = WN * NTW;
     static constexpr int NF1 = 3 * (FRA + FRB);              // 1 KiB fragments per k-step
     // k-steps per ring stage: one barrier per KGS k-steps. DS_SPLIT_KGS11 / DS_SPLIT_KGS22: measured choices for the 64 x 64 and the
     // 128 x 128 tile. The fragments of a stage are dealt to the four waves round robin; where NF is not a multiple of 4 (the 64 x 128
-    // tile: 18) waves 0 .. NF % 4 - 1 request one more than the others and wait with a count of their own.
+    // tile: 18) waves 0 .. NF % NW - 1 request one more than the others and wait with a count of their own.
     static constexpr int KGS = (MTW == 1 && NTW == 1) ? DS_SPLIT_KGS11 : (MTW == 2 && NTW == 2) ? DS_SPLIT_KGS22 : 1;
     static constexpr int NF = KGS * NF1;
-    static constexpr int LPS = (NF + 3) / 4;                 // LDS-DMA requests per wave and stage (waves >= NF % 4: one fewer if NF % 4)
+    static constexpr int LPS = (NF + NW - 1) / NW;                 // LDS-DMA requests per wave and stage (waves >= NF % NW: one fewer if NF % NW)
     static constexpr int STAGE = NF * 256;                   // floats
     // (piped loop: waves with one fragment fewer send a filler request into a pad, so that every wave counts the same vmcnt)
-    static constexpr int PAD_BYTES = (DS_SPLIT_PIPED && NF % 4 != 0) ? 4096 : 0;
+    static constexpr int PAD_BYTES = (DS_SPLIT_PIPED && NF % NW != 0) ? NW * 1024 : 0;
     static constexpr size_t LDS_BYTES = (size_t)NSLOT * STAGE * 4 + PAD_BYTES;
 #ifndef DS_RING_CLOCK
 #define DS_RING_CLOCK 0       // 1: s_memtime around the piped loop's wait / barrier / requests / rest, printed by two workgroups of the dense kernel
@@ -859,7 +860,7 @@ struct SplitRing {
         dseg = (a1 - a0) - (long)s0_ * SPLIT_KSTEP_BYTES;
 #pragma unroll
         for (int j = 0; j < LPS; ++j) {
-            const int q = min(wave_ + 4 * j, NF - 1), kgi = q / NF1, f = q - kgi * NF1;       // (q >= NF: never requested)
+            const int q = min(wave_ + NW * j, NF - 1), kgi = q / NF1, f = q - kgi * NF1;       // (q >= NF: never requested)
             kgi_[j] = kgi;
             is_a[j] = f < 3 * FRA;
             if (f < 3 * FRA) {
@@ -877,10 +878,10 @@ struct SplitRing {
         const unsigned dst = __builtin_amdgcn_readfirstlane(ring_lds + (slot * STAGE + wave * 256) * 4);
 #pragma unroll
         for (int j = 0; j < LPS; ++j) {
-            if (NF % 4 != 0 && j == LPS - 1 && wave >= NF % 4) break;      // wave-uniform: this wave has no fragment 4 j + wave
+            if (NF % NW != 0 && j == LPS - 1 && wave >= NF % NW) break;      // wave-uniform: this wave has no fragment 4 j + wave
             const int ks = st * KGS + kgi_[j];
             const long off = (long)st * (KGS * SPLIT_KSTEP_BYTES) + ((is_a[j] && ks >= s0) ? dseg : 0);
-            glds16s(src[j] + off, lane16, dst + j * 4096);      // fragment q = wave + 4 j of the stage
+            glds16s(src[j] + off, lane16, dst + j * (NW * 1024));      // fragment q = wave + 4 j of the stage
         }
     }
     // ---- piped loop, requests: the source of request J is (wave-uniform base rs[J]) + (lane offset + stage offset, ONE vector add per
@@ -899,8 +900,8 @@ struct SplitRing {
     template <int J>
     __device__ __forceinline__ void request3(unsigned voff, unsigned rdst) const
     {
-        unsigned dst = rdst + J * 4096;
-        if (NF % 4 != 0 && J == LPS - 1 && wave >= NF % 4) dst = ring_lds + NSLOT * STAGE * 4 + wave * 1024;
+        unsigned dst = rdst + J * (NW * 1024);
+        if (NF % NW != 0 && J == LPS - 1 && wave >= NF % NW) dst = ring_lds + NSLOT * STAGE * 4 + wave * 1024;
         asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(rs[J]), "s"(dst) : "memory");      // (m0: saved and restored around the run of requests by the caller; hipcc rejects m0 as a clobber -- "reserved register" -- so tests/test_kernel_resources.py holds what the save/restore relies on: no SGPR spill, hence no compiler use of m0, in these kernels)
     }
     template <int J>
@@ -927,12 +928,12 @@ struct SplitRing {
         for (int s = 0; s < NSLOT - 1; ++s)
             if (DS_RING_BISECT != 2 && DS_RING_BISECT != 4 && s < nstages) request(s, s);
     }
-    // wait until all but the last K stages requested have landed (this wave's share; waves >= NF % 4 request one fragment fewer)
+    // wait until all but the last K stages requested have landed (this wave's share; waves >= NF % NW request one fragment fewer)
     template <int K>
     __device__ __forceinline__ void wait_but(int later) const
     {
         if (later >= K) {
-            if (NF % 4 == 0 || wave < NF % 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(K * LPS) : "memory");
+            if (NF % NW == 0 || wave < NF % NW) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(K * LPS) : "memory");
             else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(K * (LPS - 1)) : "memory");
         } else if constexpr (K > 0) wait_but<K - 1>(later);
     }
@@ -1130,14 +1131,14 @@ struct SplitRing {
 // ---- the BiLSTM cells of one wavefront diagonal (layers.py:45-72), split operands: h and the weights in three bf16 terms, six
 // products per MAC, fp32 accumulate; the layer-0 table row / rank-1 terms, the gates and the cell state are fp32 as in the fp32
 // kernel (lstm_acc_init / lstm_gates are shared with it); h is split once, in the epilogue that produces it.
-template <int MTW, int NTW>
-__global__ __launch_bounds__(256, (SplitRing<MTW, NTW, 2, 2, DS_SPLIT_LSTM_SLOTS>::LDS_BYTES > 80 * 1024) ? 1 : 2) void lstm_cell_split_kernel(const LstmLaunch L_)
+template <int MTW, int NTW, int WM = 2, int WN = 2>
+__global__ __launch_bounds__(64 * WM * WN, (SplitRing<MTW, NTW, WM, WN, DS_SPLIT_LSTM_SLOTS>::LDS_BYTES > 80 * 1024) ? 1 : 2) void lstm_cell_split_kernel(const LstmLaunch L_)
 {
     const LstmLaunch* const Lp = &L_;
-    typedef SplitRing<MTW, NTW, 2, 2, DS_SPLIT_LSTM_SLOTS> R;
+    typedef SplitRing<MTW, NTW, WM, WN, DS_SPLIT_LSTM_SLOTS> R;
     extern __shared__ __attribute__((aligned(16))) float ring[];    // [NSLOT * STAGE]
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int mi = wave & 1, nj = wave >> 1;
+    const int mi = wave % WM, nj = wave / WM;
     const int bid = lstm_logical_tile(blockIdx.x, gridDim.x, Lp->cls_tiles[0], Lp->cls_tiles[1]);
     const int mtiles = Lp->mtiles;
     const int mblocks = (mtiles + R::FRA - 1) / R::FRA;
@@ -1308,6 +1309,8 @@ hipError_t launch_lstm_cells_split(int tile, const LstmLaunch& L, hipStream_t s)
     case 11: hipLaunchKernelGGL((lstm_cell_split_kernel<1, 1>), dim3(ncell * ((mtiles + 1) / 2) * 16), dim3(256), (SplitRing<1, 1, 2, 2, DS_SPLIT_LSTM_SLOTS>::LDS_BYTES), s, L); break;
     case 12: hipLaunchKernelGGL((lstm_cell_split_kernel<1, 2>), dim3(ncell * ((mtiles + 1) / 2) * 8), dim3(256), (SplitRing<1, 2, 2, 2, DS_SPLIT_LSTM_SLOTS>::LDS_BYTES), s, L); break;
     case 22: hipLaunchKernelGGL((lstm_cell_split_kernel<2, 2>), dim3(ncell * ((mtiles + 3) / 4) * 8), dim3(256), (SplitRing<2, 2, 2, 2, DS_SPLIT_LSTM_SLOTS>::LDS_BYTES), s, L); break;
+    // the same 128 x 128 workgroup tile by EIGHT waves (4 x 2, each 32 x 64): two waves per SIMD of the one workgroup a CU holds
+    case 28: hipLaunchKernelGGL((lstm_cell_split_kernel<1, 2, 4, 2>), dim3(ncell * ((mtiles + 3) / 4) * 8), dim3(512), (SplitRing<1, 2, 4, 2, DS_SPLIT_LSTM_SLOTS>::LDS_BYTES), s, L); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
@@ -1455,9 +1458,9 @@ static bool split_chain_ok(const FusedChain& c)
 
 hipError_t configure_split_kernels()
 {
-    const void* fns[9] = {(const void*)dense_split_kernel<4, 3, 2, 2>, (const void*)stem23_split_kernel, (const void*)inception_fused_split_kernel<1>, (const void*)inception_fused_split_kernel<2>,
+    const void* fns[10] = {(const void*)dense_split_kernel<4, 3, 2, 2>, (const void*)stem23_split_kernel, (const void*)inception_fused_split_kernel<1>, (const void*)inception_fused_split_kernel<2>,
                           (const void*)inception_fused_split_kernel<3>, (const void*)lstm_cell_split_kernel<1, 1>,
-                          (const void*)lstm_cell_split_kernel<1, 2>, (const void*)lstm_cell_split_kernel<2, 2>,
+                          (const void*)lstm_cell_split_kernel<1, 2>, (const void*)lstm_cell_split_kernel<2, 2>, (const void*)lstm_cell_split_kernel<1, 2, 4, 2>,
                           (const void*)dense_split_kernel<1, 3, 4, 1>};
     for (const void* f : fns) {
         const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

@@ -51,7 +51,7 @@ class DsConfig(ctypes.Structure):
 # "bf16_all" = also bf16 h / weight operands in the LSTM matmuls (fp32 accumulate, gates, cell state)
 PRECISIONS = {"fp32": 0, "bf16": 1, "bf16_all": 2, "bf16x3": 3}
 TUNE_NO_FUSED, TUNE_SERIAL, TUNE_DEBUG_STAMPS, TUNE_NO_FOLD_FC, TUNE_NO_CHAIN, TUNE_SHARED_EVENT_STREAM, TUNE_SPLIT_DENSE_NARROW, TUNE_NO_LSTM_XPROJ, TUNE_LSTM_XPROJ_ALL = 1, 2, 4, 8, 16, 32, 64, 128, 256     # ds_config.reserved[2]
-LSTM_TILINGS = {"auto": 0, "narrow": 1, "wide": 2, "lds1": 3, "lds2": 4}     # ds_config.reserved[3]
+LSTM_TILINGS = {"auto": 0, "narrow": 1, "wide": 2, "lds1": 3, "lds2": 4, "wide8": 5}     # ds_config.reserved[3]
 
 _lib: Optional[ctypes.CDLL] = None
 

@@ -109,6 +109,7 @@ typedef struct ds_config {
 #define DS_LSTM_TILING_WIDE 2    /* four n-tiles per wave          */
 #define DS_LSTM_TILING_LDS1 3    /* fp32 cells: operands shared through LDS, 64 x 64 workgroup tile  */
 #define DS_LSTM_TILING_LDS2 4    /* fp32 cells: operands shared through LDS, 64 x 128 workgroup tile */
+#define DS_LSTM_TILING_WIDE8 5   /* DS_PRECISION_BF16X3 cells: the 128 x 128 workgroup tile by eight waves (two per SIMD) instead of four */
 
 /* Replaces Model(...) + tf.Session(): call_modifications.py:203-209. */
 int ds_create(const ds_config *cfg, ds_handle **out);

@@ -86,12 +86,12 @@ def test_split_chain_gives_the_bits_of_one_launch_per_module(small_weights):
 
 
 def test_split_lstm_tile_shapes_give_the_same_bits(small_weights):
-    """lstm_cell_split_kernel runs 64 x 64, 64 x 128 or 128 x 128 workgroup tiles: every shape accumulates a unit's K in the same order,
-    so a site's bits do not depend on the tile -- also with an odd number of 32-site m-tiles."""
+    """lstm_cell_split_kernel runs 64 x 64, 64 x 128 or 128 x 128 workgroup tiles, the last by four or by eight waves: every shape accumulates a
+    unit's K in the same order, so a site's bits do not depend on the tile -- also with an odd number of 32-site m-tiles."""
     feats = synth.synthetic_features(1100, seed=906)
     args = [feats[k] for k in KEYS]
     outs = []
-    for tiling in ("narrow", "lds1", "wide"):
+    for tiling in ("narrow", "lds1", "wide", "wide8"):
         eng = _engine(small_weights, max_batch=1100, slots=1, precision="bf16x3", lstm_tiling=tiling)
         outs.append(eng.run(*args))
         eng.close()
