@@ -752,7 +752,13 @@ def main():
         "windows": {"n": len(windows), "steps_each": K, "statistic": "median",
                     "sites_per_s": [round(world * K * BATCH / x, 1) for x in windows] if K else [],
                     "min": round(world * K * BATCH / max(windows), 1) if K else 0.0,
-                    "max": round(world * K * BATCH / min(windows), 1) if K else 0.0},
+                    "max": round(world * K * BATCH / min(windows), 1) if K else 0.0,
+                    #  what a window is, so that a 20-step and a 400-step run of one library are not read as two results
+                    "boundary": "inputs resident in HBM: ds_forward_device, K forwards issued back to back over the engine's slots (up to 8 in "
+                                "flight), barrier + synchronize on both sides; a window carries ONE pipeline fill and drain (about one step): "
+                                "~4 % of a 20-step window, 0.2 % of a 400-step one -- the same library reads 406 - 409 k sites/s with --steps 20 "
+                                "and 415 - 418 k with the default 400 on one box (profiles/r06_item3_r04_vs_head.json). The host-inclusive "
+                                "rates ride along in pcie_inclusive / ds_forward_blocking / e2e_tsv"},
     }
     if not args.dry_run and _engine_mod.LIBRARY_OVERRIDE:
         result["library_override"] = _engine_mod.LIBRARY_OVERRIDE       # DS_HIP_LIBRARY was set: NOT the in-tree product library
