@@ -163,76 +163,6 @@ __device__ __forceinline__ void lstm_acc_init(const LstmCell& C, int p8, int row
     }
 }
 
-// The same initial values for all the tiles of a wave (MTW m-tiles x NTW n-tiles), with everything that does not depend on the site --
-// bias and the three rank-1 weight rows: per gate eight consecutive floats per n-tile, the same for all 32 sites of a lane half -- on the
-// SCALAR path (s_load_dwordx8 + one select per value) instead of a 16-byte load per lane through the texture path: a 128 x 128 split
-// cell tile otherwise asks for ~80 float4 per lane in front of its K loop, all of them L2-hot lines every workgroup of the launch wants
-// at the same moment (16 - 24 k cycles for a layer-0 cell, 6 - 15 k for the others: DESIGN.md 11). What stays on the vector path is what
-// depends on the site: its code and three features, and its table row. Same fma chains, same order: lstm_acc_init's bits.
-typedef float f8v __attribute__((ext_vector_type(8)));
-__device__ __forceinline__ float4 sload_half(const float* p_uniform, bool hi)
-{
-    const f8v v = *(const __attribute__((address_space(4))) f8v*)(p_uniform);
-    float e[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {      // pinned to SGPRs: hipcc otherwise folds the select into the ADDRESS and loads dword by dword through the vector path
-        e[k] = v[k];
-        asm volatile("" : "+s"(e[k]));
-    }
-    return hi ? make_float4(e[4], e[5], e[6], e[7]) : make_float4(e[0], e[1], e[2], e[3]);
-}
-template <int MTW, int NTW>
-__device__ __forceinline__ void lstm_acc_init_tiles(const LstmCell& C, const int (&ntile)[NTW], const int (&rowc)[MTW], int half, int T, floatx16 (&acc)[MTW][NTW])
-{
-    const bool hi = half != 0;
-    if (!C.use_feat) {                                   // wave-uniform
-#pragma unroll
-        for (int j = 0; j < NTW; ++j)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                float4 z = sload_half(C.bias + g * 256 + ntile[j] * 8, hi);
-                if (g == 2) { z.x += 1.0f; z.y += 1.0f; z.z += 1.0f; z.w += 1.0f; }
-#pragma unroll
-                for (int i = 0; i < MTW; ++i) { acc[i][j][4 * g] = z.x; acc[i][j][4 * g + 1] = z.y; acc[i][j][4 * g + 2] = z.z; acc[i][j][4 * g + 3] = z.w; }
-            }
-        return;
-    }
-    const float* tab = C.table;
-    float f0[MTW], f1[MTW], f2[MTW];
-    const float* trow[MTW];
-#pragma unroll
-    for (int i = 0; i < MTW; ++i) {
-        const unsigned it = (unsigned)rowc[i] * T + C.t;
-        f0[i] = gload(C.means + it); f1[i] = gload(C.stds + it); f2[i] = gload(C.lens + it);
-        const int code = tab ? min(max(*(const __attribute__((address_space(1))) int*)(C.codes + it), 0), 1023) : 0;
-        trow[i] = tab ? tab + (size_t)code * 1024 + 4 * half : C.bias;
-    }
-    float4 tb[MTW][NTW][4];
-#pragma unroll
-    for (int i = 0; i < MTW; ++i)
-#pragma unroll
-        for (int j = 0; j < NTW; ++j)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) tb[i][j][g] = gload4(trow[i] + g * 256 + ntile[j] * 8);
-#pragma unroll
-    for (int j = 0; j < NTW; ++j)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int col = g * 256 + ntile[j] * 8;
-            float4 zb = sload_half(C.bias + col, hi);
-            const float4 w0 = sload_half(C.wfeat + col, hi), w1 = sload_half(C.wfeat + 1024 + col, hi), w2 = sload_half(C.wfeat + 2048 + col, hi);
-            if (g == 2) { zb.x += 1.0f; zb.y += 1.0f; zb.z += 1.0f; zb.w += 1.0f; }
-#pragma unroll
-            for (int i = 0; i < MTW; ++i) {
-                float4 x = make_float4(fmaf(f2[i], w2.x, fmaf(f1[i], w1.x, f0[i] * w0.x)), fmaf(f2[i], w2.y, fmaf(f1[i], w1.y, f0[i] * w0.y)),
-                                       fmaf(f2[i], w2.z, fmaf(f1[i], w1.z, f0[i] * w0.z)), fmaf(f2[i], w2.w, fmaf(f1[i], w1.w, f0[i] * w0.w)));
-                if (tab) { x.x += tb[i][j][g].x; x.y += tb[i][j][g].y; x.z += tb[i][j][g].z; x.w += tb[i][j][g].w; }
-                acc[i][j][4 * g] = zb.x + x.x; acc[i][j][4 * g + 1] = zb.y + x.y; acc[i][j][4 * g + 2] = zb.z + x.z; acc[i][j][4 * g + 3] = zb.w + x.w;
-            }
-            __builtin_amdgcn_sched_barrier(0);      // one gate's scalar operands (32 SGPRs) in flight: hoisted all together they spill
-        }
-}
-
 // The same initial value from lstm_xproj_kernel's image: tile (mtile, ntile) = four 1 KiB wave loads
 __device__ __forceinline__ void lstm_acc_load(const float* xinit, int mtile, int ntile, unsigned lane4, floatx16& acc)
 {

@@ -782,9 +782,6 @@ __global__ __launch_bounds__(256, NT == 1 ? 5 : 2) void lstm_cell_lds_kernel(con
 //     contiguous bytes. c keeps the fp32 kernels' fragment-major layout.
 // Roofline: HBM / L2 (operand delivery). Algorithmic FLOPs per launch = sum over cells of 2 * n * 1024 * K.
 constexpr int LSTM_MT_BYTES_BF16 = 32 * 256 * 2;      // one m-tile of a bf16 fragment-major h buffer
-#ifndef DS_BF16_LSTM_PIPED
-#define DS_BF16_LSTM_PIPED 0      // 1: the register-piped, pinned K loop of the split ring kernels (measured round 6)
-#endif
 template <int MTW, int NTW>
 __global__ __launch_bounds__(256, MTW * NTW >= 4 ? 2 : 3) void lstm_cell_bf16_kernel(const LstmLaunch L_)
 {
@@ -900,92 +897,9 @@ __global__ __launch_bounds__(256, MTW * NTW >= 4 ? 2 : 3) void lstm_cell_bf16_ke
 
     const float* const fa0 = ring + (mi * MTW) * 256 + lane4;
     const float* const fb0 = ring + (FRA + nj * NTW) * 256 + lane4;
-#if DS_BF16_LSTM_PIPED
-    // SplitRing::run_piped's loop (ds_split.hip) on this kernel's ring -- VERDICT r05 item 2: a stage's fragments double-buffered in
-    // registers; iteration st waits until stage st + 1 has landed, passes the barrier (everybody has READ stage st: its slot is free),
-    // and runs a sequence pinned instruction by instruction: MFMA m of stage st, behind it LDS read m of stage st + 1, and after every
-    // second MFMA one LDS-DMA request of stage st + 3 (wave-uniform base + ONE vector offset per stage, m0 set per request). Past the
-    // last stage the requests repeat it into the slot just freed (no branch). The MFMAs of an accumulator keep their order: same bits.
-    {
-        constexpr int NM = KGS * MTW * NTW, NRD = KGS * (MTW + NTW);
-        const char* rs[LPS];
-#pragma unroll
-        for (int j = 0; j < LPS; ++j) rs[j] = src[j];
-        bool in_seg1 = false;
-        auto stage_voff = [&](int sreq) __attribute__((always_inline)) -> unsigned {
-            if (!in_seg1 && sreq * KGS >= 16 && dseg != 0) {      // (16 k-steps of x rows = 8 stages: a stage never straddles the two segments)
-#pragma unroll
-                for (int j = 0; j < LPS; ++j) if (is_a[j]) rs[j] += dseg;
-                in_seg1 = true;
-            }
-            return lane16 + (unsigned)sreq * (KGS * 1024);
-        };
-        auto req = [&](int j, unsigned voff, unsigned dst) __attribute__((always_inline)) {
-            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(rs[j]), "s"(dst + j * 4096) : "memory");
-        };
-        typedef float4 Frag[KGS][MTW + NTW];
-        auto read_all = [&](int slot, Frag& f) __attribute__((always_inline)) {
-#pragma unroll
-            for (int kgi = 0; kgi < KGS; ++kgi) {
-#pragma unroll
-                for (int i = 0; i < MTW; ++i) f[kgi][i] = *reinterpret_cast<const float4*>(fa0 + slot * STAGE + (kgi * FR + i) * 256);
-#pragma unroll
-                for (int j = 0; j < NTW; ++j) f[kgi][MTW + j] = *reinterpret_cast<const float4*>(fb0 + slot * STAGE + (kgi * FR + j) * 256);
-            }
-        };
-        unsigned keep_m0;
-        asm volatile("s_mov_b32 %0, m0" : "=s"(keep_m0));
-        // (the two stages requested above came through glds16s; stage 2 completes the three slots)
-        if (nstages > 0) {
-            const unsigned v2 = stage_voff(min(2, nstages - 1));
-#pragma unroll
-            for (int j = 0; j < LPS; ++j) req(j, v2, __builtin_amdgcn_readfirstlane(ring_lds + (2 * STAGE + wave * 256) * 4));
-            if (nstages == 1) { const unsigned v1 = stage_voff(0);
-#pragma unroll
-                for (int j = 0; j < LPS; ++j) req(j, v1, __builtin_amdgcn_readfirstlane(ring_lds + (1 * STAGE + wave * 256) * 4)); }
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPS) : "memory");
-            __builtin_amdgcn_s_barrier();
-            Frag f0, f1;
-            read_all(0, f0);
-            auto piped = [&](int st, int slot, const Frag& cur, Frag& nxt) __attribute__((always_inline)) {
-                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(LPS) : "memory");
-                __builtin_amdgcn_s_barrier();
-                const unsigned voff = stage_voff(min(st + 3, nstages - 1));
-                const unsigned rdst = __builtin_amdgcn_readfirstlane(ring_lds + (slot * STAGE + wave * 256) * 4);
-                const int nslot = slot + 1 == 3 ? 0 : slot + 1;
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int m = 0; m < NM; ++m) {
-                    const int kgi = m / (MTW * NTW), i = (m % (MTW * NTW)) / NTW, j = m % NTW;
-                    acc[i][j] = mfma_bf_early(cur[kgi][MTW + j], cur[kgi][i], acc[i][j]);
-                    if (m < NRD) {
-                        const int rk = m / (MTW + NTW), rf = m % (MTW + NTW);
-                        nxt[rk][rf] = *reinterpret_cast<const float4*>((rf < MTW ? fa0 + (rk * FR + rf) * 256 : fb0 + (rk * FR + rf - MTW) * 256) + nslot * STAGE);
-                    }
-                    if (m % 2 == 1 && m / 2 < LPS) req(m / 2, voff, rdst);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                // (the narrow tiles have fewer MFMAs per stage than fragments to read / requests to send: the rest follows the sequence)
-#pragma unroll
-                for (int m = NM; m < NRD; ++m) {
-                    const int rk = m / (MTW + NTW), rf = m % (MTW + NTW);
-                    nxt[rk][rf] = *reinterpret_cast<const float4*>((rf < MTW ? fa0 + (rk * FR + rf) * 256 : fb0 + (rk * FR + rf - MTW) * 256) + nslot * STAGE);
-                }
-#pragma unroll
-                for (int j = NM / 2; j < LPS; ++j) req(j, voff, rdst);
-                __builtin_amdgcn_sched_barrier(0);
-            };
-            int slot = 0, st = 0;
-            for (int p2 = 0; p2 < (nstages >> 1); ++p2) {
-                piped(st, slot, f0, f1); ++st; slot = slot + 1 == 3 ? 0 : slot + 1;
-                piped(st, slot, f1, f0); ++st; slot = slot + 1 == 3 ? 0 : slot + 1;
-            }
-            if (nstages & 1) piped(st, slot, f0, f1);
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        }
-        asm volatile("s_mov_b32 m0, %0" ::"s"(keep_m0));
-    }
-#else
+    // (SplitRing::run_piped's register-piped, pinned K loop -- ds_split.hip -- was built into this kernel in round 6, git 5dac46d: bit-identical,
+    // 715 - 722 against 689 - 693 us per 4,096-site step, 159 against 163 us at 512; at 2 - 3 workgroups per CU the other waves already fill the
+    // gaps that order closes for the one-wave-per-SIMD split kernels: profiles/r06_bf16_lstm_piped.json)
     auto stage = [&](int st, auto slot_c) __attribute__((always_inline)) {
         constexpr int SLOT = decltype(slot_c)::value;
         if (st + 1 < nstages) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
@@ -1010,7 +924,6 @@ __global__ __launch_bounds__(256, MTW * NTW >= 4 ? 2 : 3) void lstm_cell_bf16_ke
         stage(st, LdsSlot<1>{}); if (++st >= nstages) break;
         stage(st, LdsSlot<2>{}); ++st;
     }
-#endif
     DS_LSTAMP(3, __builtin_amdgcn_s_memtime());
 
     // ---- gates (fp32), new state; c fragment-major fp32, h fragment-major bf16 (8 bytes per lane), optional row-major fp32 h

@@ -804,10 +804,6 @@ constexpr int SPLIT_MT_BYTES = 16 * SPLIT_KSTEP_BYTES;    // one m-tile of a spl
 #ifndef DS_RING_BISECT
 #define DS_RING_BISECT 0      // timing experiments only (results WRONG): 4 = no K loop at all; with DS_SPLIT_PIPED=0 also 1 = no MFMAs, 2 = no LDS-DMA requests, 3 = no barrier
 #endif
-#ifndef DS_SPLIT_SCALAR_INIT
-#define DS_SPLIT_SCALAR_INIT 0      // 1: the cells' accumulator-initial values with bias / rank-1 rows on the scalar path (lstm_acc_init_tiles) -- measured round 6:
-                                    // 383 against 373 us per step alone, pipelined +- 0 (eight dependent scalar round trips); 0: lstm_acc_init per tile
-#endif
 #ifndef DS_SPLIT_LSTM_SLOTS
 #define DS_SPLIT_LSTM_SLOTS 3
 #endif
@@ -1183,14 +1179,12 @@ __global__ __launch_bounds__(64 * WM * WN, (SplitRing<MTW, NTW, WM, WN, DS_SPLIT
 #pragma unroll
                 for (int j = 0; j < NTW; ++j) lstm_acc_load(C.xinit, mt[i], ntl[j], lane4, acc[i][j]);
         } else {
-#if DS_SPLIT_SCALAR_INIT
-            lstm_acc_init_tiles<MTW, NTW>(C, ntl, rowc, half, T, acc);
-#else
+            // (bias and the rank-1 rows on the SCALAR path -- s_load_dwordx8 + selects instead of ~80 L2-hot float4 per lane -- was built and
+            // measured in round 6, git 755c1c9: 383 against 373 us per step alone, pipelined +- 0: eight dependent scalar round trips)
 #pragma unroll
             for (int i = 0; i < MTW; ++i)
 #pragma unroll
                 for (int j = 0; j < NTW; ++j) lstm_acc_init(C, ntl[j] * 8 + 4 * half, rowc[i], T, acc[i][j]);
-#endif
         }
     }
     const bool c_zero = C.c_zero != 0;
