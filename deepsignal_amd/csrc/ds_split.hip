@@ -65,8 +65,10 @@ __device__ __forceinline__ floatx16 mfma3_hi(const float4 (&w)[3], float4 a0, fl
 //       64-channel intermediate goes to LDS as terms as well (T2); its last 1x1 accumulates on top of the stem accumulators.
 // LDS (bytes): staged chunks 2 x rows x 208 (later the fp32 b1|b2 output tile) | T2 rows x 400 (raw chunks during P1) | T1
 // (spt (W + 4) + 5) x 592: 143 - 147 KB for 96-row tiles, one workgroup per CU. Every row stride is an odd number of 16-byte slots.
-// What bounds it: P1's staging work on the CU itself (26 k of its 31.5 k cycles per module remain with every global load removed;
-// 18.4 k are MFMA), the dependent phases of one workgroup per CU in P2.
+// What bounds it (round 6, profiles/r06_chain_p1_experiments.md): a P1 step takes ~1,660 cycles for 1,152 of MFMA; barrier, transform
+// arithmetic and staged writes each cost nothing when removed alone, the 30 KiB of weight fragments and rows a step asks the L2 for do
+// (18 B/clk per CU against 26 at full matrix rate), and eight re-orderings of the step's work all took the same time. Per module 47 - 53 k
+// cycles: P1 25 k in its loop + 4.5 - 8 k of start-up, P1 epilogue + barrier 6 - 7.7 k, P2 11.6 k (7.7 k of MFMA).
 constexpr int S_LDP = 208;      // staged chunk row: 6 x 32 B + 16
 constexpr int S_LD1 = 592;      // T1 row: 3 terms x 96 channels x 2 B + 16
 constexpr int S_LD2 = 400;      // T2 row: 3 terms x 64 channels x 2 B + 16
@@ -782,10 +784,12 @@ hipError_t launch_stem23_split(const Stem23Args& a, hipStream_t s)
 //     [m-tile of 32 rows][k-step of 16][term][64 lanes][8 bf16]      (lane (r, half) holds k = 16 s + 8 half .. + 7 of row 32 m + r),
 // which is what a cell's epilogue writes for h (split once, where it is produced) and what pack_joint_split_kernel writes for the
 // joint row; the weights are pack_b_split's panels [n-tile][k-step][term][64][8].
-// One workgroup per CU means one wave per SIMD: what bounded these kernels was the wave's own instruction stream (hipcc's
-// read -> wait -> MFMA schedule, the requests' issue time in front of the MFMAs), not what a CU can take in -- SplitRing::run_piped
-// and DESIGN.md section 11. The split cells use the 128 x 128 tile (0.25 KiB per MFMA): slower alone than 64 x 64, faster in the
-// pipelined step, which rewards bytes.
+// One workgroup per CU means one wave per SIMD: hipcc's read -> wait -> MFMA schedule and the requests' issue time in front of the
+// MFMAs cost these kernels 12 - 25 % until SplitRing::run_piped pinned the order (round 5). What bounds them since is what a CU takes in
+// from the L2 (round 6): at full matrix rate a tile asks for 2048 (M + N) / (M N) B/clk -- 32 at 128 x 128, where
+// the cells move 23; 18.7 at 256 x 192, where the dense is bound by the matrix pipe -- and the same 128 x 128 tile by EIGHT waves (two per
+// SIMD, WM x WN = 4 x 2) takes the same time. The split cells use the 128 x 128 tile: slower alone than 64 x 64, faster in the pipelined step;
+// 128 x 256 (24 B/clk, half the workgroups, 108 KB rings) is 5 % slower there.
 constexpr int SPLIT_KSTEP_BYTES = 3 * 1024;               // the three term fragments of one k-step
 constexpr int SPLIT_MT_BYTES = 16 * SPLIT_KSTEP_BYTES;    // one m-tile of a split h buffer (256 units = 16 k-steps)
 
